@@ -1,0 +1,175 @@
+/*
+ * gangfit.h — C ABI of libgangfit, the MI355X-native gang-scheduling bin-packer.
+ *
+ * Drop-in boundary for ONE hot path of palantir/k8s-spark-scheduler: the gang-fit decision
+ * (1 driver + K executors, 3-D cpu/mem/gpu, against a snapshot of per-node free capacity) behind the reference's
+ * plug-in seam `binpack.SparkBinPackFunction`.  Everything here is what a cgo shim in the reference tree binds
+ * (INTEGRATION.md shows that shim).  File:line citations are relative to the reference repository;
+ * LIB = vendor/github.com/palantir/k8s-spark-scheduler-lib/pkg.
+ *
+ * Conventions
+ *   - Node identity crosses the boundary as a dense uint32 index into the snapshot arrays; the caller owns the
+ *     name<->index table.  An index >= n_nodes inside an order vector is a node name that is not a key of
+ *     nodesSchedulingMetadata (the `!ok` branches at LIB/binpack/binpack.go:68, pack_tightly.go:51,
+ *     distribute_evenly.go:59): it never hosts anything.
+ *   - Quantities are canonical int64: cpu in milli-cores, memory in bytes, gpu in devices
+ *     (resource.Quantity restricted to exactly representable values; the shim must route anything else to the Go
+ *     CPU path).  |available| < 2^62; driver/executor requests in [0, 2^62).
+ *   - All host pointers are plain caller-owned arrays, copied before the call returns (cgo pointer rules); outputs
+ *     are caller-allocated.  No callbacks, no exceptions, no stdout.
+ *   - Return value: 0 = the call ran (feasible or not is in the results, like PackingResult.HasCapacity,
+ *     LIB/binpack/binpack.go:25-40); < 0 = the accelerator could not serve the call — the shim must then fall back
+ *     to the Go function so that Filter semantics never change.
+ *   - Thread safety: every gf_ctx entry point is serialised by a per-context mutex (Predicate and the
+ *     UnschedulablePodMarker goroutine may call concurrently: cmd/server.go:230, internal/extender/unschedulablepods.go:77-91).
+ *     The *_dev entry points are asynchronous on the given stream and must be externally ordered per context.
+ */
+#ifndef GANGFIT_H
+#define GANGFIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_VERSION 100 /* 0.1.0 */
+
+/* ---- status codes ---- */
+#define GF_OK 0
+#define GF_ERR_NO_DEVICE (-1)  /* no usable gfx950 device / hipInit failed */
+#define GF_ERR_HIP (-2)        /* a HIP runtime call failed; see gf_last_error */
+#define GF_ERR_INVALID (-3)    /* bad argument (NULL, duplicate node in exec order, k < 0, value out of range...) */
+#define GF_ERR_CAPACITY (-4)   /* caller's exec_nodes buffer is smaller than sum(k) */
+#define GF_ERR_STATE (-5)      /* snapshot/orders not set yet */
+#define GF_ERR_UNSUPPORTED (-6)/* algo/mode combination not served by the device path */
+
+#define GF_NO_NODE 0xFFFFFFFFu
+#define GF_MAX_K (1 << 20)     /* executorCount "is small (<1000)" — internal/extender/sparkpods.go:110 */
+#define GF_MAX_ABS_QUANTITY (INT64_C(1) << 62)
+
+/* Executor packers selectable by name in the reference (internal/binpacker/binpack.go:43-49). */
+typedef enum gf_algo {
+    GF_ALGO_TIGHTLY_PACK = 0,      /* "tightly-pack"      LIB/binpack/pack_tightly.go:25-63 */
+    GF_ALGO_DISTRIBUTE_EVENLY = 1, /* "distribute-evenly" LIB/binpack/distribute_evenly.go:25-73 */
+} gf_algo;
+
+typedef enum gf_mode {
+    /* n_apps independent SparkBinPack evaluations against the same snapshot — the batched form of
+     * UnschedulablePodMarker.scanForUnschedulablePods (internal/extender/unschedulablepods.go:93-166). */
+    GF_MODE_INDEPENDENT = 0,
+    /* fitEarlierDrivers + final pack (internal/extender/resource.go:224-262, 309-328): apps[0..n-2] are the earlier
+     * drivers in creation order, apps[n-1] is the driver being filtered; each feasible earlier app's usage is
+     * subtracted from the working copy of the snapshot exactly like sparkResourceUsage + SubtractUsageIfExists
+     * (internal/extender/sparkpods.go:139-146: ONE executor request per distinct executor node; the driver request only
+     * if the driver node hosts no executor). */
+    GF_MODE_FIFO_CHAIN = 1,
+} gf_mode;
+
+/* gf_app.flags */
+#define GF_APP_SKIPPABLE 1u /* shouldSkipDriverFifo(driver) is true (resource.go:264-270): an unfit earlier driver is ignored */
+
+/* One Spark application = types.SparkApplicationResources (internal/types/types.go:22-27) in canonical units. */
+typedef struct gf_app {
+    int64_t drv[3];    /* DriverResources   {cpu milli, memory bytes, gpu} */
+    int64_t exe[3];    /* ExecutorResources {cpu milli, memory bytes, gpu} */
+    int32_t k;         /* executorCount handed to the packer = MinExecutorCount (resource.go:242,325) */
+    uint32_t flags;
+    uint64_t exec_off; /* offset of this app's k placements in exec_nodes.  gf_fit_batch fills it (prefix sum of k)
+                          in its private copy; callers of gf_fit_batch_dev must fill it themselves. */
+} gf_app;              /* 64 bytes */
+
+/* binpack.PackingResult (LIB/binpack/binpack.go:25-30) without the efficiency map (see gf_packing_efficiency). */
+typedef struct gf_result {
+    int32_t has_capacity; /* HasCapacity */
+    uint32_t driver_node; /* DriverNode, GF_NO_NODE when empty */
+    uint32_t exec_len;    /* len(ExecutorNodes): k when feasible, 0 otherwise; entries live at exec_nodes[app.exec_off ...) in
+                             reservation order executor-1..executor-k (internal/extender/resourcereservations.go:501-502) */
+    uint32_t evaluated;   /* 1 if the app was evaluated; 0 for apps behind a FIFO chain abort */
+} gf_result;              /* 16 bytes */
+
+typedef struct gf_ctx gf_ctx;
+
+int gf_version(void);
+
+/* Create a context on one device (n_dev must be 1 in this version; device_ids NULL = device 0).
+ * Replaces nothing in the reference; the shim calls it right after SelectBinpacker (cmd/server.go:145). */
+int gf_init(const int *device_ids, int n_dev, gf_ctx **out);
+void gf_destroy(gf_ctx *ctx);
+
+/* Message for the last failing call on this context (C-owned, valid until the next call on ctx). */
+const char *gf_last_error(gf_ctx *ctx);
+
+/* Upload the per-node snapshot = the AvailableResources / SchedulableResources columns of
+ * resources.NodeGroupSchedulingMetadata (LIB/resources/resources.go:61-100, 158-166).
+ * avail_*: n_nodes values each (may be negative: overcommitted node).  sched_*: nullable (only needed by
+ * gf_packing_efficiency). */
+int gf_snapshot_set(gf_ctx *ctx, uint32_t n_nodes, const int64_t *avail_cpu_milli, const int64_t *avail_mem_bytes,
+                    const int64_t *avail_gpu, const int64_t *sched_cpu_milli, const int64_t *sched_mem_bytes,
+                    const int64_t *sched_gpu);
+
+/* Upload driverNodePriorityOrder / executorNodePriorityOrder (the two results of NodeSorter.PotentialNodes,
+ * internal/sort/nodesorting.go:41-64) as node indices.  A known node may appear at most once in exec_order
+ * (both vectors derive from map keys in the reference, nodesorting.go:153-159); violating this is GF_ERR_INVALID.
+ * Must be called after gf_snapshot_set; a new snapshot invalidates the orders. */
+int gf_orders_set(gf_ctx *ctx, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x);
+
+/* The batched replacement of the BinpackFunc call sites (internal/extender/resource.go:238, :321,
+ * internal/extender/unschedulablepods.go:156).
+ *   results[n_apps]; exec_nodes[exec_nodes_cap] receives the concatenated ExecutorNodes (needs >= sum of k);
+ *   chain_failed_at (nullable): FIFO mode — index of the first earlier driver that neither fit nor was skippable
+ *   ("failure-earlier-driver", resource.go:249-251, 315-318), else -1.
+ * Blocking.  Includes H2D of the app records and D2H of the results. */
+int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app *apps, gf_result *results,
+                 uint32_t *exec_nodes, uint64_t exec_nodes_cap, int32_t *chain_failed_at);
+
+/* Same decision kernels on DEVICE-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = the context's own
+ * stream).  d_apps must carry exec_off and must already be validated (k in [0, GF_MAX_K], requests in [0, 2^62)).
+ * exec_nodes_len = number of uint32 entries in d_exec_nodes (>= sum of k).  d_chain_failed_at: device int32,
+ * nullable (the result is then only kept inside the context).
+ * Used by callers that keep the pending-app table resident (bench.py times this entry point). */
+int gf_fit_batch_dev(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app *d_apps,
+                     gf_result *d_results, uint32_t *d_exec_nodes, uint64_t exec_nodes_len,
+                     int32_t *d_chain_failed_at, void *stream);
+
+/* One decision through the batched path: the literal shape of binpack.SparkBinPackFunction
+ * (LIB/binpack/binpack.go:43-48) for registry entries "gpu-tightly-pack" / "gpu-distribute-evenly". */
+int gf_spark_binpack(gf_ctx *ctx, gf_algo algo, const gf_app *app, gf_result *result, uint32_t *exec_nodes,
+                     uint64_t exec_nodes_cap);
+
+/* Working copy of the available table after the last GF_MODE_FIFO_CHAIN call (n_nodes x 3, row-major) — lets tests
+ * compare the replayed residuals with availableNodesSchedulingMetadata after fitEarlierDrivers. */
+int gf_residual_get(gf_ctx *ctx, int64_t *avail_out /* n_nodes*3 */);
+
+/* Kernel-only timing helper: HIP events recorded on `stream` (NULL = the context's own stream) around whatever is
+ * launched on that stream between begin and end.  gf_timer_end blocks until the end event has completed. */
+int gf_timer_begin(gf_ctx *ctx, void *stream);
+int gf_timer_end(gf_ctx *ctx, float *elapsed_ms);
+
+/* Visited-slot counters, for honest "visited bytes" reporting next to the algorithmic bytes (the scans are lazy, like
+ * the reference's loops: they stop once K executors are placed).  enable != 0 makes subsequent launches count
+ * (one atomic pair per app); out[0] = executor-order slots whose capacity was evaluated, out[1] = driver-order
+ * positions whose fit was evaluated, accumulated since the last reset.  out may be NULL. */
+int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[2]);
+
+/* On-device self-test of the wave primitives (DPP prefix scan, exact clamped 64-bit division) against plain
+ * reference code on n_cases adversarial inputs per lane.  *mismatches == 0 means pass. */
+int gf_selftest(gf_ctx *ctx, uint64_t seed, uint32_t n_cases, uint32_t *mismatches);
+
+/* Device properties the host uses to size launches (also lets a caller verify it is talking to a gfx950). */
+typedef struct gf_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t lds_bytes_per_cu;
+    int32_t wavefront_size;
+    int32_t clock_khz;
+    int64_t hbm_bytes;
+} gf_device_info;
+int gf_device_info_get(gf_ctx *ctx, gf_device_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANGFIT_H */

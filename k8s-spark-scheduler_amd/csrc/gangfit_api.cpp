@@ -1,0 +1,482 @@
+// gangfit_api.cpp — the C ABI of libgangfit (include/gangfit.h): context, snapshot/order staging, launches.
+//
+// Host side only: builds the slot-ordered node table the kernels scan (gangfit_device.h), moves app records and
+// results through pinned staging buffers and serialises callers per context.  No CPU fallback lives here: when the
+// device path cannot serve a call the function returns < 0 and the caller (the Go shim) decides what to do.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gangfit.h"
+#include "gangfit_device.h"
+
+using gangfit::NodeTable;
+using gangfit::ScanStats;
+
+namespace {
+
+constexpr int64_t kSentinelAvail = -(INT64_C(1) << 62);  // "node is not in nodesSchedulingMetadata"
+
+template <typename T>
+struct DeviceBuf {
+    T* ptr = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        size_t want = cap ? cap : 256;
+        while (want < n) want *= 2;
+        T* fresh = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (ptr) (void)hipFree(ptr);
+        ptr = fresh;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        size_t want = cap ? cap : 256;
+        while (want < n) want *= 2;
+        T* fresh = nullptr;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = fresh;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct gf_ctx {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipStream_t timer_stream = nullptr;
+    std::string err;
+    gf_device_info info{};
+
+    // host copy of the snapshot (node-index order)
+    uint32_t n_nodes = 0;
+    std::vector<int64_t> avail[3];
+    std::vector<int64_t> sched[3];
+    bool have_snapshot = false, have_sched = false, have_orders = false;
+
+    // slot-ordered device tables
+    uint32_t n_x = 0, n_d = 0, n_slots = 0;
+    DeviceBuf<int64_t> d_snap;   // 3 * n_slots: cpu | mem | gpu of the snapshot
+    DeviceBuf<int64_t> d_work;   // working copy mutated by FIFO chains
+    DeviceBuf<uint32_t> d_slot_node, d_dslot, d_node_slot;
+    std::vector<uint32_t> h_node_slot;  // kept for gf_residual_get
+    PinnedBuf<int64_t> h_table;
+    PinnedBuf<uint32_t> h_index;
+    bool work_valid = false;
+
+    // batch buffers
+    DeviceBuf<gf_app> d_apps;
+    DeviceBuf<gf_result> d_results;
+    DeviceBuf<uint32_t> d_exec, d_scratch;
+    DeviceBuf<int32_t> d_failed;
+    DeviceBuf<ScanStats> d_stats;
+    PinnedBuf<gf_app> h_apps;
+    PinnedBuf<gf_result> h_results;
+    PinnedBuf<uint32_t> h_exec;
+    PinnedBuf<int32_t> h_failed;
+    bool stats_on = false;
+};
+
+namespace {
+
+int fail(gf_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define GF_HIP(ctx, call)                                                                                    \
+    do {                                                                                                     \
+        hipError_t e__ = (call);                                                                             \
+        if (e__ != hipSuccess) return fail((ctx), GF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+NodeTable make_table(gf_ctx* ctx, int64_t* base) {
+    NodeTable t;
+    t.cpu = base;
+    t.mem = base + ctx->n_slots;
+    t.gpu = base + 2 * (size_t)ctx->n_slots;
+    t.slot_node = ctx->d_slot_node.ptr;
+    t.dslot = ctx->d_dslot.ptr;
+    t.node_slot = ctx->d_node_slot.ptr;
+    t.n_x = ctx->n_x;
+    t.n_d = ctx->n_d;
+    t.n_slots = ctx->n_slots;
+    t.n_nodes = ctx->n_nodes;
+    return t;
+}
+
+int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
+           uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
+    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_algo %d", (int)algo);
+    const uint64_t half = exec_nodes_len + 1;
+    GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
+    ScanStats* stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
+    if (mode == GF_MODE_INDEPENDENT) {
+        GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), n_apps, d_apps, d_results,
+                                                    d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
+    } else if (mode == GF_MODE_FIFO_CHAIN) {
+        // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                   hipMemcpyDeviceToDevice, stream));
+        ctx->work_valid = true;
+        GF_HIP(ctx, gangfit::launch_fit_fifo_chain(algo, make_table(ctx, ctx->d_work.ptr), n_apps, d_apps, d_results,
+                                                   d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, stats, stream));
+    } else {
+        return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
+    }
+    return GF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gf_version(void) { return GF_VERSION; }
+
+int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
+    if (!out) return GF_ERR_INVALID;
+    *out = nullptr;
+    if (n_dev != 1 && !(n_dev == 0 && device_ids == nullptr)) return GF_ERR_UNSUPPORTED;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GF_ERR_NO_DEVICE;
+    const int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return GF_ERR_NO_DEVICE;
+    gf_ctx* ctx = new (std::nothrow) gf_ctx();
+    if (!ctx) return GF_ERR_HIP;
+    ctx->device = dev;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        delete ctx;
+        return GF_ERR_NO_DEVICE;
+    }
+    std::snprintf(ctx->info.name, sizeof ctx->info.name, "%s", prop.name);
+    std::snprintf(ctx->info.arch, sizeof ctx->info.arch, "%s", prop.gcnArchName);
+    ctx->info.compute_units = prop.multiProcessorCount;
+    ctx->info.lds_bytes_per_cu = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    ctx->info.wavefront_size = prop.warpSize;
+    ctx->info.clock_khz = prop.clockRate;
+    ctx->info.hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.warpSize != 64) {
+        delete ctx;
+        return GF_ERR_NO_DEVICE;  // the kernels are gfx950 / wave64 only
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess ||
+        ctx->d_stats.reserve(1) != hipSuccess || ctx->d_failed.reserve(1) != hipSuccess ||
+        ctx->h_failed.reserve(1) != hipSuccess ||
+        hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)) != hipSuccess) {
+        gf_destroy(ctx);
+        return GF_ERR_HIP;
+    }
+    *out = ctx;
+    return GF_OK;
+}
+
+void gf_destroy(gf_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_snap.release();
+    ctx->d_work.release();
+    ctx->d_slot_node.release();
+    ctx->d_dslot.release();
+    ctx->d_node_slot.release();
+    ctx->d_apps.release();
+    ctx->d_results.release();
+    ctx->d_exec.release();
+    ctx->d_scratch.release();
+    ctx->d_failed.release();
+    ctx->d_stats.release();
+    ctx->h_table.release();
+    ctx->h_index.release();
+    ctx->h_apps.release();
+    ctx->h_results.release();
+    ctx->h_exec.release();
+    ctx->h_failed.release();
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gf_device_info_get(gf_ctx* ctx, gf_device_info* out) {
+    if (!ctx || !out) return GF_ERR_INVALID;
+    *out = ctx->info;
+    return GF_OK;
+}
+
+int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_milli, const int64_t* avail_mem_bytes,
+                    const int64_t* avail_gpu, const int64_t* sched_cpu_milli, const int64_t* sched_mem_bytes,
+                    const int64_t* sched_gpu) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_nodes > 0 && (!avail_cpu_milli || !avail_mem_bytes || !avail_gpu))
+        return fail(ctx, GF_ERR_INVALID, "available arrays must not be NULL");
+    if (n_nodes >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "too many nodes");
+    const int64_t* av[3] = {avail_cpu_milli, avail_mem_bytes, avail_gpu};
+    const int64_t* sc[3] = {sched_cpu_milli, sched_mem_bytes, sched_gpu};
+    for (int j = 0; j < 3; ++j)
+        for (uint32_t n = 0; n < n_nodes; ++n)
+            if (av[j][n] >= GF_MAX_ABS_QUANTITY || av[j][n] <= -GF_MAX_ABS_QUANTITY)
+                return fail(ctx, GF_ERR_INVALID, "available[%d][%u] outside (-2^62, 2^62)", j, n);
+    ctx->have_sched = sc[0] && sc[1] && sc[2];
+    for (int j = 0; j < 3; ++j) {
+        ctx->avail[j].assign(av[j], av[j] + n_nodes);
+        if (ctx->have_sched)
+            ctx->sched[j].assign(sc[j], sc[j] + n_nodes);
+        else
+            ctx->sched[j].clear();
+    }
+    ctx->n_nodes = n_nodes;
+    ctx->have_snapshot = true;
+    ctx->have_orders = false;
+    ctx->work_valid = false;
+    return GF_OK;
+}
+
+int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const uint32_t* exec_order, uint32_t n_x) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_orders_set");
+    if ((n_d > 0 && !driver_order) || (n_x > 0 && !exec_order))
+        return fail(ctx, GF_ERR_INVALID, "order arrays must not be NULL");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_nodes = ctx->n_nodes;
+    std::vector<uint32_t>& node_slot = ctx->h_node_slot;
+    node_slot.assign(n_nodes, GF_NO_NODE);
+    for (uint32_t i = 0; i < n_x; ++i) {
+        const uint32_t n = exec_order[i];
+        if (n >= n_nodes) continue;
+        if (node_slot[n] != GF_NO_NODE)
+            return fail(ctx, GF_ERR_INVALID, "node %u appears twice in the executor priority order", n);
+        node_slot[n] = i;
+    }
+    uint32_t extra = 0;
+    for (uint32_t i = 0; i < n_d; ++i) {
+        const uint32_t n = driver_order[i];
+        if (n < n_nodes && node_slot[n] == GF_NO_NODE) node_slot[n] = n_x + extra++;
+    }
+    const uint64_t n_slots64 = (uint64_t)n_x + extra + 1;
+    if (n_slots64 >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "order vectors too long");
+    const uint32_t n_slots = (uint32_t)n_slots64;
+    const uint32_t sentinel = n_slots - 1;
+
+    GF_HIP(ctx, ctx->h_table.reserve(3 * (size_t)n_slots));
+    GF_HIP(ctx, ctx->h_index.reserve((size_t)n_slots + n_d + n_nodes + 1));
+    int64_t* tcpu = ctx->h_table.ptr;
+    int64_t* tmem = tcpu + n_slots;
+    int64_t* tgpu = tmem + n_slots;
+    uint32_t* slot_node = ctx->h_index.ptr;
+    uint32_t* dslot = slot_node + n_slots;
+    uint32_t* nslot = dslot + n_d;
+    for (uint32_t s = 0; s < n_slots; ++s) {
+        tcpu[s] = tmem[s] = tgpu[s] = kSentinelAvail;
+        slot_node[s] = GF_NO_NODE;
+    }
+    for (uint32_t i = 0; i < n_x; ++i) slot_node[i] = exec_order[i];  // unknown names keep their raw index; never emitted
+    for (uint32_t n = 0; n < n_nodes; ++n) {
+        const uint32_t s = node_slot[n];
+        nslot[n] = s;
+        if (s == GF_NO_NODE) continue;
+        slot_node[s] = n;
+        tcpu[s] = ctx->avail[0][n];
+        tmem[s] = ctx->avail[1][n];
+        tgpu[s] = ctx->avail[2][n];
+    }
+    for (uint32_t i = 0; i < n_d; ++i) {
+        const uint32_t n = driver_order[i];
+        dslot[i] = n < n_nodes ? node_slot[n] : sentinel;
+    }
+
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still read the old tables
+    GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));
+    GF_HIP(ctx, ctx->d_work.reserve(3 * (size_t)n_slots));
+    GF_HIP(ctx, ctx->d_slot_node.reserve(n_slots));
+    GF_HIP(ctx, ctx->d_dslot.reserve(n_d + 1));
+    GF_HIP(ctx, ctx->d_node_slot.reserve(n_nodes + 1));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_snap.ptr, tcpu, 3 * (size_t)n_slots * sizeof(int64_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_slot_node.ptr, slot_node, (size_t)n_slots * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    if (n_d)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_dslot.ptr, dslot, (size_t)n_d * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+    if (n_nodes)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_node_slot.ptr, nslot, (size_t)n_nodes * sizeof(uint32_t),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_x = n_x;
+    ctx->n_d = n_d;
+    ctx->n_slots = n_slots;
+    ctx->have_orders = true;
+    ctx->work_valid = false;
+    return GF_OK;
+}
+
+int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results,
+                 uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_apps > 0 && (!apps || !results)) return fail(ctx, GF_ERR_INVALID, "apps/results must not be NULL");
+    if (chain_failed_at) *chain_failed_at = -1;
+    if (n_apps == 0) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, ctx->h_apps.reserve(n_apps));
+    uint64_t total_k = 0;
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        const gf_app& in = apps[a];
+        if (in.k < 0 || in.k > GF_MAX_K) return fail(ctx, GF_ERR_INVALID, "apps[%u].k = %d outside [0, %d]", a, in.k, GF_MAX_K);
+        for (int j = 0; j < 3; ++j)
+            if (in.drv[j] < 0 || in.drv[j] >= GF_MAX_ABS_QUANTITY || in.exe[j] < 0 || in.exe[j] >= GF_MAX_ABS_QUANTITY)
+                return fail(ctx, GF_ERR_INVALID, "apps[%u] request outside [0, 2^62)", a);
+        gf_app& o = ctx->h_apps.ptr[a];
+        o = in;
+        o.exec_off = total_k;
+        total_k += (uint64_t)in.k;
+    }
+    if (total_k > exec_nodes_cap || (total_k > 0 && !exec_nodes))
+        return fail(ctx, GF_ERR_CAPACITY, "exec_nodes holds %llu entries, %llu needed",
+                    (unsigned long long)exec_nodes_cap, (unsigned long long)total_k);
+    GF_HIP(ctx, ctx->d_apps.reserve(n_apps));
+    GF_HIP(ctx, ctx->d_results.reserve(n_apps));
+    GF_HIP(ctx, ctx->d_exec.reserve(total_k + 1));
+    GF_HIP(ctx, ctx->h_results.reserve(n_apps));
+    GF_HIP(ctx, ctx->h_exec.reserve(total_k + 1));
+    hipStream_t st = ctx->stream;
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
+    const int rc = launch(ctx, mode, algo, n_apps, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr, total_k,
+                          ctx->d_failed.ptr, st);
+    if (rc != GF_OK) return rc;
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, st));
+    if (total_k)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_exec.ptr, ctx->d_exec.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (mode == GF_MODE_FIFO_CHAIN)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_failed.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
+    if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
+    if (mode == GF_MODE_FIFO_CHAIN && chain_failed_at) *chain_failed_at = ctx->h_failed.ptr[0];
+    return GF_OK;
+}
+
+int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
+                     gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_chain_failed_at,
+                     void* stream) {
+    if (!ctx) return GF_ERR_INVALID;
+    if (n_apps > 0 && (!d_apps || !d_results)) return fail(ctx, GF_ERR_INVALID, "device apps/results must not be NULL");
+    if (mode == GF_MODE_FIFO_CHAIN && !d_chain_failed_at) d_chain_failed_at = ctx->d_failed.ptr;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    return launch(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, st);
+}
+
+int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
+                     uint64_t exec_nodes_cap) {
+    return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);
+}
+
+int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
+    if (!ctx || !avail_out) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->have_orders || !ctx->work_valid) return fail(ctx, GF_ERR_STATE, "no FIFO chain has run on the current orders");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, ctx->h_table.reserve(3 * (size_t)ctx->n_slots));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_table.ptr, ctx->d_work.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t* t = ctx->h_table.ptr;
+    for (uint32_t n = 0; n < ctx->n_nodes; ++n) {
+        const uint32_t s = ctx->h_node_slot[n];
+        for (int j = 0; j < 3; ++j)
+            avail_out[3 * (size_t)n + j] = (s == GF_NO_NODE) ? ctx->avail[j][n] : t[(size_t)j * ctx->n_slots + s];
+    }
+    return GF_OK;
+}
+
+int gf_timer_begin(gf_ctx* ctx, void* stream) {
+    if (!ctx) return GF_ERR_INVALID;
+    ctx->timer_stream = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->timer_stream));
+    return GF_OK;
+}
+
+int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
+    if (!ctx || !elapsed_ms) return GF_ERR_INVALID;
+    GF_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->timer_stream ? ctx->timer_stream : ctx->stream));
+    GF_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    GF_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return GF_OK;
+}
+
+int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[2]) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (out) {
+        ScanStats s;
+        GF_HIP(ctx, hipMemcpy(&s, ctx->d_stats.ptr, sizeof s, hipMemcpyDeviceToHost));
+        out[0] = s.exec_slots_visited;
+        out[1] = s.driver_slots_visited;
+    }
+    if (reset) GF_HIP(ctx, hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)));
+    ctx->stats_on = enable != 0;
+    return GF_OK;
+}
+
+int gf_selftest(gf_ctx* ctx, uint64_t seed, uint32_t n_cases, uint32_t* mismatches) {
+    if (!ctx || !mismatches) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceBuf<uint32_t> d;
+    GF_HIP(ctx, d.reserve(1));
+    hipError_t e = hipMemsetAsync(d.ptr, 0, sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = gangfit::launch_selftest(seed, n_cases, d.ptr, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "selftest failed: %s", hipGetErrorString(e));
+    return GF_OK;
+}
+
+}  // extern "C"

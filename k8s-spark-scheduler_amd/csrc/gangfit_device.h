@@ -1,0 +1,50 @@
+// gangfit_device.h — shared declarations between the HIP kernels (gangfit_kernels.hip) and the C-ABI host
+// layer (gangfit_api.cpp).  gfx950 / CDNA4 only: wave64, no compatibility paths.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gangfit.h"
+
+namespace gangfit {
+
+// The node table as the kernels see it.  "Slot" space: slots [0, n_x) are the executor priority order
+// (executorNodePriorityOrder, already permuted so that a wave scanning slots b..b+63 issues three coalesced
+// 512-byte loads); slots [n_x, n_slots-1) hold driver candidates that are not executor candidates; the last slot
+// is a sentinel (available = -2^62) that every unknown node name maps to.  SoA, int64, one array per dimension.
+struct NodeTable {
+    int64_t* cpu;  // milli-cores   [n_slots]
+    int64_t* mem;  // bytes         [n_slots]
+    int64_t* gpu;  // devices       [n_slots]
+    const uint32_t* slot_node;  // [n_slots] slot -> caller's node index (what is written to exec_nodes)
+    const uint32_t* dslot;      // [n_d]     position in driverNodePriorityOrder -> slot
+    const uint32_t* node_slot;  // [n_nodes] caller's node index -> slot
+    uint32_t n_x;
+    uint32_t n_d;
+    uint32_t n_slots;
+    uint32_t n_nodes;
+};
+
+// Kernel-visible counters used by tests/bench to report visited bytes honestly (SURVEY.md section 8d
+// "early-exit note").  One uint64 pair per launch, accumulated with a single atomic per app.
+struct ScanStats {
+    unsigned long long exec_slots_visited;    // executor-order slots whose capacity was evaluated
+    unsigned long long driver_slots_visited;  // driver-order positions whose fit was evaluated
+};
+
+// Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).
+hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t n_apps, const gf_app* d_apps,
+                                  gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
+
+hipError_t launch_fit_fifo_chain(gf_algo algo, const NodeTable& table, uint32_t n_apps, const gf_app* d_apps,
+                                 gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                                 uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats,
+                                 hipStream_t stream);
+
+// Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
+// Writes the number of mismatching lanes/cases to *d_mismatch.
+hipError_t launch_selftest(uint64_t seed, uint32_t n_cases, uint32_t* d_mismatch, hipStream_t stream);
+
+}  // namespace gangfit

@@ -1,0 +1,105 @@
+"""ctypes binding of libgangfit.so — the C ABI declared in include/gangfit.h.
+
+There is NO fallback: if the shared library is missing or a call fails this module raises.  The HIP path is the only
+product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+
+GF_OK = 0
+GF_ERR_NO_DEVICE, GF_ERR_HIP, GF_ERR_INVALID, GF_ERR_CAPACITY, GF_ERR_STATE, GF_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+GF_NO_NODE = 0xFFFFFFFF
+GF_MAX_K = 1 << 20
+GF_ALGO_TIGHTLY_PACK = 0
+GF_ALGO_DISTRIBUTE_EVENLY = 1
+GF_MODE_INDEPENDENT = 0
+GF_MODE_FIFO_CHAIN = 1
+GF_APP_SKIPPABLE = 1
+
+APP_DTYPE = np.dtype(
+    [("drv", "<i8", (3,)), ("exe", "<i8", (3,)), ("k", "<i4"), ("flags", "<u4"), ("exec_off", "<u8")], align=True
+)
+RESULT_DTYPE = np.dtype(
+    [("has_capacity", "<i4"), ("driver_node", "<u4"), ("exec_len", "<u4"), ("evaluated", "<u4")], align=True
+)
+assert APP_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
+
+# every symbol include/gangfit.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch",
+    "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats",
+    "gf_selftest", "gf_device_info_get",
+]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int32),
+                ("lds_bytes_per_cu", C.c_int32), ("wavefront_size", C.c_int32), ("clock_khz", C.c_int32),
+                ("hbm_bytes", C.c_int64)]
+
+
+class GangfitError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libgangfit error {code}: {message}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree libgangfit.so; raises if it has not been built (see __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (build()) first — there is no CPU fallback")
+    L = C.CDLL(path)
+    p, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.gf_version.restype = i32
+    L.gf_init.restype = i32
+    L.gf_init.argtypes = [p, i32, C.POINTER(p)]
+    L.gf_destroy.restype = None
+    L.gf_destroy.argtypes = [p]
+    L.gf_last_error.restype = C.c_char_p
+    L.gf_last_error.argtypes = [p]
+    L.gf_snapshot_set.restype = i32
+    L.gf_snapshot_set.argtypes = [p, u32, p, p, p, p, p, p]
+    L.gf_orders_set.restype = i32
+    L.gf_orders_set.argtypes = [p, p, u32, p, u32]
+    L.gf_fit_batch.restype = i32
+    L.gf_fit_batch.argtypes = [p, i32, i32, u32, p, p, p, u64, p]
+    L.gf_fit_batch_dev.restype = i32
+    L.gf_fit_batch_dev.argtypes = [p, i32, i32, u32, p, p, p, u64, p, p]
+    L.gf_spark_binpack.restype = i32
+    L.gf_spark_binpack.argtypes = [p, i32, p, p, p, u64]
+    L.gf_residual_get.restype = i32
+    L.gf_residual_get.argtypes = [p, p]
+    L.gf_timer_begin.restype = i32
+    L.gf_timer_begin.argtypes = [p, p]
+    L.gf_timer_end.restype = i32
+    L.gf_timer_end.argtypes = [p, C.POINTER(C.c_float)]
+    L.gf_scan_stats.restype = i32
+    L.gf_scan_stats.argtypes = [p, i32, i32, p]
+    L.gf_selftest.restype = i32
+    L.gf_selftest.argtypes = [p, u64, u32, C.POINTER(u32)]
+    L.gf_device_info_get.restype = i32
+    L.gf_device_info_get.argtypes = [p, C.POINTER(DeviceInfo)]
+    _lib = L
+    return L
+
+
+def ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

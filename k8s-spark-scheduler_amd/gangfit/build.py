@@ -1,0 +1,60 @@
+"""Build libgangfit.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.  No JIT cache: the .so sits next to the
+package so that it travels with the repository snapshot to the GPU box."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # k8s-spark-scheduler_amd/
+_REPO_ROOT = os.path.dirname(_PKG_ROOT)
+CSRC = os.path.join(_PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(_PKG_ROOT, "libgangfit.so")
+HOST_LIB_PATH = os.path.join(_PKG_ROOT, "libgangfit_host.so")
+INCLUDE = os.path.join(_REPO_ROOT, "include")
+
+_SOURCES = ["gangfit_kernels.hip", "gangfit_api.cpp"]
+_HEADERS = [os.path.join(CSRC, "gangfit_device.h"), os.path.join(INCLUDE, "gangfit.h")]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libgangfit cannot be built (ROCm toolchain required)")
+    return exe
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force: bool = False, extra_flags=()) -> str:
+    """hipcc --offload-arch=gfx950 ... -> k8s-spark-scheduler_amd/libgangfit.so"""
+    srcs = [os.path.join(CSRC, s) for s in _SOURCES]
+    if force or extra_flags or _stale(LIB_PATH, srcs + _HEADERS):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+               *extra_flags, *srcs, "-o", LIB_PATH]
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def build_host(force: bool = False) -> str:
+    """C++ host mirror of the reference's plug-in interface (string node names, Quantity parsing) on top of the C ABI."""
+    host_dir = os.path.join(_PKG_ROOT, "host")
+    srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
+    hdrs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".hpp")]
+    if not srcs:
+        return ""
+    if force or _stale(HOST_LIB_PATH, srcs + hdrs + _HEADERS + [LIB_PATH]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", INCLUDE, "-I", host_dir, *srcs,
+               "-L", _PKG_ROOT, "-lgangfit", "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB_PATH]
+        subprocess.check_call(cmd)
+    return HOST_LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True))
+    print(build_host(force=True))

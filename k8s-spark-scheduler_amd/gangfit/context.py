@@ -1,0 +1,162 @@
+"""Thin Python handle over the C ABI (include/gangfit.h) for tests and bench.py.
+
+Everything computational happens in libgangfit.so (HIP kernels); this file only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+
+def make_apps(drv, exe, k, flags=None) -> np.ndarray:
+    """Pack per-app columns into gf_app records (exec_off is filled by the library / by `with_offsets`)."""
+    drv = np.asarray(drv, dtype=np.int64).reshape(-1, 3)
+    exe = np.asarray(exe, dtype=np.int64).reshape(-1, 3)
+    k = np.asarray(k, dtype=np.int32).reshape(-1)
+    apps = np.zeros(len(k), dtype=N.APP_DTYPE)
+    apps["drv"], apps["exe"], apps["k"] = drv, exe, k
+    if flags is not None:
+        apps["flags"] = np.asarray(flags, dtype=np.uint32)
+    return apps
+
+
+def with_offsets(apps: np.ndarray) -> Tuple[np.ndarray, int]:
+    """Fill exec_off = exclusive prefix sum of k (what gf_fit_batch does internally); returns (apps, total_k)."""
+    apps = apps.copy()
+    k = apps["k"].astype(np.uint64)
+    off = np.zeros(len(apps), dtype=np.uint64)
+    if len(apps) > 1:
+        off[1:] = np.cumsum(k[:-1])
+    apps["exec_off"] = off
+    return apps, int(k.sum())
+
+
+@dataclass
+class BatchOut:
+    results: np.ndarray  # RESULT_DTYPE
+    exec_off: np.ndarray  # uint64
+    exec_nodes: np.ndarray  # uint32, concatenated
+    failed_at: int = -1
+
+    def placement(self, a: int):
+        r = self.results[a]
+        n = int(r["exec_len"])
+        o = int(self.exec_off[a])
+        return bool(r["has_capacity"]), int(r["driver_node"]), self.exec_nodes[o:o + n]
+
+
+class Context:
+    """gf_ctx wrapper. Raises GangfitError on any negative return code — no silent fallback."""
+
+    def __init__(self, device: int = 0):
+        self._lib = N.load()
+        h = C.c_void_p()
+        ids = (C.c_int * 1)(device)
+        rc = self._lib.gf_init(ids, 1, C.byref(h))
+        if rc != N.GF_OK:
+            raise N.GangfitError(rc, "gf_init failed (no gfx950 device visible?)")
+        self._h = h
+        self.n_nodes = 0
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gf_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != N.GF_OK:
+            msg = self._lib.gf_last_error(self._h)
+            raise N.GangfitError(rc, msg.decode() if msg else "")
+
+    # -- inputs
+    def set_snapshot(self, avail, sched=None):
+        """avail/sched: (n_nodes, 3) int64 [cpu milli, mem bytes, gpu]."""
+        avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3)
+        cols = [np.ascontiguousarray(avail[:, j]) for j in range(3)]
+        scols = [None, None, None]
+        if sched is not None:
+            sched = np.ascontiguousarray(sched, dtype=np.int64).reshape(-1, 3)
+            scols = [np.ascontiguousarray(sched[:, j]) for j in range(3)]
+        self._check(self._lib.gf_snapshot_set(self._h, len(avail), *[N.ptr(c) for c in cols], *[N.ptr(c) for c in scols]))
+        self.n_nodes = len(avail)
+
+    def set_orders(self, driver_order, exec_order):
+        d = np.ascontiguousarray(driver_order, dtype=np.uint32)
+        x = np.ascontiguousarray(exec_order, dtype=np.uint32)
+        self._check(self._lib.gf_orders_set(self._h, N.ptr(d), len(d), N.ptr(x), len(x)))
+
+    # -- decisions (host buffers; includes H2D/D2H)
+    def fit_batch(self, mode: int, algo: int, apps: np.ndarray) -> BatchOut:
+        apps = np.ascontiguousarray(apps, dtype=N.APP_DTYPE)
+        apps_off, total_k = with_offsets(apps)
+        res = np.zeros(len(apps), dtype=N.RESULT_DTYPE)
+        out = np.zeros(total_k + 1, dtype=np.uint32)
+        failed = C.c_int32(-1)
+        self._check(self._lib.gf_fit_batch(self._h, mode, algo, len(apps), N.ptr(apps), N.ptr(res), N.ptr(out), total_k,
+                                           C.byref(failed)))
+        return BatchOut(res, apps_off["exec_off"].copy(), out[:total_k], int(failed.value))
+
+    def spark_binpack(self, algo: int, drv, exe, k: int):
+        """One decision in the shape of binpack.SparkBinPackFunction. Returns (has_capacity, driver, exec_nodes)."""
+        app = make_apps([drv], [exe], [k])
+        res = np.zeros(1, dtype=N.RESULT_DTYPE)
+        out = np.zeros(k + 1, dtype=np.uint32)
+        self._check(self._lib.gf_spark_binpack(self._h, algo, N.ptr(app), N.ptr(res), N.ptr(out), k))
+        n = int(res[0]["exec_len"])
+        return bool(res[0]["has_capacity"]), int(res[0]["driver_node"]), out[:n].copy()
+
+    def residual(self) -> np.ndarray:
+        out = np.zeros((self.n_nodes, 3), dtype=np.int64)
+        self._check(self._lib.gf_residual_get(self._h, N.ptr(out)))
+        return out
+
+    # -- device-resident entry point (pointers are raw device addresses, e.g. torch.Tensor.data_ptr())
+    def fit_batch_dev(self, mode: int, algo: int, n_apps: int, d_apps: int, d_results: int, d_exec_nodes: int,
+                      exec_nodes_len: int, d_failed_at: int = 0, stream: int = 0):
+        self._check(self._lib.gf_fit_batch_dev(self._h, mode, algo, n_apps, C.c_void_p(d_apps), C.c_void_p(d_results),
+                                               C.c_void_p(d_exec_nodes), exec_nodes_len,
+                                               C.c_void_p(d_failed_at) if d_failed_at else None,
+                                               C.c_void_p(stream) if stream else None))
+
+    def timer_begin(self, stream: int = 0):
+        self._check(self._lib.gf_timer_begin(self._h, C.c_void_p(stream) if stream else None))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0.0)
+        self._check(self._lib.gf_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def scan_stats(self, enable: bool = True, reset: bool = False):
+        out = np.zeros(2, dtype=np.uint64)
+        self._check(self._lib.gf_scan_stats(self._h, int(enable), int(reset), N.ptr(out)))
+        return int(out[0]), int(out[1])
+
+    def selftest(self, seed: int = 1, n_cases: int = 256) -> int:
+        bad = C.c_uint32(0)
+        self._check(self._lib.gf_selftest(self._h, seed, n_cases, C.byref(bad)))
+        return int(bad.value)
+
+    def device_info(self) -> dict:
+        info = N.DeviceInfo()
+        self._check(self._lib.gf_device_info_get(self._h, C.byref(info)))
+        return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
+                "lds_bytes_per_cu": info.lds_bytes_per_cu, "wavefront_size": info.wavefront_size,
+                "clock_khz": info.clock_khz, "hbm_bytes": info.hbm_bytes}

@@ -1,0 +1,173 @@
+"""ctypes binding of the plain-C CPU oracle (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgangfit_oracle.so")
+
+ALGO_TIGHTLY_PACK = 0
+ALGO_DISTRIBUTE_EVENLY = 1
+ALGO_MINIMAL_FRAGMENTATION = 2
+NO_NODE = 0xFFFFFFFF
+APP_SKIPPABLE = 1
+
+APP_DTYPE = np.dtype(
+    [("drv", "<i8", (3,)), ("exe", "<i8", (3,)), ("k", "<i4"), ("flags", "<u4")], align=True
+)
+RESULT_DTYPE = np.dtype(
+    [("has_capacity", "<i4"), ("driver_node", "<u4"), ("exec_len", "<u4"), ("evaluated", "<u4")], align=True
+)
+assert APP_DTYPE.itemsize == 56 and RESULT_DTYPE.itemsize == 16
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/gangfit_oracle.c with gcc (seconds)."""
+    src = os.path.join(_HERE, "gangfit_oracle.c")
+    hdr = os.path.join(_HERE, "gangfit_oracle.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgangfit_oracle.so"])
+    return _LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        p = C.c_void_p
+        L.go_spark_binpack.restype = C.c_int
+        L.go_spark_binpack.argtypes = [C.c_int, p, C.c_uint32, p, p, C.c_uint32, p, C.c_uint32, p, p]
+        L.go_spark_binpack_closed_form.restype = C.c_int
+        L.go_spark_binpack_closed_form.argtypes = L.go_spark_binpack.argtypes
+        L.go_fit_independent.restype = None
+        L.go_fit_independent.argtypes = [C.c_int, C.c_int, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p,
+                                         C.c_uint32, p, p, p]
+        L.go_fit_fifo_chain.restype = C.c_int32
+        L.go_fit_fifo_chain.argtypes = L.go_fit_independent.argtypes
+        L.go_node_capacity.restype = C.c_int64
+        L.go_node_capacity.argtypes = [p, p, p]
+        L.go_packing_efficiency.restype = None
+        L.go_packing_efficiency.argtypes = [p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, p]
+        L.go_executor_first_fit.restype = C.c_uint32
+        L.go_executor_first_fit.argtypes = [p, C.c_uint32, p, p, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_apps(drv, exe, k, flags=None) -> np.ndarray:
+    """Pack per-app arrays (A x 3, A x 3, A, A) into the go_app record layout."""
+    drv = np.asarray(drv, dtype=np.int64).reshape(-1, 3)
+    exe = np.asarray(exe, dtype=np.int64).reshape(-1, 3)
+    k = np.asarray(k, dtype=np.int32).reshape(-1)
+    apps = np.zeros(len(k), dtype=APP_DTYPE)
+    apps["drv"], apps["exe"], apps["k"] = drv, exe, k
+    if flags is not None:
+        apps["flags"] = np.asarray(flags, dtype=np.uint32)
+    return apps
+
+
+def exec_offsets(k: np.ndarray) -> np.ndarray:
+    off = np.zeros(len(k), dtype=np.uint64)
+    if len(k) > 1:
+        off[1:] = np.cumsum(np.asarray(k[:-1], dtype=np.uint64))
+    return off
+
+
+@dataclass
+class BatchOut:
+    results: np.ndarray  # RESULT_DTYPE
+    exec_off: np.ndarray  # uint64
+    exec_nodes: np.ndarray  # uint32, concatenated
+    failed_at: int = -1
+    avail_after: Optional[np.ndarray] = None
+
+    def placement(self, a: int) -> Tuple[bool, int, np.ndarray]:
+        r = self.results[a]
+        n = int(r["exec_len"])
+        o = int(self.exec_off[a])
+        return bool(r["has_capacity"]), int(r["driver_node"]), self.exec_nodes[o:o + n]
+
+
+def _prep(avail, driver_order, exec_order):
+    avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3)
+    d = np.ascontiguousarray(driver_order, dtype=np.uint32)
+    x = np.ascontiguousarray(exec_order, dtype=np.uint32)
+    return avail, d, x
+
+
+def fit_independent(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False) -> BatchOut:
+    avail, d, x = _prep(avail, driver_order, exec_order)
+    apps = np.ascontiguousarray(apps)
+    res = np.zeros(len(apps), dtype=RESULT_DTYPE)
+    off = exec_offsets(apps["k"])
+    out = np.zeros(int(apps["k"].astype(np.int64).sum()) + 1, dtype=np.uint32)
+    lib().go_fit_independent(algo, int(closed_form), _ptr(avail), len(avail), _ptr(apps), len(apps), _ptr(d), len(d),
+                             _ptr(x), len(x), _ptr(res), _ptr(off), _ptr(out))
+    return BatchOut(res, off, out[:-1])
+
+
+def fit_fifo_chain(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False) -> BatchOut:
+    avail, d, x = _prep(avail, driver_order, exec_order)
+    avail = avail.copy()
+    apps = np.ascontiguousarray(apps)
+    res = np.zeros(len(apps), dtype=RESULT_DTYPE)
+    off = exec_offsets(apps["k"])
+    out = np.zeros(int(apps["k"].astype(np.int64).sum()) + 1, dtype=np.uint32)
+    failed = lib().go_fit_fifo_chain(algo, int(closed_form), _ptr(avail), len(avail), _ptr(apps), len(apps), _ptr(d),
+                                     len(d), _ptr(x), len(x), _ptr(res), _ptr(off), _ptr(out))
+    return BatchOut(res, off, out[:-1], int(failed), avail)
+
+
+def spark_binpack(algo: int, avail, drv, exe, k: int, driver_order, exec_order, closed_form: bool = False):
+    """One decision. Returns (has_capacity, driver_node, exec_nodes ndarray)."""
+    apps = make_apps([drv], [exe], [k])
+    out = fit_independent(algo, avail, apps, driver_order, exec_order, closed_form)
+    return out.placement(0)
+
+
+def node_capacity(avail3, reserved3, required3) -> int:
+    a = np.asarray(avail3, dtype=np.int64)
+    r = np.asarray(reserved3, dtype=np.int64)
+    q = np.asarray(required3, dtype=np.int64)
+    return int(lib().go_node_capacity(_ptr(a), _ptr(r), _ptr(q)))
+
+
+def packing_efficiency(avail, sched, drv, exe, driver_node: int, exec_nodes):
+    avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3)
+    sched = np.ascontiguousarray(sched, dtype=np.int64).reshape(-1, 3)
+    app = make_apps([drv], [exe], [len(exec_nodes)])
+    en = np.ascontiguousarray(exec_nodes, dtype=np.uint32)
+    eff = np.zeros((len(avail), 3), dtype=np.float64)
+    avg = np.zeros(4, dtype=np.float64)
+    lib().go_packing_efficiency(_ptr(avail), _ptr(sched), len(avail), _ptr(app), driver_node, _ptr(en), len(en),
+                                _ptr(eff), _ptr(avg))
+    return eff, avg
+
+
+def executor_first_fit(avail, exe, exec_order) -> int:
+    avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3)
+    e = np.asarray(exe, dtype=np.int64)
+    x = np.ascontiguousarray(exec_order, dtype=np.uint32)
+    return int(lib().go_executor_first_fit(_ptr(avail), len(avail), _ptr(e), _ptr(x), len(x)))

@@ -1,0 +1,590 @@
+/*
+ * gangfit_oracle.c — CPU ORACLE (test infrastructure, NOT product code; see gangfit_oracle.h).
+ *
+ * Two independent restatements of the reference's gang bin-packing:
+ *   (i)  literal   — the add-then-compare loops exactly as the Go code runs them, Go maps keyed by node name
+ *                    replaced by arrays keyed by the dense node index;
+ *   (ii) closed form — floor-division capacities + O(N) driver choice.
+ * tests/ require (i) == (ii) on every input; the HIP path is compared with (i).
+ *
+ * File:line citations are relative to /root/reference;
+ * LIB = vendor/github.com/palantir/k8s-spark-scheduler-lib/pkg.
+ */
+#include "gangfit_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- Resources (LIB/resources/resources.go) */
+
+/* Resources.GreaterThan, resources.go:239-241: ANY component greater. */
+static int res_greater_than(const int64_t a[3], const int64_t b[3]) {
+    return a[0] > b[0] || a[1] > b[1] || a[2] > b[2];
+}
+static void res_add(int64_t a[3], const int64_t b[3]) { /* resources.go:201-205 */
+    a[0] += b[0];
+    a[1] += b[1];
+    a[2] += b[2];
+}
+static void res_sub(int64_t a[3], const int64_t b[3]) { /* resources.go:207-211 */
+    a[0] -= b[0];
+    a[1] -= b[1];
+    a[2] -= b[2];
+}
+
+/* ---------------------------------------------------------------- reservedResources map (NodeGroupResources) */
+
+/* `reserved := make(resources.NodeGroupResources, ...)` (binpack.go:72): a fresh, empty map per driver candidate.
+ * Array keyed by node index + a touched list so that "fresh" costs O(entries) instead of O(N). */
+typedef struct {
+    int64_t *r;        /* n_nodes x 3 */
+    uint8_t *present;  /* key exists */
+    uint32_t *touched;
+    uint32_t n_touched;
+    uint32_t n_nodes;
+} reserved_map;
+
+static int rm_init(reserved_map *m, uint32_t n_nodes) {
+    m->n_nodes = n_nodes;
+    m->n_touched = 0;
+    m->r = (int64_t *)calloc((size_t)n_nodes * 3 + 3, sizeof(int64_t));
+    m->present = (uint8_t *)calloc((size_t)n_nodes + 1, 1);
+    m->touched = (uint32_t *)malloc(((size_t)n_nodes + 1) * sizeof(uint32_t));
+    return m->r && m->present && m->touched;
+}
+static void rm_free(reserved_map *m) {
+    free(m->r);
+    free(m->present);
+    free(m->touched);
+}
+static void rm_clear(reserved_map *m) {
+    for (uint32_t i = 0; i < m->n_touched; ++i) {
+        uint32_t n = m->touched[i];
+        m->present[n] = 0;
+        m->r[3 * n] = m->r[3 * n + 1] = m->r[3 * n + 2] = 0;
+    }
+    m->n_touched = 0;
+}
+/* `if reservedResources[n] == nil { reservedResources[n] = resources.Zero() }` */
+static int64_t *rm_get_or_zero(reserved_map *m, uint32_t n) {
+    if (!m->present[n]) {
+        m->present[n] = 1;
+        m->touched[m->n_touched++] = n;
+    }
+    return &m->r[3 * n];
+}
+
+/* ---------------------------------------------------------------- literal executor packers */
+
+/* tightlyPackExecutors, LIB/binpack/pack_tightly.go:34-63 */
+static int tightly_pack_executors(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t k,
+                                  const uint32_t *order, uint32_t n_x, reserved_map *reserved,
+                                  uint32_t *out) {
+    int32_t count = 0;
+    if (k == 0) return 1; /* :42-44 */
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t n = order[i];
+        if (n >= n_nodes) continue; /* :51 `!ok`: Add, Sub, break — no placement, entry is never read again */
+        int64_t *rsv = rm_get_or_zero(reserved, n); /* :46-48 */
+        for (;;) {
+            res_add(rsv, exe);                               /* :50 */
+            if (res_greater_than(rsv, &avail[3 * n])) {      /* :52 */
+                res_sub(rsv, exe);                           /* :53 */
+                break;
+            }
+            out[count++] = n;                                /* :56 */
+            if (count == k) return 1;                        /* :57-59 */
+        }
+    }
+    return 0; /* :62 */
+}
+
+/* distributeExecutorsEvenly, LIB/binpack/distribute_evenly.go:34-73 */
+static int distribute_executors_evenly(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t k,
+                                       const uint32_t *order, uint32_t n_x, reserved_map *reserved,
+                                       uint32_t *out) {
+    /* availableNodes := map[name]bool (:41-44).  Known names: flag by node index (so a duplicated name is ONE key,
+     * as in the Go map).  Unknown names (>= n_nodes) are deleted on their first visit and can never place anything;
+     * they are tracked per position. */
+    uint8_t *avail_known = (uint8_t *)calloc((size_t)n_nodes + 1, 1);
+    uint8_t *avail_unknown_pos = (uint8_t *)calloc((size_t)n_x + 1, 1);
+    uint64_t n_available = 0;
+    int32_t count = 0;
+    int ok = 0;
+    if (!avail_known || !avail_unknown_pos) goto done;
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t n = order[i];
+        if (n < n_nodes) {
+            if (!avail_known[n]) {
+                avail_known[n] = 1;
+                ++n_available;
+            }
+        } else {
+            avail_unknown_pos[i] = 1;
+            ++n_available;
+        }
+    }
+    if (k == 0) { /* :46-48 */
+        ok = 1;
+        goto done;
+    }
+    while (n_available > 0) {                                   /* :49 */
+        for (uint32_t i = 0; i < n_x; ++i) {                    /* :50 */
+            uint32_t n = order[i];
+            if (n >= n_nodes) {
+                if (!avail_unknown_pos[i]) continue;            /* :51-53 */
+                avail_unknown_pos[i] = 0;                       /* :59-62 `!ok` -> delete */
+                --n_available;
+                continue;
+            }
+            if (!avail_known[n]) continue;                      /* :51-53 */
+            int64_t *rsv = rm_get_or_zero(reserved, n);         /* :55-57 */
+            res_add(rsv, exe);                                  /* :58 */
+            if (res_greater_than(rsv, &avail[3 * n])) {         /* :60 */
+                avail_known[n] = 0;                             /* :62 */
+                --n_available;
+                res_sub(rsv, exe);                              /* :63 */
+            } else {
+                out[count++] = n;                               /* :65 */
+                if (count == k) {                               /* :66-68 */
+                    ok = 1;
+                    goto done;
+                }
+            }
+        }
+    }
+done:
+    free(avail_known);
+    free(avail_unknown_pos);
+    return ok;
+}
+
+/* ---------------------------------------------------------------- capacity (LIB/capacity/capacity.go) */
+
+static int64_t floor_div(int64_t a, int64_t b) { /* b > 0 */
+    int64_t q = a / b, r = a % b;
+    return (r != 0 && r < 0) ? q - 1 : q;
+}
+
+/* getCapacityAgainstSingleDimension, capacity.go:36-56 */
+static int64_t capacity_single_dim(int64_t available, int64_t reserved, int64_t required) {
+    if (reserved > available) return 0;          /* :37-40 */
+    if (required == 0) return INT64_MAX;         /* :42-45 math.MaxInt */
+    return floor_div(available - reserved, required); /* :48-55 QuoRound(..., RoundFloor) */
+}
+
+/* GetNodeCapacity, capacity.go:59-75 */
+int64_t go_node_capacity(const int64_t avail[3], const int64_t reserved[3], const int64_t required[3]) {
+    int64_t c = capacity_single_dim(avail[0], reserved[0], required[0]);
+    int64_t m = capacity_single_dim(avail[1], reserved[1], required[1]);
+    int64_t g = capacity_single_dim(avail[2], reserved[2], required[2]);
+    int64_t r = c < m ? c : m;
+    return r < g ? r : g;
+}
+
+/* ---------------------------------------------------------------- minimalFragmentation (next-tier packer) */
+
+typedef struct {
+    uint32_t node;
+    int64_t cap;
+} node_cap;
+
+/* sort.Search: smallest i in [0,n) with pred true (pred monotone), else n. */
+static uint32_t search_cap_ge(const node_cap *v, uint32_t n, int64_t target) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (v[mid].cap >= target) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+/* internalMinimalFragmentation, minimal_fragmentation.go:93-137.  Returns 1 and writes k nodes on success. */
+static int internal_min_frag(int64_t k, const node_cap *caps_in, uint32_t n, uint32_t *out) {
+    node_cap *caps = (node_cap *)malloc(((size_t)n + 1) * sizeof(node_cap));
+    int64_t count = 0;
+    int ok = 0;
+    if (!caps) return 0;
+    memcpy(caps, caps_in, (size_t)n * sizeof(node_cap)); /* :96-97 */
+    while (n > 0) {                                      /* :101 */
+        uint32_t pos = search_cap_ge(caps, n, k);        /* :103-105 */
+        if (pos != n) {                                  /* :107-110 */
+            for (int64_t i = 0; i < k; ++i) out[count++] = caps[pos].node;
+            ok = 1;
+            break;
+        }
+        int64_t max_cap = caps[n - 1].cap;                               /* :113 */
+        uint32_t first_max = search_cap_ge(caps, n, max_cap);            /* :114-116 */
+        uint32_t cur = first_max;                                        /* :119 */
+        for (; k >= max_cap && cur < n; ++cur) {                         /* :120 */
+            for (int64_t i = 0; i < max_cap; ++i) out[count++] = caps[cur].node; /* :122 */
+            k -= max_cap;                                                /* :123 */
+        }
+        if (k == 0) { /* :126-128 */
+            ok = 1;
+            break;
+        }
+        memmove(&caps[first_max], &caps[cur], (size_t)(n - cur) * sizeof(node_cap)); /* :130 */
+        n -= (cur - first_max);
+    }
+    free(caps);
+    return ok;
+}
+
+/* stable insertion-merge sort by capacity ascending (sort.SliceStable, minimal_fragmentation.go:64-66) */
+static void stable_sort_caps(node_cap *v, uint32_t n) {
+    if (n < 2) return;
+    node_cap *tmp = (node_cap *)malloc((size_t)n * sizeof(node_cap));
+    if (!tmp) return;
+    for (uint32_t w = 1; w < n; w *= 2) {
+        for (uint32_t lo = 0; lo < n; lo += 2 * w) {
+            uint32_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            uint32_t i = lo, j = mid, o = lo;
+            while (i < mid && j < hi) tmp[o++] = (v[j].cap < v[i].cap) ? v[j++] : v[i++];
+            while (i < mid) tmp[o++] = v[i++];
+            while (j < hi) tmp[o++] = v[j++];
+        }
+        memcpy(v, tmp, (size_t)n * sizeof(node_cap));
+    }
+    free(tmp);
+}
+
+/* minimalFragmentation, minimal_fragmentation.go:33-91 */
+static int minimal_fragmentation(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t k,
+                                 const uint32_t *order, uint32_t n_x, reserved_map *reserved, uint32_t *out) {
+    static const int64_t zero[3] = {0, 0, 0};
+    if (k == 0) return 1; /* :40-42 */
+    node_cap *caps = (node_cap *)malloc(((size_t)n_x + 1) * sizeof(node_cap));
+    uint32_t n = 0;
+    int ok = 0;
+    if (!caps) return 0;
+    /* capacity.GetNodeCapacities (capacity.go:78-102) then FilterOutNodesWithoutCapacity (:105-113) */
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t node = order[i];
+        if (node >= n_nodes) continue; /* capacity.go:87 `if ... ok` */
+        const int64_t *rsv = reserved->present[node] ? &reserved->r[3 * node] : zero;
+        int64_t c = go_node_capacity(&avail[3 * node], rsv, exe);
+        if (c > 0) {
+            caps[n].node = node;
+            caps[n].cap = c;
+            ++n;
+        }
+    }
+    if (n == 0) goto done;             /* :46-48 */
+    stable_sort_caps(caps, n);         /* :64-66 */
+    {
+        int64_t max_cap = caps[n - 1].cap; /* :67 */
+        if ((int64_t)k < max_cap) {        /* :68 */
+            /* (executorCount + maxCapacity) / 2 in Go int arithmetic; with maxCapacity == math.MaxInt the sum
+             * wraps in Go too — mirror with unsigned wrap then signed divide. */
+            int64_t target = (int64_t)((uint64_t)k + (uint64_t)max_cap) / 2; /* :69 */
+            uint32_t first = search_cap_ge(caps, n, target);                   /* :70-72 */
+            if (internal_min_frag(k, caps, first, out)) {                      /* :75-77 */
+                ok = 1;
+                goto done;
+            }
+        }
+    }
+    ok = internal_min_frag(k, caps, n, out); /* :81 */
+done:
+    free(caps);
+    return ok;
+}
+
+/* ---------------------------------------------------------------- SparkBinPack, literal */
+
+static int run_packer(int algo, const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t k,
+                      const uint32_t *order, uint32_t n_x, reserved_map *reserved, uint32_t *out) {
+    switch (algo) {
+    case GO_ALGO_TIGHTLY_PACK:
+        return tightly_pack_executors(avail, n_nodes, exe, k, order, n_x, reserved, out);
+    case GO_ALGO_DISTRIBUTE_EVENLY:
+        return distribute_executors_evenly(avail, n_nodes, exe, k, order, n_x, reserved, out);
+    case GO_ALGO_MINIMAL_FRAGMENTATION:
+        return minimal_fragmentation(avail, n_nodes, exe, k, order, n_x, reserved, out);
+    default:
+        return 0;
+    }
+}
+
+/* SparkBinPack, LIB/binpack/binpack.go:60-87 */
+static int spark_binpack_rm(int algo, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                            const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                            uint32_t n_x, uint32_t *driver_out, uint32_t *exec_out, reserved_map *reserved) {
+    for (uint32_t i = 0; i < n_d; ++i) {                                          /* :67 */
+        uint32_t d = driver_order[i];
+        if (d >= n_nodes || res_greater_than(app->drv, &avail[3 * d])) continue;  /* :68-71 driver-fit check */
+        rm_clear(reserved);                                                       /* :72 fresh map */
+        int64_t *rsv = rm_get_or_zero(reserved, d);
+        rsv[0] = app->drv[0];                                                     /* :73 */
+        rsv[1] = app->drv[1];
+        rsv[2] = app->drv[2];
+        if (run_packer(algo, avail, n_nodes, app->exe, app->k, exec_order, n_x, reserved, exec_out)) { /* :74-76 */
+            *driver_out = d;
+            return 1; /* :77-83 */
+        }
+    }
+    *driver_out = GO_NO_NODE;
+    return 0; /* :86 EmptyPackingResult */
+}
+
+int go_spark_binpack(int algo, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                     const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
+                     uint32_t *driver_out, uint32_t *exec_out) {
+    reserved_map rm;
+    int ok = 0;
+    if (rm_init(&rm, n_nodes))
+        ok = spark_binpack_rm(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out,
+                              exec_out, &rm);
+    else
+        *driver_out = GO_NO_NODE;
+    rm_free(&rm);
+    return ok;
+}
+
+/* ---------------------------------------------------------------- closed-form restatement */
+
+/* cap(n, base) clamped to k: the number of consecutive successful add-then-compare steps on one node
+ * (SURVEY.md section 8).  avail may be negative; base/exe are >= 0. */
+static int64_t cap_clamped(const int64_t avail[3], const int64_t base[3], const int64_t exe[3], int64_t k) {
+    int64_t c = k;
+    for (int j = 0; j < 3; ++j) {
+        int64_t a = avail[j] - base[j];
+        if (a < 0) return 0;
+        if (exe[j] == 0) continue;
+        int64_t q = a / exe[j];
+        if (q < c) c = q;
+    }
+    return c;
+}
+
+static int spark_binpack_closed(int algo, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                                const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                                uint32_t n_x, uint32_t *driver_out, uint32_t *exec_out) {
+    static const int64_t zero[3] = {0, 0, 0};
+    const int64_t k = app->k;
+    int64_t *c0 = (int64_t *)malloc(((size_t)n_x + 1) * sizeof(int64_t));
+    /* pos_in_x[node] = position in exec order (first occurrence), or -1 */
+    int64_t *pos_in_x = (int64_t *)malloc(((size_t)n_nodes + 1) * sizeof(int64_t));
+    int ok = 0;
+    *driver_out = GO_NO_NODE;
+    if (!c0 || !pos_in_x) goto done;
+    for (uint32_t n = 0; n < n_nodes; ++n) pos_in_x[n] = -1;
+    int64_t s = 0;
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t n = exec_order[i];
+        c0[i] = 0;
+        if (n >= n_nodes) continue;
+        if (pos_in_x[n] >= 0) continue; /* duplicate name: its reserved entry is already saturated (tightly) */
+        pos_in_x[n] = i;
+        c0[i] = cap_clamped(&avail[3 * n], zero, app->exe, k);
+        s += c0[i];
+    }
+    /* O(N) driver choice */
+    uint32_t d = GO_NO_NODE;
+    int64_t cd = 0;
+    for (uint32_t i = 0; i < n_d; ++i) {
+        uint32_t cand = driver_order[i];
+        if (cand >= n_nodes || res_greater_than(app->drv, &avail[3 * cand])) continue;
+        int64_t total = s, cdd = 0;
+        if (pos_in_x[cand] >= 0) {
+            cdd = cap_clamped(&avail[3 * cand], app->drv, app->exe, k);
+            total = s - c0[pos_in_x[cand]] + cdd;
+        }
+        if (total >= k) {
+            d = cand;
+            cd = cdd;
+            break;
+        }
+    }
+    if (d == GO_NO_NODE) goto done;
+    if (pos_in_x[d] >= 0) c0[pos_in_x[d]] = cd;
+    *driver_out = d;
+    ok = 1;
+    if (k == 0) goto done;
+    if (algo == GO_ALGO_TIGHTLY_PACK) {
+        int64_t taken = 0;
+        for (uint32_t i = 0; i < n_x && taken < k; ++i) {
+            int64_t t = c0[i] < k - taken ? c0[i] : k - taken;
+            for (int64_t j = 0; j < t; ++j) exec_out[taken + j] = exec_order[i];
+            taken += t;
+        }
+    } else { /* distribute evenly: passes r = 1, 2, ...: every node with cap >= r, in order */
+        int64_t taken = 0;
+        for (int64_t r = 1; taken < k; ++r)
+            for (uint32_t i = 0; i < n_x && taken < k; ++i)
+                if (c0[i] >= r) exec_out[taken++] = exec_order[i];
+    }
+done:
+    free(c0);
+    free(pos_in_x);
+    return ok;
+}
+
+int go_spark_binpack_closed_form(int algo, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                                 const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                                 uint32_t n_x, uint32_t *driver_out, uint32_t *exec_out) {
+    if (algo == GO_ALGO_MINIMAL_FRAGMENTATION) /* no closed form: same literal code */
+        return go_spark_binpack(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out,
+                                exec_out);
+    return spark_binpack_closed(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out,
+                                exec_out);
+}
+
+/* ---------------------------------------------------------------- batch drivers */
+
+static int binpack_any(int algo, int closed_form, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                       const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
+                       uint32_t *driver_out, uint32_t *exec_out, reserved_map *rm) {
+    if (closed_form && algo != GO_ALGO_MINIMAL_FRAGMENTATION)
+        return spark_binpack_closed(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out,
+                                    exec_out);
+    return spark_binpack_rm(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out, exec_out,
+                            rm);
+}
+
+void go_fit_independent(int algo, int closed_form, const int64_t *avail, uint32_t n_nodes, const go_app *apps,
+                        uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                        uint32_t n_x, go_result *results, const uint64_t *exec_off, uint32_t *exec_out) {
+    reserved_map rm;
+    int have_rm = rm_init(&rm, n_nodes);
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        uint32_t d = GO_NO_NODE;
+        int ok = have_rm && binpack_any(algo, closed_form, avail, n_nodes, &apps[a], driver_order, n_d,
+                                        exec_order, n_x, &d, exec_out + exec_off[a], &rm);
+        results[a].has_capacity = ok;
+        results[a].driver_node = ok ? d : GO_NO_NODE;
+        results[a].exec_len = ok ? (uint32_t)apps[a].k : 0;
+        results[a].evaluated = 1;
+    }
+    rm_free(&rm);
+}
+
+/* sparkResourceUsage + SubtractUsageIfExists (internal/extender/sparkpods.go:139-146, LIB/resources/resources.go:129-135):
+ * res := map{}; res[driverNode] = drv; for n in execNodes { res[n] = exe }  — a MAP, so multiplicity is lost and a
+ * driver entry is overwritten by an executor on the same node; then avail[n] -= res[n] for n in metadata. */
+static void subtract_usage(int64_t *avail, uint32_t n_nodes, const go_app *app, uint32_t driver_node,
+                           const uint32_t *exec_nodes, uint32_t n_exec, uint8_t *mark /* n_nodes zeros */) {
+    int driver_overwritten = 0;
+    for (uint32_t i = 0; i < n_exec; ++i) {
+        uint32_t n = exec_nodes[i];
+        if (n == driver_node) driver_overwritten = 1;
+        if (n >= n_nodes || mark[n]) continue;
+        mark[n] = 1;
+        res_sub(&avail[3 * n], app->exe);
+    }
+    for (uint32_t i = 0; i < n_exec; ++i)
+        if (exec_nodes[i] < n_nodes) mark[exec_nodes[i]] = 0;
+    if (!driver_overwritten && driver_node < n_nodes) res_sub(&avail[3 * driver_node], app->drv);
+}
+
+int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_nodes, const go_app *apps,
+                          uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d,
+                          const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                          const uint64_t *exec_off, uint32_t *exec_out) {
+    reserved_map rm;
+    int have_rm = rm_init(&rm, n_nodes);
+    uint8_t *mark = (uint8_t *)calloc((size_t)n_nodes + 1, 1);
+    int32_t failed_at = -1;
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        results[a].has_capacity = 0;
+        results[a].driver_node = GO_NO_NODE;
+        results[a].exec_len = 0;
+        results[a].evaluated = 0;
+    }
+    if (!have_rm || !mark) goto done;
+    for (uint32_t a = 0; a < n_apps; ++a) { /* resource.go:229 over earlier drivers, then :321 for the last */
+        uint32_t d = GO_NO_NODE;
+        int ok = binpack_any(algo, closed_form, avail, n_nodes, &apps[a], driver_order, n_d, exec_order, n_x, &d,
+                             exec_out + exec_off[a], &rm);
+        results[a].evaluated = 1;
+        results[a].has_capacity = ok;
+        results[a].driver_node = ok ? d : GO_NO_NODE;
+        results[a].exec_len = ok ? (uint32_t)apps[a].k : 0;
+        if (a + 1 == n_apps) break; /* the driver being filtered: no subtraction afterwards */
+        if (!ok) {
+            if (apps[a].flags & GO_APP_SKIPPABLE) continue; /* resource.go:244-248 */
+            failed_at = (int32_t)a;                          /* :249-251 -> "failure-earlier-driver" */
+            break;
+        }
+        subtract_usage(avail, n_nodes, &apps[a], d, exec_out + exec_off[a], (uint32_t)apps[a].k, mark); /* :255-259 */
+    }
+done:
+    free(mark);
+    rm_free(&rm);
+    return failed_at;
+}
+
+/* ---------------------------------------------------------------- efficiencies (LIB/binpack/efficiency.go) */
+
+/* Quantity.Value(): rounded to the nearest integer AWAY from zero (K8S apimachinery quantity.go:731-734,
+ * math.go:169-199).  unit = 1000 for cpu (canonical milli), 1 for memory bytes and gpu count. */
+static int64_t value_round_away(int64_t v, int64_t unit) {
+    if (unit == 1) return v;
+    int64_t q = v / unit, r = v % unit;
+    if (r > 0) return q + 1;
+    if (r < 0) return q - 1;
+    return q;
+}
+static int64_t normalize_resource(int64_t v) { return v == 0 ? 1 : v; } /* efficiency.go:105-110 */
+
+void go_packing_efficiency(const int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *app,
+                           uint32_t driver_node, const uint32_t *exec_nodes, uint32_t n_exec, double *eff_out,
+                           double avg_out[4]) {
+    static const int64_t unit[3] = {1000, 1, 1};
+    int64_t *reserved = (int64_t *)calloc((size_t)n_nodes * 3 + 3, sizeof(int64_t));
+    double cpu_sum = 0, mem_sum = 0, gpu_sum = 0, max_sum = 0;
+    uint32_t with_gpu = 0;
+    if (!reserved) return;
+    /* `reserved` as left by SparkBinPack: driver + one executorResources per placed executor */
+    if (driver_node < n_nodes) res_add(&reserved[3 * driver_node], app->drv);
+    for (uint32_t i = 0; i < n_exec; ++i)
+        if (exec_nodes[i] < n_nodes) res_add(&reserved[3 * exec_nodes[i]], app->exe);
+    for (uint32_t n = 0; n < n_nodes; ++n) {
+        double e[3];
+        for (int j = 0; j < 3; ++j) { /* computePackingEfficiency, efficiency.go:79-103 */
+            int64_t used = sched[3 * n + j] - avail[3 * n + j] + reserved[3 * n + j];
+            int64_t sv = value_round_away(sched[3 * n + j], unit[j]);
+            e[j] = (double)value_round_away(used, unit[j]) / (double)normalize_resource(sv);
+        }
+        int has_gpu = value_round_away(sched[3 * n + 2], 1) != 0;
+        if (!has_gpu) e[2] = 0.0; /* :91-94 */
+        if (eff_out) {
+            eff_out[3 * n] = e[0];
+            eff_out[3 * n + 1] = e[1];
+            eff_out[3 * n + 2] = e[2];
+        }
+        /* ComputeAvgPackingEfficiency, efficiency.go:114-156 */
+        cpu_sum += e[0];
+        mem_sum += e[1];
+        if (has_gpu) {
+            gpu_sum += e[2];
+            ++with_gpu;
+        }
+        double m = e[0] > e[1] ? e[0] : e[1];
+        max_sum += e[2] > m ? e[2] : m;
+    }
+    if (n_nodes == 0) { /* WorstAvgPackingEfficiency, :119-121 */
+        avg_out[0] = avg_out[1] = avg_out[2] = avg_out[3] = 0.0;
+    } else {
+        double len = (double)n_nodes;
+        avg_out[0] = cpu_sum / len;
+        avg_out[1] = mem_sum / len;
+        avg_out[2] = with_gpu == 0 ? 1.0 : gpu_sum / (double)with_gpu;
+        avg_out[3] = max_sum / len;
+    }
+    free(reserved);
+}
+
+/* ---------------------------------------------------------------- executor first-fit */
+
+/* rescheduleExecutor first-fit, internal/extender/resource.go:658-662 */
+uint32_t go_executor_first_fit(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3],
+                               const uint32_t *exec_order, uint32_t n_x) {
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t n = exec_order[i];
+        if (n >= n_nodes) continue; /* order is derived from the metadata keys; defensive */
+        if (!res_greater_than(exe, &avail[3 * n])) return n;
+    }
+    return GO_NO_NODE;
+}

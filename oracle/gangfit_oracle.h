@@ -1,0 +1,100 @@
+/*
+ * gangfit_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the gang bin-packing hot path of palantir/k8s-spark-scheduler,
+ * used ONLY as the checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * Nothing under k8s-spark-scheduler_amd/ may include, link or call this.
+ *
+ * Paths below are relative to /root/reference; LIB = vendor/github.com/palantir/k8s-spark-scheduler-lib/pkg.
+ *
+ * Parity status (see DESIGN.md "Oracle pinning"):
+ *   - TightlyPack feasibility: pinned by the reference's own tests T1/T3/T4
+ *     (internal/extender/resource_test.go:27-71, unschedulablepods_test.go:24-80) — tests/test_oracle_reference_kats.py.
+ *   - DistributeEvenly placements and FIFO replay with >=1 earlier driver: PARITY UNPINNED — no reference test
+ *     selects them and the Go reference cannot be built here (no Go toolchain). They follow the cited source
+ *     line by line and are cross-checked against an independent pure-Python restatement (oracle/pyoracle.py).
+ *
+ * Conventions: a node "name" is a dense uint32 index; an index >= n_nodes is a name that is NOT a key of
+ * nodesSchedulingMetadata (the `!ok` branches of the reference). Quantities are canonical int64:
+ * cpu milli-cores, memory bytes, gpu count (resource.Quantity restricted to exactly-representable values).
+ */
+#ifndef GANGFIT_ORACLE_H
+#define GANGFIT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GO_ALGO_TIGHTLY_PACK 0      /* LIB/binpack/pack_tightly.go:25-63 */
+#define GO_ALGO_DISTRIBUTE_EVENLY 1 /* LIB/binpack/distribute_evenly.go:25-73 */
+#define GO_ALGO_MINIMAL_FRAGMENTATION 2 /* LIB/binpack/minimal_fragmentation.go:33-137 */
+
+#define GO_NO_NODE 0xFFFFFFFFu
+#define GO_APP_SKIPPABLE 1u /* shouldSkipDriverFifo() is true for this earlier driver, resource.go:264-270 */
+
+typedef struct go_app {
+    int64_t drv[3]; /* driver   cpu milli, mem bytes, gpu */
+    int64_t exe[3]; /* executor cpu milli, mem bytes, gpu */
+    int32_t k;      /* executorCount (MinExecutorCount for dynamic allocation, resource.go:242,325) */
+    uint32_t flags;
+} go_app;
+
+typedef struct go_result {
+    int32_t has_capacity;  /* PackingResult.HasCapacity */
+    uint32_t driver_node;  /* PackingResult.DriverNode, GO_NO_NODE when empty */
+    uint32_t exec_len;     /* len(PackingResult.ExecutorNodes): k when feasible, 0 otherwise */
+    uint32_t evaluated;    /* 0 for apps after a FIFO chain abort */
+} go_result;
+
+/* One SparkBinPack evaluation, literal loops (binpack.go:60-87 + the chosen executor packer).
+ * avail: n_nodes x 3 row-major (AvailableResources).  exec_out: room for app->k entries.
+ * Returns has_capacity. */
+int go_spark_binpack(int algo, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                     const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
+                     uint32_t *driver_out, uint32_t *exec_out);
+
+/* Same decision through the array/closed-form restatement (SURVEY.md section 8 "array restatement"):
+ * capacities by floor division, O(N) driver choice.  Must agree with go_spark_binpack everywhere. */
+int go_spark_binpack_closed_form(int algo, const int64_t *avail, uint32_t n_nodes, const go_app *app,
+                                 const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                                 uint32_t n_x, uint32_t *driver_out, uint32_t *exec_out);
+
+/* Batch of independent decisions against ONE snapshot (the unschedulable-pod scan shape,
+ * internal/extender/unschedulablepods.go:93-166).  exec_out is the concatenation, app i at exec_off[i].
+ * closed_form selects which restatement runs. */
+void go_fit_independent(int algo, int closed_form, const int64_t *avail, uint32_t n_nodes, const go_app *apps,
+                        uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                        uint32_t n_x, go_result *results, const uint64_t *exec_off, uint32_t *exec_out);
+
+/* FIFO replay + final pack (internal/extender/resource.go:224-262, 304-328): apps[0..n_apps-2] are the earlier
+ * drivers in creation order, apps[n_apps-1] is the driver being filtered.  avail is mutated exactly like
+ * availableNodesSchedulingMetadata (sparkResourceUsage overwrite quirk, sparkpods.go:139-146).
+ * Returns the index of the first non-skippable earlier driver that did not fit ("failure-earlier-driver"),
+ * or -1. */
+int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_nodes, const go_app *apps,
+                          uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d,
+                          const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                          const uint64_t *exec_off, uint32_t *exec_out);
+
+/* capacity.GetNodeCapacity (LIB/capacity/capacity.go:36-75) on canonical int64; INT64_MAX stands for math.MaxInt. */
+int64_t go_node_capacity(const int64_t avail[3], const int64_t reserved[3], const int64_t required[3]);
+
+/* Packing efficiencies (LIB/binpack/efficiency.go:66-156).  sched: n_nodes x 3 SchedulableResources.
+ * Per-node efficiencies after placing (driver_node, exec nodes) go to eff_out (n_nodes x 3 doubles: cpu, mem, gpu;
+ * nullable).  avg_out[4] = {CPU, Memory, GPU, Max} of ComputeAvgPackingEfficiency over ALL nodes summed in
+ * ascending node-index order (the reference sums in Go map order, which is unspecified —
+ * internal/extender/resource.go:372-381). */
+void go_packing_efficiency(const int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *app,
+                           uint32_t driver_node, const uint32_t *exec_nodes, uint32_t n_exec, double *eff_out,
+                           double avg_out[4]);
+
+/* Single executor first-fit used by rescheduleExecutor (internal/extender/resource.go:658-662). */
+uint32_t go_executor_first_fit(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3],
+                               const uint32_t *exec_order, uint32_t n_x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
