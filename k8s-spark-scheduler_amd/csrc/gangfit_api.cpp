@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -95,6 +96,9 @@ struct gf_ctx {
     PinnedBuf<int64_t> h_table;
     PinnedBuf<uint32_t> h_index;
     bool work_valid = false;
+    bool d_identity = false;
+    int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
+    uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
     // batch buffers
     DeviceBuf<gf_app> d_apps;
@@ -139,6 +143,7 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     t.n_d = ctx->n_d;
     t.n_slots = ctx->n_slots;
     t.n_nodes = ctx->n_nodes;
+    t.d_identity = ctx->d_identity ? 1u : 0u;
     return t;
 }
 
@@ -158,8 +163,14 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
-        GF_HIP(ctx, gangfit::launch_fit_fifo_chain(algo, make_table(ctx, ctx->d_work.ptr), n_apps, d_apps, d_results,
-                                                   d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, stats, stream));
+        // as much of the table front as fits next to the kernel's fixed LDS needs stays in LDS for the whole chain
+        const size_t fixed = gangfit::fifo_fixed_lds_bytes(ctx->fifo_waves);
+        uint32_t lds_slots = ctx->lds_budget > fixed ? (uint32_t)((ctx->lds_budget - fixed) / 24) : 0;
+        lds_slots &= ~63u;
+        if (lds_slots > ctx->n_slots) lds_slots = ctx->n_slots;
+        GF_HIP(ctx, gangfit::launch_fit_fifo_chain(algo, ctx->fifo_waves, make_table(ctx, ctx->d_work.ptr), lds_slots,
+                                                   n_apps, d_apps, d_results, d_exec_nodes, ctx->d_scratch.ptr, half,
+                                                   d_failed, stats, stream));
     } else {
         return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
     }
@@ -195,6 +206,15 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     ctx->info.wavefront_size = prop.warpSize;
     ctx->info.clock_khz = prop.clockRate;
     ctx->info.hbm_bytes = (int64_t)prop.totalGlobalMem;
+    ctx->lds_budget = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (const char* w = std::getenv("GANGFIT_FIFO_WAVES")) {
+        const int v = std::atoi(w);
+        if (v == 1 || v == 4 || v == 16) ctx->fifo_waves = v;
+    }
+    if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
+        const long v = std::atol(l);
+        if (v >= 0 && (uint32_t)v <= ctx->lds_budget) ctx->lds_budget = (uint32_t)v;
+    }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.warpSize != 64) {
         delete ctx;
         return GF_ERR_NO_DEVICE;  // the kernels are gfx950 / wave64 only
@@ -324,10 +344,13 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         tmem[s] = ctx->avail[1][n];
         tgpu[s] = ctx->avail[2][n];
     }
+    bool identity = true;
     for (uint32_t i = 0; i < n_d; ++i) {
         const uint32_t n = driver_order[i];
         dslot[i] = n < n_nodes ? node_slot[n] : sentinel;
+        identity = identity && dslot[i] == i;
     }
+    ctx->d_identity = identity;
 
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still read the old tables
     GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));

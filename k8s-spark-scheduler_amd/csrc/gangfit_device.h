@@ -24,6 +24,7 @@ struct NodeTable {
     uint32_t n_d;
     uint32_t n_slots;
     uint32_t n_nodes;
+    uint32_t d_identity;  // 1 when dslot[i] == i for all i (driver order is a prefix of the executor order)
 };
 
 // Kernel-visible counters used by tests/bench to report visited bytes honestly (SURVEY.md section 8d
@@ -38,10 +39,13 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
                                   gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
 
-hipError_t launch_fit_fifo_chain(gf_algo algo, const NodeTable& table, uint32_t n_apps, const gf_app* d_apps,
-                                 gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                 uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats,
-                                 hipStream_t stream);
+// FIFO chain: one workgroup of n_waves (1, 4 or 16) wavefronts; the first lds_slots slots of the working table are
+// kept in LDS (24 bytes per slot + fifo_fixed_lds_bytes).  Followed by the slot->node translation kernel.
+size_t fifo_fixed_lds_bytes(int n_waves);
+hipError_t launch_fit_fifo_chain(gf_algo algo, int n_waves, const NodeTable& table, uint32_t lds_slots,
+                                 uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
+                                 uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
+                                 ScanStats* d_stats, hipStream_t stream);
 
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
 // Writes the number of mismatching lanes/cases to *d_mismatch.

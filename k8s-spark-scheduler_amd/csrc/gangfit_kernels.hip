@@ -15,8 +15,9 @@
 //   scan (TightlyPack) or __ballot/popcount ranks (DistributeEvenly).  Pure integer results, bit-exact.
 //   The scan is LAZY like the reference: it stops at the chunk where K executors are placed.
 //
-// No MFMA (nothing here is a contraction), no LDS staging in this first version (node table is read through
-// L1/L2 with coalesced 8-byte-per-lane loads) — see DESIGN.md for the roofline discussion.
+// Two kernels: fit_independent_kernel (one wave per app, table read through L1/L2 with coalesced 8-byte-per-lane
+// loads) and fit_fifo_chain_kernel (one workgroup walks the chain, table front resident in LDS).
+// No MFMA (nothing here is a contraction) — see DESIGN.md for the roofline discussion.
 
 #include "gangfit_device.h"
 
@@ -155,68 +156,133 @@ __device__ __forceinline__ bool driver_fits(int64_t a0, int64_t a1, int64_t a2, 
     return app.drv0 <= a0 && app.drv1 <= a1 && app.drv2 <= a2;
 }
 
+// ------------------------------------------------------------------------------------------------ table views
+
+// Node table read straight from global memory (L1/L2 resident after first touch): independent-batch kernel.
+struct GlobalView {
+    int64_t* cpu;
+    int64_t* mem;
+    int64_t* gpu;
+    __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
+        a0 = cpu[s];
+        a1 = mem[s];
+        a2 = gpu[s];
+    }
+    __device__ __forceinline__ void sub(uint32_t s, int64_t r0, int64_t r1, int64_t r2) const {
+        cpu[s] -= r0;
+        mem[s] -= r1;
+        gpu[s] -= r2;
+    }
+};
+
+// FIFO chain: the first `lds_slots` slots of the (mutable) working table live in LDS — the front of the executor
+// priority order is what every app of the chain scans — the tail stays in global memory.
+struct HybridView {
+    int64_t* lcpu;  // LDS, SoA: consecutive lanes read consecutive 8-byte words (ds_read_b64, conflict-free)
+    int64_t* lmem;
+    int64_t* lgpu;
+    uint32_t lds_slots;
+    int64_t* cpu;  // global
+    int64_t* mem;
+    int64_t* gpu;
+    __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
+        if (s < lds_slots) {
+            a0 = lcpu[s];
+            a1 = lmem[s];
+            a2 = lgpu[s];
+        } else {
+            a0 = cpu[s];
+            a1 = mem[s];
+            a2 = gpu[s];
+        }
+    }
+    __device__ __forceinline__ void sub(uint32_t s, int64_t r0, int64_t r1, int64_t r2) const {
+        if (s < lds_slots) {
+            lcpu[s] -= r0;
+            lmem[s] -= r1;
+            lgpu[s] -= r2;
+        } else {
+            cpu[s] -= r0;
+            mem[s] -= r1;
+            gpu[s] -= r2;
+        }
+    }
+};
+
+// Index tables that never change during a launch.
+struct Orders {
+    const uint32_t* slot_node;
+    const uint32_t* dslot;
+    uint32_t n_x;
+    uint32_t n_d;
+    bool d_identity;  // dslot[i] == i for every i (driver order == a prefix of the executor order): skip the gather
+    __device__ __forceinline__ uint32_t driver_slot(uint32_t i) const { return d_identity ? i : dslot[i]; }
+};
+
 // ------------------------------------------------------------------------------------------------ emission
 
-// Lane `lane` owns a run of t copies of `node` starting at out[start].  Short runs: per-lane loop.  Long runs are
+// Lane `lane` owns a run of t copies of `id` starting at out[start].  Short runs: per-lane loop.  Long runs are
 // written cooperatively by all 64 lanes (coalesced) so that one huge node cannot serialise the wave.
-__device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t start, int32_t t, uint32_t node,
-                                          int lane) {
+__device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t start, int32_t t, uint32_t id, int lane) {
     constexpr int32_t kLong = 16;
     uint64_t long_mask = __ballot(t > kLong);
     if (t > 0 && t <= kLong) {
-        for (int32_t i = 0; i < t; ++i) out[start + i] = node;
+        for (int32_t i = 0; i < t; ++i) out[start + i] = id;
     }
     while (long_mask) {
         const int src = __ffsll((unsigned long long)long_mask) - 1;
         long_mask &= long_mask - 1;
         const int64_t s = read_lane(start, src);
         const int32_t n = read_lane(t, src);
-        const uint32_t nd = read_lane(node, src);
-        for (int32_t i = lane; i < n; i += kWave) out[s + i] = nd;
+        const uint32_t v = read_lane(id, src);
+        for (int32_t i = lane; i < n; i += kWave) out[s + i] = v;
     }
 }
 
-// ------------------------------------------------------------------------------------------------ driver scan
+__device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t width) {
+    return (n - b) < width ? (n - b) : width;
+}
+
+// ------------------------------------------------------------------------------------------------ wave-level decision
+// One wavefront evaluates one application.  SLOTS selects what is written to out[]: slot ids (FIFO kernel; translated
+// by a follow-up kernel) or the caller's node indices (independent kernel).
 
 // First position p in [from, n_d) of driverNodePriorityOrder whose node passes the driver-fit check, else -1.
-__device__ __forceinline__ int64_t first_fitting_driver(const NodeTable& T, const App& app, uint32_t from, int lane,
-                                                        unsigned long long& visited) {
-    for (uint32_t b = from; b < T.n_d; b += kWave) {
+template <class View>
+__device__ __forceinline__ int64_t wave_first_fitting_driver(const View& V, const Orders& O, const App& app,
+                                                             uint32_t from, int lane, unsigned long long& visited) {
+    for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool fit = false;
-        if (i < T.n_d) {
-            const uint32_t s = T.dslot[i];
-            fit = driver_fits(T.cpu[s], T.mem[s], T.gpu[s], app);
+        if (i < O.n_d) {
+            int64_t a0, a1, a2;
+            V.load(O.driver_slot(i), a0, a1, a2);
+            fit = driver_fits(a0, a1, a2, app);
         }
-        visited += (T.n_d - b) < (uint32_t)kWave ? (T.n_d - b) : (uint32_t)kWave;
+        visited += chunk_len(O.n_d, b, kWave);
         const uint64_t m = __ballot(fit);
         if (m) return (int64_t)b + (__ffsll((unsigned long long)m) - 1);
     }
     return -1;
 }
 
-// Clamped capacities of one slot without / with the driver as base (wave-uniform slot -> every lane computes the
-// same values; used only on the rare fallback path).
-__device__ __forceinline__ void slot_caps(const NodeTable& T, const App& app, uint32_t s, int32_t& c0, int32_t& cd) {
-    const int64_t a0 = T.cpu[s], a1 = T.mem[s], a2 = T.gpu[s];
-    c0 = cap3(a0, a1, a2, app);
-    cd = cap3(a0 - app.drv0, a1 - app.drv1, a2 - app.drv2, app);
-}
-
-// O(N) driver choice on the fallback path: first position p > after in driver order with
+// O(N) driver choice on the fallback path: first position p >= from in driver order with
 //   fit(p) && total(p) >= K,  total = S            if the node is not an executor candidate
 //                                   = S - c0 + cd   otherwise           (SURVEY.md section 8 "O(N) driver choice")
-__device__ __forceinline__ int64_t next_feasible_driver(const NodeTable& T, const App& app, uint32_t from, int64_t S,
-                                                        int lane, unsigned long long& visited) {
-    for (uint32_t b = from; b < T.n_d; b += kWave) {
+template <class View>
+__device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, const Orders& O, const App& app,
+                                                             uint32_t from, int64_t S, int lane,
+                                                             unsigned long long& visited) {
+    for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool ok = false;
-        if (i < T.n_d) {
-            const uint32_t s = T.dslot[i];
-            const int64_t a0 = T.cpu[s], a1 = T.mem[s], a2 = T.gpu[s];
+        if (i < O.n_d) {
+            const uint32_t s = O.driver_slot(i);
+            int64_t a0, a1, a2;
+            V.load(s, a0, a1, a2);
             if (driver_fits(a0, a1, a2, app)) {
                 int64_t total = S;
-                if (s < T.n_x) {
+                if (s < O.n_x) {
                     const int32_t c0 = cap3(a0, a1, a2, app);
                     const int32_t cd = cap3(a0 - app.drv0, a1 - app.drv1, a2 - app.drv2, app);
                     total = S - c0 + cd;
@@ -224,28 +290,27 @@ __device__ __forceinline__ int64_t next_feasible_driver(const NodeTable& T, cons
                 ok = total >= (int64_t)app.k;
             }
         }
-        visited += (T.n_d - b) < (uint32_t)kWave ? (T.n_d - b) : (uint32_t)kWave;
+        visited += chunk_len(O.n_d, b, kWave);
         const uint64_t m = __ballot(ok);
         if (m) return (int64_t)b + (__ffsll((unsigned long long)m) - 1);
     }
     return -1;
 }
 
-// ------------------------------------------------------------------------------------------------ TightlyPack scan
-
-// tightlyPackExecutors with the driver reserved on slot ds.  Returns sum of clamped capacities over the visited
+// tightlyPackExecutors with the driver reserved on slot ds.  Returns the sum of clamped capacities over the visited
 // prefix (>= K  <=>  feasible; the scan stops at the first chunk where K is reached).  Writes placements.
-__device__ __forceinline__ int64_t tight_scan(const NodeTable& T, const App& app, uint32_t ds,
-                                              uint32_t* __restrict__ out, int lane, unsigned long long& visited) {
+template <class View, bool SLOTS>
+__device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& O, const App& app, uint32_t ds,
+                                                   uint32_t* __restrict__ out, int lane,
+                                                   unsigned long long& visited) {
     const int64_t K = app.k;
     int64_t taken = 0;
-    for (uint32_t b = 0; b < T.n_x; b += kWave) {
+    for (uint32_t b = 0; b < O.n_x; b += kWave) {
         const uint32_t j = b + lane;
         int32_t c = 0;
-        uint32_t node = GF_NO_NODE;
-        if (j < T.n_x) {
-            int64_t a0 = T.cpu[j], a1 = T.mem[j], a2 = T.gpu[j];
-            node = T.slot_node[j];
+        if (j < O.n_x) {
+            int64_t a0, a1, a2;
+            V.load(j, a0, a1, a2);
             if (j == ds) {
                 a0 -= app.drv0;
                 a1 -= app.drv1;
@@ -253,14 +318,16 @@ __device__ __forceinline__ int64_t tight_scan(const NodeTable& T, const App& app
             }
             c = cap3(a0, a1, a2, app);
         }
-        visited += (T.n_x - b) < (uint32_t)kWave ? (T.n_x - b) : (uint32_t)kWave;
+        visited += chunk_len(O.n_x, b, kWave);
         const int32_t incl = wave_inclusive_scan(c);
         const int32_t tot = read_lane(incl, kWave - 1);
         if (tot > 0) {
             const int64_t start = taken + (int64_t)(incl - c);
             const int64_t room = K - start;
             const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
-            emit_runs(out, start, t, node, lane);
+            uint32_t id = j;
+            if (!SLOTS && t > 0) id = O.slot_node[j];
+            emit_runs(out, start, t, id, lane);
         }
         taken += tot;
         if (taken >= K) break;
@@ -268,24 +335,22 @@ __device__ __forceinline__ int64_t tight_scan(const NodeTable& T, const App& app
     return taken;
 }
 
-// ------------------------------------------------------------------------------------------------ DistributeEvenly
-
 // Pass r = 1 of distributeExecutorsEvenly, lazily: every node with cap >= 1, in order, until K are placed.
 // Records the surviving slots (needed for passes >= 2) in surv[].  Returns the number of nodes with cap >= 1 seen
 // (>= K means the app is placed entirely by pass 1).
-__device__ __forceinline__ int64_t even_pass1(const NodeTable& T, const App& app, uint32_t ds,
-                                              uint32_t* __restrict__ out, uint32_t* __restrict__ surv, int lane,
-                                              unsigned long long& visited) {
+template <class View, bool SLOTS>
+__device__ __forceinline__ int64_t wave_even_pass1(const View& V, const Orders& O, const App& app, uint32_t ds,
+                                                   uint32_t* __restrict__ out, uint32_t* __restrict__ surv, int lane,
+                                                   unsigned long long& visited) {
     const int64_t K = app.k;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     int64_t taken = 0;
-    for (uint32_t b = 0; b < T.n_x; b += kWave) {
+    for (uint32_t b = 0; b < O.n_x; b += kWave) {
         const uint32_t j = b + lane;
         bool flag = false;
-        uint32_t node = GF_NO_NODE;
-        if (j < T.n_x) {
-            int64_t a0 = T.cpu[j], a1 = T.mem[j], a2 = T.gpu[j];
-            node = T.slot_node[j];
+        if (j < O.n_x) {
+            int64_t a0, a1, a2;
+            V.load(j, a0, a1, a2);
             if (j == ds) {
                 a0 -= app.drv0;
                 a1 -= app.drv1;
@@ -293,11 +358,11 @@ __device__ __forceinline__ int64_t even_pass1(const NodeTable& T, const App& app
             }
             flag = cap_ge1(a0, a1, a2, app);
         }
-        visited += (T.n_x - b) < (uint32_t)kWave ? (T.n_x - b) : (uint32_t)kWave;
+        visited += chunk_len(O.n_x, b, kWave);
         const uint64_t m = __ballot(flag);
         const int64_t pos = taken + (int64_t)__popcll((unsigned long long)(m & lt_mask));
         if (flag && pos < K) {
-            out[pos] = node;
+            out[pos] = SLOTS ? j : O.slot_node[j];
             surv[pos] = j;
         }
         taken += (int64_t)__popcll((unsigned long long)m);
@@ -308,22 +373,23 @@ __device__ __forceinline__ int64_t even_pass1(const NodeTable& T, const App& app
 
 // Passes r >= 2 when pass 1 found m1 < K nodes.  surv[0..m1) = surviving slots in order; caps[] receives their
 // clamped capacities.  Returns S = sum of capacities (feasible <=> S >= K) and, when feasible, completes out[].
-__device__ __forceinline__ int64_t even_general(const NodeTable& T, const App& app, uint32_t ds,
-                                                uint32_t* __restrict__ out, const uint32_t* __restrict__ surv,
-                                                uint32_t* __restrict__ caps, int64_t m1, int lane) {
+template <class View, bool SLOTS>
+__device__ __forceinline__ int64_t wave_even_general(const View& V, const Orders& O, const App& app, uint32_t ds,
+                                                     uint32_t* __restrict__ out, const uint32_t* __restrict__ surv,
+                                                     uint32_t* __restrict__ caps, int64_t m1, int lane) {
     const int64_t K = app.k;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // surv[] was written rank-wise by other lanes of this wave in pass 1
+    // surv[] was written rank-wise by other lanes in pass 1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // capacities of the survivors
     int64_t S = 0;
     for (int64_t b = 0; b < m1; b += kWave) {
         const int64_t i = b + lane;
         int32_t c = 0;
         if (i < m1) {
             const uint32_t j = surv[i];
-            int64_t a0 = T.cpu[j], a1 = T.mem[j], a2 = T.gpu[j];
+            int64_t a0, a1, a2;
+            V.load(j, a0, a1, a2);
             if (j == ds) {
                 a0 -= app.drv0;
                 a1 -= app.drv1;
@@ -336,7 +402,7 @@ __device__ __forceinline__ int64_t even_general(const NodeTable& T, const App& a
         S += read_lane(incl, kWave - 1);
     }
     if (S < K) return S;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // caps[] written above are re-read below by other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // caps[] are re-read below by other lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // passes r = 2, 3, ...: nodes with cap >= r, in order, appended until K placements exist
     int64_t pos = m1;
@@ -351,103 +417,125 @@ __device__ __forceinline__ int64_t even_general(const NodeTable& T, const App& a
             }
             const uint64_t m = __ballot(flag);
             const int64_t p = pos + (int64_t)__popcll((unsigned long long)(m & lt_mask));
-            if (flag && p < K) out[p] = T.slot_node[j];
+            if (flag && p < K) out[p] = SLOTS ? j : O.slot_node[j];
             pos += (int64_t)__popcll((unsigned long long)m);
         }
     }
     return S;
 }
 
-// ------------------------------------------------------------------------------------------------ one decision
-
 struct Decision {
     bool feasible;
-    uint32_t dpos;     // position in driver order
-    uint32_t ds;       // driver slot
-    int64_t pass1;     // DistributeEvenly: number of pass-1 placements (first occurrences); TightlyPack: unused
+    uint32_t ds;    // driver slot
+    int64_t pass1;  // DistributeEvenly: number of pass-1 placements (= distinct executor nodes); TightlyPack: unused
 };
 
-// SparkBinPack for one app by one wave.  out = exec_nodes + exec_off.  scratch_a / scratch_b: K uint32 each.
-template <int ALGO>
-__device__ __forceinline__ Decision decide(const NodeTable& T, const App& app, uint32_t* __restrict__ out,
-                                           uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
-                                           int lane, unsigned long long& xvis, unsigned long long& dvis) {
+template <int ALGO, class View, bool SLOTS>
+__device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, const App& app, uint32_t ds,
+                                             uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
+                                             uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
+                                             unsigned long long& xvis) {
+    if (ALGO == GF_ALGO_TIGHTLY_PACK) return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis);
+    pass1 = wave_even_pass1<View, SLOTS>(V, O, app, ds, out, scratch_a, lane, xvis);
+    if (pass1 >= (int64_t)app.k) return pass1;
+    return wave_even_general<View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, pass1, lane);
+}
+
+// Recovery after the first fitting candidate (position p0, slot ds0) could not host the gang: S_d is the exact
+// capacity total with the driver reserved on ds0 (< K).  Finds the first later candidate that works and packs with it.
+// Same answer as the reference's retry loop (binpack.go:67-85) in O(N) instead of O(|D| N).
+template <int ALGO, class View, bool SLOTS>
+__device__ __forceinline__ Decision wave_fallback(const View& V, const Orders& O, const App& app, int64_t p0,
+                                                  uint32_t ds0, int64_t S_d, uint32_t* __restrict__ out,
+                                                  uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
+                                                  int lane, unsigned long long& xvis, unsigned long long& dvis) {
     Decision dec;
     dec.feasible = false;
-    dec.dpos = 0;
-    dec.ds = 0;
+    dec.ds = ds0;
     dec.pass1 = 0;
     const int64_t K = app.k;
-
-    // (1) first driver candidate that passes the driver-fit check (binpack.go:67-71)
-    int64_t p0 = first_fitting_driver(T, app, 0, lane, dvis);
-    if (p0 < 0) return dec;
-    uint32_t ds = T.dslot[p0];
-    if (K == 0) {  // pack_tightly.go:42-44 / distribute_evenly.go:46-48: nothing to place
-        dec.feasible = true;
-        dec.dpos = (uint32_t)p0;
-        dec.ds = ds;
-        return dec;
-    }
-
-    // (2) executors with the driver reserved on that candidate — the common case ends here
-    int64_t S_d;  // sum over executor order of min(cap(n, base_d), K) (exact whenever < K)
-    int64_t pass1 = 0;
-    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
-        S_d = tight_scan(T, app, ds, out, lane, xvis);
-    } else {
-        pass1 = even_pass1(T, app, ds, out, scratch_a, lane, xvis);
-        S_d = pass1 >= K ? pass1 : even_general(T, app, ds, out, scratch_a, scratch_b, pass1, lane);
-    }
-    if (S_d >= K) {
-        dec.feasible = true;
-        dec.dpos = (uint32_t)p0;
-        dec.ds = ds;
-        dec.pass1 = pass1;
-        return dec;
-    }
-
-    // (3) rare: the first candidate's node is where the executors were needed.  S_d is now the exact total with
-    //     the driver on ds; recover S (no driver anywhere) and pick the first later candidate d with
-    //     fit(d) && S - c0[d] + cd[d] >= K.  Same answer as the reference's retry loop (binpack.go:67-85).
     int64_t S = S_d;
-    if (ds < T.n_x) {
-        int32_t c0, cd;
-        slot_caps(T, app, ds, c0, cd);
-        S = S_d + c0 - cd;
+    if (ds0 < O.n_x) {  // undo the driver reservation: S = S_d + cap(ds0, 0) - cap(ds0, drv)
+        int64_t a0, a1, a2;
+        V.load(ds0, a0, a1, a2);
+        S = S_d + cap3(a0, a1, a2, app) - cap3(a0 - app.drv0, a1 - app.drv1, a2 - app.drv2, app);
     }
     if (S < K) return dec;
-    const int64_t p1 = next_feasible_driver(T, app, (uint32_t)p0 + 1, S, lane, dvis);
+    const int64_t p1 = wave_next_feasible_driver(V, O, app, (uint32_t)p0 + 1, S, lane, dvis);
     if (p1 < 0) return dec;
-    ds = T.dslot[p1];
-    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
-        S_d = tight_scan(T, app, ds, out, lane, xvis);
-    } else {
-        pass1 = even_pass1(T, app, ds, out, scratch_a, lane, xvis);
-        S_d = pass1 >= K ? pass1 : even_general(T, app, ds, out, scratch_a, scratch_b, pass1, lane);
-    }
-    dec.feasible = S_d >= K;  // always true here; kept as a guard so a logic error shows up as a parity failure
-    dec.dpos = (uint32_t)p1;
+    const uint32_t ds = O.driver_slot((uint32_t)p1);
+    int64_t pass1 = 0;
+    const int64_t S1 = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis);
+    dec.feasible = S1 >= K;  // always true here; kept as a guard so a logic error shows up as a parity failure
     dec.ds = ds;
     dec.pass1 = pass1;
     return dec;
 }
 
-__device__ __forceinline__ void write_result(gf_result* __restrict__ results, uint32_t a, const NodeTable& T,
-                                             const App& app, const Decision& dec, int lane) {
-    if (lane == 0) {
-        gf_result r;
-        r.has_capacity = dec.feasible ? 1 : 0;
-        r.driver_node = dec.feasible ? T.slot_node[dec.ds] : GF_NO_NODE;
-        r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
-        r.evaluated = 1;
-        results[a] = r;
+// SparkBinPack for one app by one wave.  out = exec_nodes + exec_off.  scratch_a / scratch_b: K uint32 each.
+template <int ALGO, class View, bool SLOTS>
+__device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, const App& app,
+                                                uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
+                                                uint32_t* __restrict__ scratch_b, int lane, unsigned long long& xvis,
+                                                unsigned long long& dvis) {
+    Decision dec;
+    dec.feasible = false;
+    dec.ds = 0;
+    dec.pass1 = 0;
+    const int64_t K = app.k;
+    // (1) first driver candidate that passes the driver-fit check (binpack.go:67-71)
+    const int64_t p0 = wave_first_fitting_driver(V, O, app, 0, lane, dvis);
+    if (p0 < 0) return dec;
+    const uint32_t ds = O.driver_slot((uint32_t)p0);
+    dec.ds = ds;
+    if (K == 0) {  // pack_tightly.go:42-44 / distribute_evenly.go:46-48: nothing to place
+        dec.feasible = true;
+        return dec;
     }
+    // (2) executors with the driver reserved on that candidate — the common case ends here
+    int64_t pass1 = 0;
+    const int64_t S_d = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis);
+    if (S_d >= K) {
+        dec.feasible = true;
+        dec.pass1 = pass1;
+        return dec;
+    }
+    // (3) rare: the first candidate's node is where the executors were needed
+    return wave_fallback<ALGO, View, SLOTS>(V, O, app, p0, ds, S_d, out, scratch_a, scratch_b, lane, xvis, dvis);
 }
 
-// ------------------------------------------------------------------------------------------------ kernels
+// sparkResourceUsage + SubtractUsageIfExists (internal/extender/sparkpods.go:139-146, LIB/resources/resources.go:129-135)
+// applied from a placement list of SLOT ids: ONE executor request per distinct executor node; the driver request only
+// if no executor sits on the driver node.  Wave-level; used on the slow path of the FIFO kernel.
+template <int ALGO, class View>
+__device__ __forceinline__ void wave_commit_from_list(const View& V, const App& app, const Decision& dec,
+                                                      const uint32_t* __restrict__ out, int lane) {
+    const int64_t K = app.k;
+    bool driver_hosts_exec = false;
+    // out[] was written by other lanes of this wave: make it visible before re-reading it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int64_t first_region = (ALGO == GF_ALGO_TIGHTLY_PACK) ? K : (dec.pass1 < K ? dec.pass1 : K);
+    for (int64_t b = 0; b < K; b += kWave) {
+        const int64_t i = b + lane;
+        bool first = false;
+        uint32_t s = GF_NO_NODE;
+        if (i < K) {
+            s = out[i];
+            if (ALGO == GF_ALGO_TIGHTLY_PACK)
+                first = (i == 0) || (out[i - 1] != s);  // placements are node-major runs
+            else
+                first = i < first_region;  // pass 1 lists every executor node exactly once
+        }
+        if (first) V.sub(s, app.exe0, app.exe1, app.exe2);
+        if (__ballot(i < K && s == dec.ds)) driver_hosts_exec = true;
+    }
+    if (!driver_hosts_exec && lane == 0) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+}
 
-// Independent batch: one wave per app, 4 apps per workgroup.  Grid = ceil(n_apps / 4) >> 256 CUs at the target sizes.
+// ------------------------------------------------------------------------------------------------ independent batch
+
+// One wave per app, 4 apps per workgroup.  Grid = ceil(n_apps / 4) >> 256 CUs at the target sizes.
 template <int ALGO>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     NodeTable T, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
@@ -458,79 +546,258 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     if (a >= n_apps) return;
     const App app = load_app(apps, a);
+    GlobalView V{T.cpu, T.mem, T.gpu};
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
     unsigned long long xvis = 0, dvis = 0;
-    const Decision dec = decide<ALGO>(T, app, exec_nodes + app.exec_off, scratch + app.exec_off,
-                                      scratch + scratch_half + app.exec_off, lane, xvis, dvis);
-    write_result(results, a, T, app, dec, lane);
-    if (stats != nullptr && lane == 0) {
-        atomicAdd(&stats->exec_slots_visited, xvis);
-        atomicAdd(&stats->driver_slots_visited, dvis);
+    const Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off,
+                                                              scratch + app.exec_off,
+                                                              scratch + scratch_half + app.exec_off, lane, xvis, dvis);
+    if (lane == 0) {
+        gf_result r;
+        r.has_capacity = dec.feasible ? 1 : 0;
+        r.driver_node = dec.feasible ? T.slot_node[dec.ds] : GF_NO_NODE;
+        r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
+        r.evaluated = 1;
+        results[a] = r;
+        if (stats != nullptr) {
+            atomicAdd(&stats->exec_slots_visited, xvis);
+            atomicAdd(&stats->driver_slots_visited, dvis);
+        }
     }
 }
 
-// sparkResourceUsage + SubtractUsageIfExists (internal/extender/sparkpods.go:139-146, LIB/resources/resources.go:129-135)
-// applied from the placement list the wave has just written: ONE executor request per distinct executor node;
-// the driver request only if no executor sits on the driver node.
-template <int ALGO>
-__device__ __forceinline__ void commit_usage(const NodeTable& T, const App& app, const Decision& dec,
-                                             const uint32_t* __restrict__ out, int lane) {
-    const int64_t K = app.k;
-    const uint32_t dnode = T.slot_node[dec.ds];
-    bool driver_hosts_exec = false;
-    // out[] was written by other lanes of this wave: make it visible before re-reading it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const int64_t first_region = (ALGO == GF_ALGO_TIGHTLY_PACK) ? K : (dec.pass1 < K ? dec.pass1 : K);
-    for (int64_t b = 0; b < K; b += kWave) {
-        const int64_t i = b + lane;
-        bool first = false;
-        uint32_t node = GF_NO_NODE;
-        if (i < K) {
-            node = out[i];
-            if (ALGO == GF_ALGO_TIGHTLY_PACK)
-                first = (i == 0) || (out[i - 1] != node);  // placements are node-major runs
-            else
-                first = i < first_region;  // pass 1 lists every executor node exactly once
-        }
-        if (first) {
-            const uint32_t s = T.node_slot[node];
-            T.cpu[s] -= app.exe0;
-            T.mem[s] -= app.exe1;
-            T.gpu[s] -= app.exe2;
-        }
-        if (__ballot(i < K && node == dnode)) driver_hosts_exec = true;
+// ------------------------------------------------------------------------------------------------ FIFO chain
+
+// Workgroup-level exchange of one value per wave through LDS.  Two alternating buffers: one __syncthreads per
+// exchange is enough (a wave can only be one exchange ahead of the slowest wave).
+template <int NW>
+struct Exchange {
+    int64_t first[2][NW];
+    int32_t tot[2][NW];
+};
+
+template <int NW>
+__device__ __forceinline__ int64_t block_min(Exchange<NW>* X, int& xb, int64_t wave_value, int wave, int lane) {
+    if (NW == 1) return wave_value;
+    if (lane == 0) X->first[xb][wave] = wave_value;
+    __syncthreads();
+    int64_t m = X->first[xb][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        const int64_t v = X->first[xb][w];
+        m = v < m ? v : m;
     }
-    if (!driver_hosts_exec && lane == 0) {
-        T.cpu[dec.ds] -= app.drv0;
-        T.mem[dec.ds] -= app.drv1;
-        T.gpu[dec.ds] -= app.drv2;
-    }
-    // the next app's scan (other lanes) must observe the residuals
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    xb ^= 1;
+    return m;
 }
 
-// FIFO chain: sequential over apps (each sees the residuals left by its predecessors), nodes in parallel.
-// Single wave in this version: no workgroup barriers on the critical path.
-template <int ALGO>
-__global__ __launch_bounds__(kWave) void fit_fifo_chain_kernel(NodeTable T, uint32_t n_apps,
-                                                               const gf_app* __restrict__ apps,
-                                                               gf_result* __restrict__ results,
-                                                               uint32_t* __restrict__ exec_nodes,
-                                                               uint32_t* __restrict__ scratch, uint64_t scratch_half,
-                                                               int32_t* __restrict__ chain_failed_at,
-                                                               ScanStats* __restrict__ stats) {
+template <int NW>
+__device__ __forceinline__ void block_scan(Exchange<NW>* X, int& xb, int32_t wave_total, int wave, int lane,
+                                           int64_t& prefix, int64_t& total) {
+    if (NW == 1) {
+        prefix = 0;
+        total = wave_total;
+        return;
+    }
+    if (lane == 0) X->tot[xb][wave] = wave_total;
+    __syncthreads();
+    int64_t p = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int32_t v = X->tot[xb][w];
+        t += v;
+        if (w < wave) p += v;
+    }
+    xb ^= 1;
+    prefix = p;
+    total = t;
+}
+
+constexpr int kAppStage = 32;  // app records staged into LDS per refill
+
+struct FifoShared {
+    App apps[kAppStage];
+    int32_t slow_feasible;
+    uint32_t slow_ds;
+    int64_t slow_pass1;
+};
+
+// FIFO replay (internal/extender/resource.go:224-262 + :321): apps strictly in order, each against the residuals its
+// predecessors left.  ONE workgroup of NW waves: nodes in parallel (NW*64 per step), apps sequential.  The working
+// table's front lives in LDS, so the per-app critical path is LDS latency + a few workgroup barriers instead of
+// global-memory round trips.  Placements are written as SLOT ids (translated by translate_kernel afterwards).
+template <int ALGO, int NW>
+__global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, uint32_t lds_slots, uint32_t n_apps,
+                                                                  const gf_app* __restrict__ apps,
+                                                                  gf_result* __restrict__ results,
+                                                                  uint32_t* __restrict__ exec_nodes,
+                                                                  uint32_t* __restrict__ scratch,
+                                                                  uint64_t scratch_half,
+                                                                  int32_t* __restrict__ chain_failed_at,
+                                                                  ScanStats* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t BLOCK = kWave * NW;
+    const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
+    const int wave = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- LDS carve: table front | exchange | shared scalars + staged apps
+    int64_t* lcpu = reinterpret_cast<int64_t*>(smem);
+    int64_t* lmem = lcpu + lds_slots;
+    int64_t* lgpu = lmem + lds_slots;
+    Exchange<NW>* X = reinterpret_cast<Exchange<NW>*>(lgpu + lds_slots);
+    FifoShared* sh = reinterpret_cast<FifoShared*>(X + 1);
+    for (uint32_t s = tid; s < lds_slots; s += BLOCK) {
+        lcpu[s] = T.cpu[s];
+        lmem[s] = T.mem[s];
+        lgpu[s] = T.gpu[s];
+    }
+    HybridView V{lcpu, lmem, lgpu, lds_slots, T.cpu, T.mem, T.gpu};
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
+    const bool mask_commit = O.n_x <= 64u * BLOCK;  // per-thread 64-bit hit mask covers every chunk of a scan
+
     unsigned long long xvis = 0, dvis = 0;
+    int xb = 0;
     int32_t failed_at = -1;
     uint32_t a = 0;
     for (; a < n_apps; ++a) {
-        const App app = load_app(apps, a);
+        // ---- stage the next kAppStage app records (incl. reciprocals) into LDS
+        if ((a % kAppStage) == 0) {
+            __syncthreads();  // previous stage fully consumed; also publishes the table fill / last commit
+            const uint32_t n_stage = (n_apps - a) < (uint32_t)kAppStage ? (n_apps - a) : (uint32_t)kAppStage;
+            if (tid < n_stage) sh->apps[tid] = load_app(apps, a + tid);
+            __syncthreads();
+        }
+        const App app = sh->apps[a % kAppStage];
+        const int64_t K = app.k;
         uint32_t* out = exec_nodes + app.exec_off;
-        const Decision dec = decide<ALGO>(T, app, out, scratch + app.exec_off, scratch + scratch_half + app.exec_off,
-                                          lane, xvis, dvis);
-        write_result(results, a, T, app, dec, lane);
-        if (a + 1 == n_apps) {
+        const bool last = (a + 1 == n_apps);
+
+        // ---- (1) first fitting driver candidate, BLOCK candidates per step
+        int64_t p0 = -1;
+        for (uint32_t b = 0; b < O.n_d; b += BLOCK) {
+            const uint32_t i = b + tid;
+            bool fit = false;
+            if (i < O.n_d) {
+                int64_t a0, a1, a2;
+                V.load(O.driver_slot(i), a0, a1, a2);
+                fit = driver_fits(a0, a1, a2, app);
+            }
+            dvis += chunk_len(O.n_d, b, BLOCK);
+            const uint64_t m = __ballot(fit);
+            const int64_t wfirst = m ? (int64_t)b + wave * kWave + (__ffsll((unsigned long long)m) - 1) : INT64_MAX;
+            const int64_t f = block_min<NW>(X, xb, wfirst, wave, lane);
+            if (f != INT64_MAX) {
+                p0 = f;
+                break;
+            }
+        }
+
+        Decision dec;
+        dec.feasible = false;
+        dec.ds = 0;
+        dec.pass1 = 0;
+        enum { kCommitDone, kCommitMask, kCommitList } commit = kCommitDone;
+        uint64_t hit = 0;  // bit `it`: this thread's slot in chunk `it` hosts >= 1 executor of this app
+        if (p0 >= 0) {
+            const uint32_t ds = O.driver_slot((uint32_t)p0);
+            dec.ds = ds;
+            if (K == 0) {
+                dec.feasible = true;
+                commit = kCommitMask;  // nothing placed: only the driver request is subtracted
+            } else {
+                // ---- (2) executors, BLOCK slots per step, lazy stop
+                int64_t taken = 0;
+                uint32_t it = 0;
+                for (uint32_t b = 0; b < O.n_x; b += BLOCK, ++it) {
+                    const uint32_t j = b + tid;
+                    int64_t a0 = -1, a1 = -1, a2 = -1;
+                    if (j < O.n_x) {
+                        V.load(j, a0, a1, a2);
+                        if (j == ds) {
+                            a0 -= app.drv0;
+                            a1 -= app.drv1;
+                            a2 -= app.drv2;
+                        }
+                    }
+                    xvis += chunk_len(O.n_x, b, BLOCK);
+                    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
+                        const int32_t c = (j < O.n_x) ? cap3(a0, a1, a2, app) : 0;
+                        const int32_t incl = wave_inclusive_scan(c);
+                        int64_t prefix, total;
+                        block_scan<NW>(X, xb, read_lane(incl, kWave - 1), wave, lane, prefix, total);
+                        if (total > 0) {
+                            const int64_t start = taken + prefix + (int64_t)(incl - c);
+                            const int64_t room = K - start;
+                            const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
+                            if (t > 0 && it < 64) hit |= 1ull << it;
+                            emit_runs(out, start, t, j, lane);
+                        }
+                        taken += total;
+                    } else {
+                        const bool flag = (j < O.n_x) && cap_ge1(a0, a1, a2, app);
+                        const uint64_t m = __ballot(flag);
+                        int64_t prefix, total;
+                        block_scan<NW>(X, xb, (int32_t)__popcll((unsigned long long)m), wave, lane, prefix, total);
+                        const int64_t pos = taken + prefix +
+                                            (int64_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+                        if (flag && pos < K) {
+                            out[pos] = j;
+                            scratch[app.exec_off + pos] = j;  // survivor list for the (rare) multi-pass path
+                            if (it < 64) hit |= 1ull << it;
+                        }
+                        taken += total;
+                    }
+                    if (taken >= K) break;
+                }
+                if (taken >= K) {
+                    dec.feasible = true;
+                    dec.pass1 = taken;
+                    commit = mask_commit ? kCommitMask : kCommitList;
+                } else {
+                    // ---- (3) slow path, wave 0 alone: multi-pass distribute-evenly and/or driver fallback.
+                    // `taken` is the exact capacity total S_d for tightly-pack, the pass-1 survivor count for evenly.
+                    __syncthreads();  // out[] / scratch[] writes of all waves are complete
+                    if (wave == 0) {
+                        uint32_t* sa = scratch + app.exec_off;
+                        uint32_t* sb = scratch + scratch_half + app.exec_off;
+                        Decision d2;
+                        d2.feasible = false;
+                        d2.ds = ds;
+                        d2.pass1 = taken;
+                        int64_t S_d = taken;
+                        if (ALGO != GF_ALGO_TIGHTLY_PACK)
+                            S_d = wave_even_general<HybridView, true>(V, O, app, ds, out, sa, sb, taken, lane);
+                        if (S_d >= K)
+                            d2.feasible = true;
+                        else
+                            d2 = wave_fallback<ALGO, HybridView, true>(V, O, app, p0, ds, S_d, out, sa, sb, lane, xvis,
+                                                                      dvis);
+                        if (d2.feasible && !last) wave_commit_from_list<ALGO, HybridView>(V, app, d2, out, lane);
+                        if (lane == 0) {
+                            sh->slow_feasible = d2.feasible ? 1 : 0;
+                            sh->slow_ds = d2.ds;
+                            sh->slow_pass1 = d2.pass1;
+                        }
+                    }
+                    __syncthreads();
+                    dec.feasible = sh->slow_feasible != 0;
+                    dec.ds = sh->slow_ds;
+                    dec.pass1 = sh->slow_pass1;
+                    commit = kCommitDone;
+                }
+            }
+        }
+
+        if (tid == 0) {
+            gf_result r;
+            r.has_capacity = dec.feasible ? 1 : 0;
+            r.driver_node = dec.feasible ? dec.ds : GF_NO_NODE;  // SLOT id; translate_kernel maps it to the node index
+            r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
+            r.evaluated = 1;
+            results[a] = r;
+        }
+        if (last) {
             ++a;
             break;  // the driver being filtered: nothing is subtracted after it (resource.go:321-328)
         }
@@ -540,10 +807,29 @@ __global__ __launch_bounds__(kWave) void fit_fifo_chain_kernel(NodeTable T, uint
             ++a;
             break;
         }
-        commit_usage<ALGO>(T, app, dec, out, lane);
+        // ---- (4) commit the usage of this earlier driver (sparkpods.go:139-146: one executor request per DISTINCT
+        //          executor node; the driver request only if no executor landed on the driver's node)
+        if (commit == kCommitMask) {
+            bool hosts = false;
+            uint64_t h = hit;
+            while (h) {
+                const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
+                h &= h - 1;
+                const uint32_t s = it * BLOCK + tid;
+                V.sub(s, app.exe0, app.exe1, app.exe2);
+                if (s == dec.ds) hosts = true;
+            }
+            // the thread that would scan slot ds knows whether an executor landed there (a slot beyond the cut or a
+            // driver-only slot >= n_x was never hit)
+            if (tid == dec.ds % BLOCK && !hosts) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+        } else if (commit == kCommitList) {
+            __syncthreads();  // every wave's placements are written
+            if (wave == 0) wave_commit_from_list<ALGO, HybridView>(V, app, dec, out, lane);
+        }
+        __syncthreads();  // residuals visible to every wave before the next app scans
     }
     // apps behind an abort are reported as not evaluated
-    for (uint32_t r = a + lane; r < n_apps; r += kWave) {
+    for (uint32_t r = a + tid; r < n_apps; r += BLOCK) {
         gf_result z;
         z.has_capacity = 0;
         z.driver_node = GF_NO_NODE;
@@ -551,13 +837,37 @@ __global__ __launch_bounds__(kWave) void fit_fifo_chain_kernel(NodeTable T, uint
         z.evaluated = 0;
         results[r] = z;
     }
-    if (lane == 0) {
+    __syncthreads();
+    // write the LDS-resident front of the working table back (gf_residual_get reads the global copy)
+    for (uint32_t s = tid; s < lds_slots; s += BLOCK) {
+        T.cpu[s] = lcpu[s];
+        T.mem[s] = lmem[s];
+        T.gpu[s] = lgpu[s];
+    }
+    if (tid == 0) {
         if (chain_failed_at != nullptr) *chain_failed_at = failed_at;
         if (stats != nullptr) {
             atomicAdd(&stats->exec_slots_visited, xvis);
             atomicAdd(&stats->driver_slots_visited, dvis);
         }
     }
+}
+
+// Placements and driver ids written by the FIFO kernel are SLOT ids; map them to the caller's node indices.
+// One wave per app (only evaluated, feasible apps own valid slices).
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void translate_kernel(const uint32_t* __restrict__ slot_node,
+                                                                         uint32_t n_apps,
+                                                                         const gf_app* __restrict__ apps,
+                                                                         gf_result* __restrict__ results,
+                                                                         uint32_t* __restrict__ exec_nodes) {
+    const int lane = lane_id();
+    const uint32_t a = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (a >= n_apps) return;
+    const gf_result r = results[a];
+    if (!r.evaluated || !r.has_capacity) return;
+    uint32_t* out = exec_nodes + apps[a].exec_off;
+    for (uint32_t i = lane; i < r.exec_len; i += kWave) out[i] = slot_node[out[i]];
+    if (lane == 0) results[a].driver_node = slot_node[r.driver_node];
 }
 
 // ------------------------------------------------------------------------------------------------ self-test
@@ -588,28 +898,29 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
         if (wave_inclusive_scan(v) != ref) ++bad;
         // (b) division
         const uint64_t r0 = splitmix64(s), r1 = splitmix64(s), r2 = splitmix64(s);
-        const int ebits = 1 + (int)(r0 % 61);                    // divisor magnitude 2^1 .. 2^61
+        const int ebits = 1 + (int)(r0 % 61);  // divisor magnitude 2^1 .. 2^61
         int64_t e = (int64_t)(r1 >> (64 - ebits));
         if (e == 0) e = 1;
         const int32_t k = (int32_t)(1 + (r2 % (uint64_t)GF_MAX_K));
         const int64_t lim = (int64_t)((1ull << 62) - 1);
         int64_t a;
         switch ((r0 >> 8) % 4) {
-        case 0: a = (int64_t)(splitmix64(s) >> 2); break;                       // uniform in [0, 2^62)
-        case 1: {                                                                // just around a multiple of e
+        case 0: a = (int64_t)(splitmix64(s) >> 2); break;  // uniform in [0, 2^62)
+        case 1: {                                          // just around a multiple of e
             const int64_t mult = (int64_t)(splitmix64(s) % (uint64_t)(2 * (int64_t)k + 3));
             const int64_t maxq = lim / e;
             const int64_t qq = mult < maxq ? mult : maxq;
             a = qq * e + (int64_t)(splitmix64(s) % 3) - 1;
             break;
         }
-        case 2: a = (int64_t)(splitmix64(s) % (uint64_t)(e)) ; break;          // below the divisor
-        default: a = -(int64_t)(splitmix64(s) >> 3); break;                     // negative availability
+        case 2: a = (int64_t)(splitmix64(s) % (uint64_t)(e)); break;  // below the divisor
+        default: a = -(int64_t)(splitmix64(s) >> 3); break;           // negative availability
         }
         if (a > lim) a = lim;
         const double rcp = 1.0 / (double)e;
         int32_t want;
-        if (a < 0) want = 0;
+        if (a < 0)
+            want = 0;
         else {
             const int64_t q = a / e;
             want = q < (int64_t)k ? (int32_t)q : k;
@@ -639,19 +950,61 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_fit_fifo_chain(gf_algo algo, const NodeTable& table, uint32_t n_apps, const gf_app* d_apps,
-                                 gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                 uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats,
-                                 hipStream_t stream) {
+size_t fifo_fixed_lds_bytes(int n_waves) {
+    const size_t ex = n_waves == 16 ? sizeof(Exchange<16>) : (n_waves == 4 ? sizeof(Exchange<4>) : sizeof(Exchange<1>));
+    return ex + sizeof(FifoShared) + 64;
+}
+
+namespace {
+template <int ALGO, int NW>
+hipError_t launch_fifo_t(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
+                         gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
+                         int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+    const size_t lds = 24 * (size_t)lds_slots + fifo_fixed_lds_bytes(NW);
+    auto kernel = fit_fifo_chain_kernel<ALGO, NW>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave * NW), lds, stream, table, lds_slots, n_apps, d_apps, d_results,
+                       d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at, d_stats);
+    return hipGetLastError();
+}
+template <int ALGO>
+hipError_t launch_fifo_a(int n_waves, const NodeTable& table, uint32_t lds_slots, uint32_t n_apps,
+                         const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                         uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+    switch (n_waves) {
+    case 1:
+        return launch_fifo_t<ALGO, 1>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
+                                      scratch_half, d_chain_failed_at, d_stats, stream);
+    case 4:
+        return launch_fifo_t<ALGO, 4>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
+                                      scratch_half, d_chain_failed_at, d_stats, stream);
+    default:
+        return launch_fifo_t<ALGO, 16>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
+                                       scratch_half, d_chain_failed_at, d_stats, stream);
+    }
+}
+}  // namespace
+
+hipError_t launch_fit_fifo_chain(gf_algo algo, int n_waves, const NodeTable& table, uint32_t lds_slots,
+                                 uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
+                                 uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
+                                 ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
+    hipError_t e;
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(fit_fifo_chain_kernel<GF_ALGO_TIGHTLY_PACK>, dim3(1), dim3(kWave), 0, stream, table,
-                           n_apps, d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at,
-                           d_stats);
+        e = launch_fifo_a<GF_ALGO_TIGHTLY_PACK>(n_waves, table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes,
+                                                d_scratch, scratch_half, d_chain_failed_at, d_stats, stream);
     else
-        hipLaunchKernelGGL(fit_fifo_chain_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, dim3(1), dim3(kWave), 0, stream, table,
-                           n_apps, d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at,
-                           d_stats);
+        e = launch_fifo_a<GF_ALGO_DISTRIBUTE_EVENLY>(n_waves, table, lds_slots, n_apps, d_apps, d_results,
+                                                     d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at, d_stats,
+                                                     stream);
+    if (e != hipSuccess) return e;
+    const dim3 block(kWave * kWavesPerBlock);
+    const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(translate_kernel, grid, block, 0, stream, table.slot_node, n_apps, d_apps, d_results,
+                       d_exec_nodes);
     return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 import numpy as np
@@ -63,6 +64,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64, and a process that
+    # loads /opt/rocm's copy first and torch's second ends up with two HSA runtimes (torch then sees no GPU).  When torch
+    # is installed, load it first so that libgangfit.so binds to the runtime torch already brought in.  A Go host has no
+    # torch and simply uses /opt/rocm's runtime.
+    if "torch" not in sys.modules and os.environ.get("GANGFIT_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py` (build()) first — there is no CPU fallback")

@@ -28,7 +28,7 @@ def make_apps(drv, exe, k, flags=None) -> np.ndarray:
 def with_offsets(apps: np.ndarray) -> Tuple[np.ndarray, int]:
     """Fill exec_off = exclusive prefix sum of k (what gf_fit_batch does internally); returns (apps, total_k)."""
     apps = apps.copy()
-    k = apps["k"].astype(np.uint64)
+    k = np.clip(apps["k"].astype(np.int64), 0, None).astype(np.uint64)  # negative k is rejected by the library
     off = np.zeros(len(apps), dtype=np.uint64)
     if len(apps) > 1:
         off[1:] = np.cumsum(k[:-1])
