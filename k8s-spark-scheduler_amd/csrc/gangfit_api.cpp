@@ -97,6 +97,7 @@ struct gf_ctx {
     PinnedBuf<uint32_t> h_index;
     bool work_valid = false;
     bool d_identity = false;
+    uint32_t x_skip = 0, d_skip = 0;  // dead prefixes of the two orders (see NodeTable)
     int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
@@ -144,6 +145,8 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     t.n_slots = ctx->n_slots;
     t.n_nodes = ctx->n_nodes;
     t.d_identity = ctx->d_identity ? 1u : 0u;
+    t.x_skip = ctx->x_skip;
+    t.d_skip = ctx->d_skip;
     return t;
 }
 
@@ -351,6 +354,15 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         identity = identity && dslot[i] == i;
     }
     ctx->d_identity = identity;
+    // Dead prefix: a slot with any negative component has capacity 0 for every app (cap_dim: a < 0 -> 0) and fails
+    // every driver-fit check (requests are >= 0); FIFO commits only ever subtract, so it stays dead for the whole
+    // chain.  The reference's priority order (least free memory first) puts overcommitted nodes right at the front.
+    auto dead = [&](uint32_t s) { return tcpu[s] < 0 || tmem[s] < 0 || tgpu[s] < 0; };
+    uint32_t xs = 0, dsk = 0;
+    while (xs < n_x && dead(xs)) ++xs;
+    while (dsk < n_d && dead(dslot[dsk])) ++dsk;
+    ctx->x_skip = xs;
+    ctx->d_skip = dsk;
 
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still read the old tables
     GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));

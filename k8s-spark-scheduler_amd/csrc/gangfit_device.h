@@ -25,6 +25,8 @@ struct NodeTable {
     uint32_t n_slots;
     uint32_t n_nodes;
     uint32_t d_identity;  // 1 when dslot[i] == i for all i (driver order is a prefix of the executor order)
+    uint32_t x_skip;      // leading executor-order slots with a negative component (dead for every app: cap == 0)
+    uint32_t d_skip;      // leading driver-order positions that sit on dead slots / unknown nodes
 };
 
 // Kernel-visible counters used by tests/bench to report visited bytes honestly (SURVEY.md section 8d

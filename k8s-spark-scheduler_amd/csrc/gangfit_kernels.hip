@@ -71,6 +71,13 @@ __device__ __forceinline__ int64_t read_lane(int64_t v, int src) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): with placement stores in
+// flight every barrier would stall for a global-memory round trip (measured: ~2 us per app in the FIFO chain).
+// Data exchanged through this barrier must live in LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------ app registers
 
 struct App {
@@ -215,6 +222,8 @@ struct Orders {
     const uint32_t* dslot;
     uint32_t n_x;
     uint32_t n_d;
+    uint32_t x_skip;  // leading executor-order slots with a negative component: capacity 0 for every app, forever
+    uint32_t d_skip;  // leading driver-order positions on such slots (or on unknown nodes): never pass the fit check
     bool d_identity;  // dslot[i] == i for every i (driver order == a prefix of the executor order): skip the gather
     __device__ __forceinline__ uint32_t driver_slot(uint32_t i) const { return d_identity ? i : dslot[i]; }
 };
@@ -251,7 +260,7 @@ __device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t w
 template <class View>
 __device__ __forceinline__ int64_t wave_first_fitting_driver(const View& V, const Orders& O, const App& app,
                                                              uint32_t from, int lane, unsigned long long& visited) {
-    for (uint32_t b = from; b < O.n_d; b += kWave) {
+    for (uint32_t b = from < O.d_skip ? O.d_skip : from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool fit = false;
         if (i < O.n_d) {
@@ -273,7 +282,7 @@ template <class View>
 __device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, const Orders& O, const App& app,
                                                              uint32_t from, int64_t S, int lane,
                                                              unsigned long long& visited) {
-    for (uint32_t b = from; b < O.n_d; b += kWave) {
+    for (uint32_t b = from < O.d_skip ? O.d_skip : from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool ok = false;
         if (i < O.n_d) {
@@ -305,7 +314,7 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
                                                    unsigned long long& visited) {
     const int64_t K = app.k;
     int64_t taken = 0;
-    for (uint32_t b = 0; b < O.n_x; b += kWave) {
+    for (uint32_t b = O.x_skip; b < O.n_x; b += kWave) {
         const uint32_t j = b + lane;
         int32_t c = 0;
         if (j < O.n_x) {
@@ -345,7 +354,7 @@ __device__ __forceinline__ int64_t wave_even_pass1(const View& V, const Orders& 
     const int64_t K = app.k;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     int64_t taken = 0;
-    for (uint32_t b = 0; b < O.n_x; b += kWave) {
+    for (uint32_t b = O.x_skip; b < O.n_x; b += kWave) {
         const uint32_t j = b + lane;
         bool flag = false;
         if (j < O.n_x) {
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     if (a >= n_apps) return;
     const App app = load_app(apps, a);
     GlobalView V{T.cpu, T.mem, T.gpu};
-    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, T.d_identity != 0};
     unsigned long long xvis = 0, dvis = 0;
     const Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off,
                                                               scratch + app.exec_off,
@@ -580,7 +589,7 @@ template <int NW>
 __device__ __forceinline__ int64_t block_min(Exchange<NW>* X, int& xb, int64_t wave_value, int wave, int lane) {
     if (NW == 1) return wave_value;
     if (lane == 0) X->first[xb][wave] = wave_value;
-    __syncthreads();
+    lds_barrier();
     int64_t m = X->first[xb][0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
@@ -600,7 +609,7 @@ __device__ __forceinline__ void block_scan(Exchange<NW>* X, int& xb, int32_t wav
         return;
     }
     if (lane == 0) X->tot[xb][wave] = wave_total;
-    __syncthreads();
+    lds_barrier();
     int64_t p = 0, t = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -653,8 +662,8 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         lgpu[s] = T.gpu[s];
     }
     HybridView V{lcpu, lmem, lgpu, lds_slots, T.cpu, T.mem, T.gpu};
-    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
-    const bool mask_commit = O.n_x <= 64u * BLOCK;  // per-thread 64-bit hit mask covers every chunk of a scan
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, T.d_identity != 0};
+    const bool mask_commit = (O.n_x - O.x_skip) <= 64u * BLOCK;  // a 64-bit per-thread hit mask covers a whole scan
 
     unsigned long long xvis = 0, dvis = 0;
     int xb = 0;
@@ -663,10 +672,10 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     for (; a < n_apps; ++a) {
         // ---- stage the next kAppStage app records (incl. reciprocals) into LDS
         if ((a % kAppStage) == 0) {
-            __syncthreads();  // previous stage fully consumed; also publishes the table fill / last commit
+            lds_barrier();  // previous stage fully consumed; also publishes the table fill
             const uint32_t n_stage = (n_apps - a) < (uint32_t)kAppStage ? (n_apps - a) : (uint32_t)kAppStage;
             if (tid < n_stage) sh->apps[tid] = load_app(apps, a + tid);
-            __syncthreads();
+            lds_barrier();
         }
         const App app = sh->apps[a % kAppStage];
         const int64_t K = app.k;
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 
         // ---- (1) first fitting driver candidate, BLOCK candidates per step
         int64_t p0 = -1;
-        for (uint32_t b = 0; b < O.n_d; b += BLOCK) {
+        for (uint32_t b = O.d_skip; b < O.n_d; b += BLOCK) {
             const uint32_t i = b + tid;
             bool fit = false;
             if (i < O.n_d) {
@@ -699,6 +708,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         dec.pass1 = 0;
         enum { kCommitDone, kCommitMask, kCommitList } commit = kCommitDone;
         uint64_t hit = 0;  // bit `it`: this thread's slot in chunk `it` hosts >= 1 executor of this app
+        uint32_t scan_end = 0;  // one past the last executor-order slot the fast path looked at
         if (p0 >= 0) {
             const uint32_t ds = O.driver_slot((uint32_t)p0);
             dec.ds = ds;
@@ -709,8 +719,10 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                 // ---- (2) executors, BLOCK slots per step, lazy stop
                 int64_t taken = 0;
                 uint32_t it = 0;
-                for (uint32_t b = 0; b < O.n_x; b += BLOCK, ++it) {
+                uint32_t scanned_end = O.x_skip;
+                for (uint32_t b = O.x_skip; b < O.n_x; b += BLOCK, ++it) {
                     const uint32_t j = b + tid;
+                    scanned_end = b + BLOCK;
                     int64_t a0 = -1, a1 = -1, a2 = -1;
                     if (j < O.n_x) {
                         V.load(j, a0, a1, a2);
@@ -750,6 +762,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                     }
                     if (taken >= K) break;
                 }
+                scan_end = scanned_end;
                 if (taken >= K) {
                     dec.feasible = true;
                     dec.pass1 = taken;
@@ -815,18 +828,23 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
             while (h) {
                 const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
                 h &= h - 1;
-                const uint32_t s = it * BLOCK + tid;
+                const uint32_t s = O.x_skip + it * BLOCK + tid;
                 V.sub(s, app.exe0, app.exe1, app.exe2);
                 if (s == dec.ds) hosts = true;
             }
             // the thread that would scan slot ds knows whether an executor landed there (a slot beyond the cut or a
             // driver-only slot >= n_x was never hit)
-            if (tid == dec.ds % BLOCK && !hosts) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+            const uint32_t owner = (dec.ds >= O.x_skip && dec.ds < O.n_x) ? (dec.ds - O.x_skip) % BLOCK : 0u;
+            if (tid == owner && !hosts) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
         } else if (commit == kCommitList) {
             __syncthreads();  // every wave's placements are written
             if (wave == 0) wave_commit_from_list<ALGO, HybridView>(V, app, dec, out, lane);
         }
-        __syncthreads();  // residuals visible to every wave before the next app scans
+        // residuals visible to every wave before the next app scans: LDS-only unless the global tail was touched
+        if (commit == kCommitMask && scan_end <= lds_slots && dec.ds < lds_slots)
+            lds_barrier();
+        else
+            __syncthreads();
     }
     // apps behind an abort are reported as not evaluated
     for (uint32_t r = a + tid; r < n_apps; r += BLOCK) {

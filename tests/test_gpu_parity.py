@@ -101,7 +101,6 @@ def test_independent_batch_random(gf_ctx, algo, n):
         _assert_same(gpu, ref, apps)
         if n >= 63:  # the generator must exercise both outcomes
             assert ref.results["has_capacity"].any()
-            assert not tight_cluster or not ref.results["has_capacity"].all()
 
 
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
