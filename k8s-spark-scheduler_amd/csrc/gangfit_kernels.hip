@@ -184,14 +184,18 @@ struct GlobalView {
 
 // FIFO chain: the first `lds_slots` slots of the (mutable) working table live in LDS — the front of the executor
 // priority order is what every app of the chain scans — the tail stays in global memory.
+// The pointers carry explicit address spaces: with generic pointers the compiler folds the two arms into ONE flat_load
+// of a selected address, and every flat access waits on vmcnt(0) — i.e. on all placement stores still in flight.
+typedef __attribute__((address_space(3))) int64_t lds_i64;
+typedef __attribute__((address_space(1))) int64_t glb_i64;
 struct HybridView {
-    int64_t* lcpu;  // LDS, SoA: consecutive lanes read consecutive 8-byte words (ds_read_b64, conflict-free)
-    int64_t* lmem;
-    int64_t* lgpu;
+    lds_i64* lcpu;  // LDS, SoA: consecutive lanes read consecutive 8-byte words (ds_read_b64, conflict-free)
+    lds_i64* lmem;
+    lds_i64* lgpu;
     uint32_t lds_slots;
-    int64_t* cpu;  // global
-    int64_t* mem;
-    int64_t* gpu;
+    glb_i64* cpu;  // global
+    glb_i64* mem;
+    glb_i64* gpu;
     __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
         if (s < lds_slots) {
             a0 = lcpu[s];
@@ -202,6 +206,18 @@ struct HybridView {
             a1 = mem[s];
             a2 = gpu[s];
         }
+    }
+    // LDS-only accessors for wave-uniformly LDS-resident ranges: no vmcnt wait is generated, so the chain never
+    // stalls on placement stores that are still in flight (stores count in vmcnt on gfx9-family ISAs).
+    __device__ __forceinline__ void load_lds(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
+        a0 = lcpu[s];
+        a1 = lmem[s];
+        a2 = lgpu[s];
+    }
+    __device__ __forceinline__ void sub_lds(uint32_t s, int64_t r0, int64_t r1, int64_t r2) const {
+        lcpu[s] -= r0;
+        lmem[s] -= r1;
+        lgpu[s] -= r2;
     }
     __device__ __forceinline__ void sub(uint32_t s, int64_t r0, int64_t r1, int64_t r2) const {
         if (s < lds_slots) {
@@ -631,11 +647,92 @@ struct FifoShared {
     int64_t slow_pass1;
 };
 
+// State of one executor scan of the FIFO fast path (all fields workgroup-uniform except `hit`).
+struct FifoScan {
+    int64_t taken;  // placements so far (tightly-pack: sum of clamped capacities)
+    uint32_t it;    // chunk index since x_skip
+    uint32_t end;   // one past the last slot looked at
+    uint64_t hit;   // per thread: bit `it` set when this thread's slot in chunk `it` hosts >= 1 executor
+};
+
+// One step of the executor scan: BLOCK consecutive slots starting at b.  LDS_ONLY is a compile-time promise that every
+// valid slot of the step lives in LDS: that instantiation contains no global LOAD, hence no vmcnt wait — placement
+// stores still in flight (which count in vmcnt on gfx9-family ISAs) never stall the chain.
+template <int ALGO, int NW, bool LDS_ONLY>
+__device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders& O, const App& app, uint32_t ds,
+                                               uint32_t b, uint32_t tid, int wave, int lane, Exchange<NW>* X, int& xb,
+                                               uint32_t* __restrict__ out, uint32_t* __restrict__ surv, FifoScan& st) {
+    constexpr uint32_t BLOCK = kWave * NW;
+    const int64_t K = app.k;
+    const uint32_t j = b + tid;
+    int64_t a0 = -1, a1 = -1, a2 = -1;
+    if (j < O.n_x) {
+        if (LDS_ONLY)
+            V.load_lds(j, a0, a1, a2);
+        else
+            V.load(j, a0, a1, a2);
+        if (j == ds) {
+            a0 -= app.drv0;
+            a1 -= app.drv1;
+            a2 -= app.drv2;
+        }
+    }
+    st.end = b + BLOCK;
+    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
+        const int32_t c = (j < O.n_x) ? cap3(a0, a1, a2, app) : 0;
+        const int32_t incl = wave_inclusive_scan(c);
+        int64_t prefix, total;
+        block_scan<NW>(X, xb, read_lane(incl, kWave - 1), wave, lane, prefix, total);
+        if (total > 0) {
+            const int64_t start = st.taken + prefix + (int64_t)(incl - c);
+            const int64_t room = K - start;
+            const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
+            if (t > 0 && st.it < 64) st.hit |= 1ull << st.it;
+            emit_runs(out, start, t, j, lane);
+        }
+        st.taken += total;
+    } else {
+        const bool flag = (j < O.n_x) && cap_ge1(a0, a1, a2, app);
+        const uint64_t m = __ballot(flag);
+        int64_t prefix, total;
+        block_scan<NW>(X, xb, (int32_t)__popcll((unsigned long long)m), wave, lane, prefix, total);
+        const int64_t pos = st.taken + prefix + (int64_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+        if (flag && pos < K) {
+            out[pos] = j;
+            surv[pos] = j;  // survivor list for the (rare) multi-pass path
+            if (st.it < 64) st.hit |= 1ull << st.it;
+        }
+        st.taken += total;
+    }
+    ++st.it;
+}
+
+// One step of the driver-candidate scan: returns the first fitting position of this step or INT64_MAX.
+template <int NW, bool LDS_ONLY>
+__device__ __forceinline__ int64_t fifo_driver_step(const HybridView& V, const Orders& O, const App& app, uint32_t b,
+                                                    uint32_t tid, int wave, int lane, Exchange<NW>* X, int& xb) {
+    const uint32_t i = b + tid;
+    bool fit = false;
+    if (i < O.n_d) {
+        int64_t a0, a1, a2;
+        if (LDS_ONLY)
+            V.load_lds(i, a0, a1, a2);  // identity mapping: position == slot
+        else
+            V.load(O.driver_slot(i), a0, a1, a2);
+        fit = driver_fits(a0, a1, a2, app);
+    }
+    const uint64_t m = __ballot(fit);
+    const int64_t wfirst = m ? (int64_t)b + wave * kWave + (__ffsll((unsigned long long)m) - 1) : INT64_MAX;
+    return block_min<NW>(X, xb, wfirst, wave, lane);
+}
+
 // FIFO replay (internal/extender/resource.go:224-262 + :321): apps strictly in order, each against the residuals its
 // predecessors left.  ONE workgroup of NW waves: nodes in parallel (NW*64 per step), apps sequential.  The working
 // table's front lives in LDS, so the per-app critical path is LDS latency + a few workgroup barriers instead of
 // global-memory round trips.  Placements are written as SLOT ids (translated by translate_kernel afterwards).
-template <int ALGO, int NW>
+// DIDENT: the driver order is a prefix of the executor order (position == slot), the production shape; that
+// instantiation has no driver-slot gather, i.e. no global load anywhere on the per-app fast path.
+template <int ALGO, int NW, bool DIDENT>
 __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, uint32_t lds_slots, uint32_t n_apps,
                                                                   const gf_app* __restrict__ apps,
                                                                   gf_result* __restrict__ results,
@@ -651,19 +748,22 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     const int wave = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- LDS carve: table front | exchange | shared scalars + staged apps
-    int64_t* lcpu = reinterpret_cast<int64_t*>(smem);
-    int64_t* lmem = lcpu + lds_slots;
-    int64_t* lgpu = lmem + lds_slots;
-    Exchange<NW>* X = reinterpret_cast<Exchange<NW>*>(lgpu + lds_slots);
+    lds_i64* lcpu = (lds_i64*)smem;
+    lds_i64* lmem = lcpu + lds_slots;
+    lds_i64* lgpu = lmem + lds_slots;
+    Exchange<NW>* X = reinterpret_cast<Exchange<NW>*>(smem + 24 * (size_t)lds_slots);
     FifoShared* sh = reinterpret_cast<FifoShared*>(X + 1);
     for (uint32_t s = tid; s < lds_slots; s += BLOCK) {
         lcpu[s] = T.cpu[s];
         lmem[s] = T.mem[s];
         lgpu[s] = T.gpu[s];
     }
-    HybridView V{lcpu, lmem, lgpu, lds_slots, T.cpu, T.mem, T.gpu};
-    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, T.d_identity != 0};
+    HybridView V{lcpu, lmem, lgpu, lds_slots, (glb_i64*)T.cpu, (glb_i64*)T.mem, (glb_i64*)T.gpu};
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, DIDENT};
     const bool mask_commit = (O.n_x - O.x_skip) <= 64u * BLOCK;  // a 64-bit per-thread hit mask covers a whole scan
+    // a step starting at b is LDS-only when b + BLOCK <= *_lds_limit (whole order resident -> no limit)
+    const uint32_t x_lds_limit = O.n_x <= lds_slots ? 0xFFFFFFFFu - BLOCK : lds_slots;
+    const uint32_t d_lds_limit = !DIDENT ? 0u : (O.n_d <= lds_slots ? 0xFFFFFFFFu - BLOCK : lds_slots);
 
     unsigned long long xvis = 0, dvis = 0;
     int xb = 0;
@@ -680,26 +780,27 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         const App app = sh->apps[a % kAppStage];
         const int64_t K = app.k;
         uint32_t* out = exec_nodes + app.exec_off;
+        uint32_t* surv = scratch + app.exec_off;
         const bool last = (a + 1 == n_apps);
 
         // ---- (1) first fitting driver candidate, BLOCK candidates per step
         int64_t p0 = -1;
-        for (uint32_t b = O.d_skip; b < O.n_d; b += BLOCK) {
-            const uint32_t i = b + tid;
-            bool fit = false;
-            if (i < O.n_d) {
-                int64_t a0, a1, a2;
-                V.load(O.driver_slot(i), a0, a1, a2);
-                fit = driver_fits(a0, a1, a2, app);
+        {
+            uint32_t b = O.d_skip;
+            int64_t f = INT64_MAX;
+            for (; b < O.n_d && b + BLOCK <= d_lds_limit; b += BLOCK) {
+                f = fifo_driver_step<NW, true>(V, O, app, b, tid, wave, lane, X, xb);
+                dvis += chunk_len(O.n_d, b, BLOCK);
+                if (f != INT64_MAX) break;
             }
-            dvis += chunk_len(O.n_d, b, BLOCK);
-            const uint64_t m = __ballot(fit);
-            const int64_t wfirst = m ? (int64_t)b + wave * kWave + (__ffsll((unsigned long long)m) - 1) : INT64_MAX;
-            const int64_t f = block_min<NW>(X, xb, wfirst, wave, lane);
-            if (f != INT64_MAX) {
-                p0 = f;
-                break;
+            if (f == INT64_MAX) {
+                for (; b < O.n_d; b += BLOCK) {
+                    f = fifo_driver_step<NW, false>(V, O, app, b, tid, wave, lane, X, xb);
+                    dvis += chunk_len(O.n_d, b, BLOCK);
+                    if (f != INT64_MAX) break;
+                }
             }
+            if (f != INT64_MAX) p0 = f;
         }
 
         Decision dec;
@@ -707,85 +808,50 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         dec.ds = 0;
         dec.pass1 = 0;
         enum { kCommitDone, kCommitMask, kCommitList } commit = kCommitDone;
-        uint64_t hit = 0;  // bit `it`: this thread's slot in chunk `it` hosts >= 1 executor of this app
-        uint32_t scan_end = 0;  // one past the last executor-order slot the fast path looked at
+        FifoScan st;
+        st.taken = 0;
+        st.it = 0;
+        st.end = 0;
+        st.hit = 0;
         if (p0 >= 0) {
-            const uint32_t ds = O.driver_slot((uint32_t)p0);
+            const uint32_t ds = DIDENT ? (uint32_t)p0 : O.driver_slot((uint32_t)p0);
             dec.ds = ds;
             if (K == 0) {
                 dec.feasible = true;
                 commit = kCommitMask;  // nothing placed: only the driver request is subtracted
             } else {
-                // ---- (2) executors, BLOCK slots per step, lazy stop
-                int64_t taken = 0;
-                uint32_t it = 0;
-                uint32_t scanned_end = O.x_skip;
-                for (uint32_t b = O.x_skip; b < O.n_x; b += BLOCK, ++it) {
-                    const uint32_t j = b + tid;
-                    scanned_end = b + BLOCK;
-                    int64_t a0 = -1, a1 = -1, a2 = -1;
-                    if (j < O.n_x) {
-                        V.load(j, a0, a1, a2);
-                        if (j == ds) {
-                            a0 -= app.drv0;
-                            a1 -= app.drv1;
-                            a2 -= app.drv2;
-                        }
-                    }
+                // ---- (2) executors, BLOCK slots per step, lazy stop; LDS-resident steps first
+                uint32_t b = O.x_skip;
+                for (; b < O.n_x && b + BLOCK <= x_lds_limit && st.taken < K; b += BLOCK) {
+                    fifo_scan_step<ALGO, NW, true>(V, O, app, ds, b, tid, wave, lane, X, xb, out, surv, st);
                     xvis += chunk_len(O.n_x, b, BLOCK);
-                    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
-                        const int32_t c = (j < O.n_x) ? cap3(a0, a1, a2, app) : 0;
-                        const int32_t incl = wave_inclusive_scan(c);
-                        int64_t prefix, total;
-                        block_scan<NW>(X, xb, read_lane(incl, kWave - 1), wave, lane, prefix, total);
-                        if (total > 0) {
-                            const int64_t start = taken + prefix + (int64_t)(incl - c);
-                            const int64_t room = K - start;
-                            const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
-                            if (t > 0 && it < 64) hit |= 1ull << it;
-                            emit_runs(out, start, t, j, lane);
-                        }
-                        taken += total;
-                    } else {
-                        const bool flag = (j < O.n_x) && cap_ge1(a0, a1, a2, app);
-                        const uint64_t m = __ballot(flag);
-                        int64_t prefix, total;
-                        block_scan<NW>(X, xb, (int32_t)__popcll((unsigned long long)m), wave, lane, prefix, total);
-                        const int64_t pos = taken + prefix +
-                                            (int64_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-                        if (flag && pos < K) {
-                            out[pos] = j;
-                            scratch[app.exec_off + pos] = j;  // survivor list for the (rare) multi-pass path
-                            if (it < 64) hit |= 1ull << it;
-                        }
-                        taken += total;
-                    }
-                    if (taken >= K) break;
                 }
-                scan_end = scanned_end;
-                if (taken >= K) {
+                for (; b < O.n_x && st.taken < K; b += BLOCK) {
+                    fifo_scan_step<ALGO, NW, false>(V, O, app, ds, b, tid, wave, lane, X, xb, out, surv, st);
+                    xvis += chunk_len(O.n_x, b, BLOCK);
+                }
+                if (st.taken >= K) {
                     dec.feasible = true;
-                    dec.pass1 = taken;
+                    dec.pass1 = st.taken;
                     commit = mask_commit ? kCommitMask : kCommitList;
                 } else {
                     // ---- (3) slow path, wave 0 alone: multi-pass distribute-evenly and/or driver fallback.
-                    // `taken` is the exact capacity total S_d for tightly-pack, the pass-1 survivor count for evenly.
-                    __syncthreads();  // out[] / scratch[] writes of all waves are complete
+                    // st.taken is the exact capacity total S_d for tightly-pack, the pass-1 survivor count for evenly.
+                    __syncthreads();  // out[] / surv[] writes of all waves are complete
                     if (wave == 0) {
-                        uint32_t* sa = scratch + app.exec_off;
                         uint32_t* sb = scratch + scratch_half + app.exec_off;
                         Decision d2;
                         d2.feasible = false;
                         d2.ds = ds;
-                        d2.pass1 = taken;
-                        int64_t S_d = taken;
+                        d2.pass1 = st.taken;
+                        int64_t S_d = st.taken;
                         if (ALGO != GF_ALGO_TIGHTLY_PACK)
-                            S_d = wave_even_general<HybridView, true>(V, O, app, ds, out, sa, sb, taken, lane);
+                            S_d = wave_even_general<HybridView, true>(V, O, app, ds, out, surv, sb, st.taken, lane);
                         if (S_d >= K)
                             d2.feasible = true;
                         else
-                            d2 = wave_fallback<ALGO, HybridView, true>(V, O, app, p0, ds, S_d, out, sa, sb, lane, xvis,
-                                                                      dvis);
+                            d2 = wave_fallback<ALGO, HybridView, true>(V, O, app, p0, ds, S_d, out, surv, sb, lane,
+                                                                      xvis, dvis);
                         if (d2.feasible && !last) wave_commit_from_list<ALGO, HybridView>(V, app, d2, out, lane);
                         if (lane == 0) {
                             sh->slow_feasible = d2.feasible ? 1 : 0;
@@ -822,26 +888,39 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         }
         // ---- (4) commit the usage of this earlier driver (sparkpods.go:139-146: one executor request per DISTINCT
         //          executor node; the driver request only if no executor landed on the driver's node)
+        const bool lds_only = commit == kCommitMask && (st.end <= lds_slots || O.n_x <= lds_slots) &&
+                              dec.ds < lds_slots;  // uniform: the commit touches LDS only
         if (commit == kCommitMask) {
             bool hosts = false;
-            uint64_t h = hit;
-            while (h) {
-                const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
-                h &= h - 1;
-                const uint32_t s = O.x_skip + it * BLOCK + tid;
-                V.sub(s, app.exe0, app.exe1, app.exe2);
-                if (s == dec.ds) hosts = true;
-            }
+            uint64_t h = st.hit;
             // the thread that would scan slot ds knows whether an executor landed there (a slot beyond the cut or a
             // driver-only slot >= n_x was never hit)
             const uint32_t owner = (dec.ds >= O.x_skip && dec.ds < O.n_x) ? (dec.ds - O.x_skip) % BLOCK : 0u;
-            if (tid == owner && !hosts) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+            if (lds_only) {
+                while (h) {
+                    const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
+                    h &= h - 1;
+                    const uint32_t s = O.x_skip + it * BLOCK + tid;
+                    V.sub_lds(s, app.exe0, app.exe1, app.exe2);
+                    if (s == dec.ds) hosts = true;
+                }
+                if (tid == owner && !hosts) V.sub_lds(dec.ds, app.drv0, app.drv1, app.drv2);
+            } else {
+                while (h) {
+                    const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
+                    h &= h - 1;
+                    const uint32_t s = O.x_skip + it * BLOCK + tid;
+                    V.sub(s, app.exe0, app.exe1, app.exe2);
+                    if (s == dec.ds) hosts = true;
+                }
+                if (tid == owner && !hosts) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+            }
         } else if (commit == kCommitList) {
             __syncthreads();  // every wave's placements are written
             if (wave == 0) wave_commit_from_list<ALGO, HybridView>(V, app, dec, out, lane);
         }
         // residuals visible to every wave before the next app scans: LDS-only unless the global tail was touched
-        if (commit == kCommitMask && scan_end <= lds_slots && dec.ds < lds_slots)
+        if (lds_only)
             lds_barrier();
         else
             __syncthreads();
@@ -974,18 +1053,28 @@ size_t fifo_fixed_lds_bytes(int n_waves) {
 }
 
 namespace {
-template <int ALGO, int NW>
-hipError_t launch_fifo_t(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
+template <int ALGO, int NW, bool DIDENT>
+hipError_t launch_fifo_d(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
                          gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
                          int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
     const size_t lds = 24 * (size_t)lds_slots + fifo_fixed_lds_bytes(NW);
-    auto kernel = fit_fifo_chain_kernel<ALGO, NW>;
+    auto kernel = fit_fifo_chain_kernel<ALGO, NW, DIDENT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave * NW), lds, stream, table, lds_slots, n_apps, d_apps, d_results,
                        d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at, d_stats);
     return hipGetLastError();
+}
+template <int ALGO, int NW>
+hipError_t launch_fifo_t(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
+                         gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
+                         int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+    if (table.d_identity)
+        return launch_fifo_d<ALGO, NW, true>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
+                                             scratch_half, d_chain_failed_at, d_stats, stream);
+    return launch_fifo_d<ALGO, NW, false>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
+                                          scratch_half, d_chain_failed_at, d_stats, stream);
 }
 template <int ALGO>
 hipError_t launch_fifo_a(int n_waves, const NodeTable& table, uint32_t lds_slots, uint32_t n_apps,
