@@ -150,8 +150,10 @@ int gf_timer_end(gf_ctx *ctx, float *elapsed_ms);
 /* Visited-slot counters, for honest "visited bytes" reporting next to the algorithmic bytes (the scans are lazy, like
  * the reference's loops: they stop once K executors are placed).  enable != 0 makes subsequent launches count
  * (one atomic pair per app); out[0] = executor-order slots whose capacity was evaluated, out[1] = driver-order
- * positions whose fit was evaluated, accumulated since the last reset.  out may be NULL. */
-int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[2]);
+ * positions whose fit was evaluated, accumulated since the last reset; out[2] / out[3] = shader-clock cycles and
+ * 100 MHz real-time ticks spent inside the last FIFO-chain kernel (their ratio is the effective shader clock).
+ * out may be NULL. */
+int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[4]);
 
 /* On-device self-test of the wave primitives (DPP prefix scan, exact clamped 64-bit division) against plain
  * reference code on n_cases adversarial inputs per lane.  *mismatches == 0 means pass. */

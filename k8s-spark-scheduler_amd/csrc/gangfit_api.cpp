@@ -92,6 +92,9 @@ struct gf_ctx {
     DeviceBuf<int64_t> d_snap;   // 3 * n_slots: cpu | mem | gpu of the snapshot
     DeviceBuf<int64_t> d_work;   // working copy mutated by FIFO chains
     DeviceBuf<uint32_t> d_slot_node, d_dslot, d_node_slot;
+    DeviceBuf<int64_t> d_cmax;   // chunk-maxima index, 3 * n_chunks
+    PinnedBuf<int64_t> h_cmax;
+    uint32_t n_chunks = 0;
     std::vector<uint32_t> h_node_slot;  // kept for gf_residual_get
     PinnedBuf<int64_t> h_table;
     PinnedBuf<uint32_t> h_index;
@@ -140,6 +143,8 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     t.slot_node = ctx->d_slot_node.ptr;
     t.dslot = ctx->d_dslot.ptr;
     t.node_slot = ctx->d_node_slot.ptr;
+    t.cmax = ctx->d_cmax.ptr;
+    t.n_chunks = ctx->n_chunks;
     t.n_x = ctx->n_x;
     t.n_d = ctx->n_d;
     t.n_slots = ctx->n_slots;
@@ -167,7 +172,7 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
         // as much of the table front as fits next to the kernel's fixed LDS needs stays in LDS for the whole chain
-        const size_t fixed = gangfit::fifo_fixed_lds_bytes(ctx->fifo_waves);
+        const size_t fixed = gangfit::fifo_fixed_lds_bytes(ctx->fifo_waves) + 24 * (size_t)ctx->n_chunks;
         uint32_t lds_slots = ctx->lds_budget > fixed ? (uint32_t)((ctx->lds_budget - fixed) / 24) : 0;
         lds_slots &= ~63u;
         if (lds_slots > ctx->n_slots) lds_slots = ctx->n_slots;
@@ -243,6 +248,8 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_slot_node.release();
     ctx->d_dslot.release();
     ctx->d_node_slot.release();
+    ctx->d_cmax.release();
+    ctx->h_cmax.release();
     ctx->d_apps.release();
     ctx->d_results.release();
     ctx->d_exec.release();
@@ -364,7 +371,24 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     ctx->x_skip = xs;
     ctx->d_skip = dsk;
 
+    // chunk-maxima index over all slots (see NodeTable::cmax)
+    const uint32_t n_chunks = (n_slots + 63) / 64;
+    GF_HIP(ctx, ctx->h_cmax.reserve(3 * (size_t)n_chunks));
+    {
+        const int64_t* cols[3] = {tcpu, tmem, tgpu};
+        for (int j = 0; j < 3; ++j)
+            for (uint32_t c = 0; c < n_chunks; ++c) {
+                int64_t m = INT64_MIN;
+                const uint32_t hi = (c + 1) * 64 < n_slots ? (c + 1) * 64 : n_slots;
+                for (uint32_t s2 = c * 64; s2 < hi; ++s2) m = cols[j][s2] > m ? cols[j][s2] : m;
+                ctx->h_cmax.ptr[(size_t)j * n_chunks + c] = m;
+            }
+    }
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still read the old tables
+    GF_HIP(ctx, ctx->d_cmax.reserve(3 * (size_t)n_chunks));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_cmax.ptr, ctx->h_cmax.ptr, 3 * (size_t)n_chunks * sizeof(int64_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_chunks = n_chunks;
     GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));
     GF_HIP(ctx, ctx->d_work.reserve(3 * (size_t)n_slots));
     GF_HIP(ctx, ctx->d_slot_node.reserve(n_slots));
@@ -483,7 +507,7 @@ int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
     return GF_OK;
 }
 
-int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[2]) {
+int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[4]) {
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -493,6 +517,8 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[2]) {
         GF_HIP(ctx, hipMemcpy(&s, ctx->d_stats.ptr, sizeof s, hipMemcpyDeviceToHost));
         out[0] = s.exec_slots_visited;
         out[1] = s.driver_slots_visited;
+        out[2] = s.fifo_shader_cycles;
+        out[3] = s.fifo_realtime_ticks;
     }
     if (reset) GF_HIP(ctx, hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)));
     ctx->stats_on = enable != 0;

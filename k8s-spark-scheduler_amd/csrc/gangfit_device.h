@@ -20,6 +20,12 @@ struct NodeTable {
     const uint32_t* slot_node;  // [n_slots] slot -> caller's node index (what is written to exec_nodes)
     const uint32_t* dslot;      // [n_d]     position in driverNodePriorityOrder -> slot
     const uint32_t* node_slot;  // [n_nodes] caller's node index -> slot
+    // Chunk-maxima index: cmax[d * n_chunks + c] = max over slots [64c, 64c+64) of dimension d, taken on the SNAPSHOT.
+    // Upper bounds stay valid while a FIFO chain subtracts, so "cmax < request in some dimension" proves that no slot
+    // of the chunk can host the request: the scans skip such chunks without loading them.  The reference's priority
+    // order (least free memory first) makes this skip the whole front of the order for large executors.
+    const int64_t* cmax;        // [3][n_chunks]
+    uint32_t n_chunks;          // ceil(n_slots / 64)
     uint32_t n_x;
     uint32_t n_d;
     uint32_t n_slots;
@@ -34,6 +40,8 @@ struct NodeTable {
 struct ScanStats {
     unsigned long long exec_slots_visited;    // executor-order slots whose capacity was evaluated
     unsigned long long driver_slots_visited;  // driver-order positions whose fit was evaluated
+    unsigned long long fifo_shader_cycles;    // s_memtime delta over the last FIFO chain kernel (shader clock)
+    unsigned long long fifo_realtime_ticks;   // s_memrealtime delta over the same span (constant 100 MHz)
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).

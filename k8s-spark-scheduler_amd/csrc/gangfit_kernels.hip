@@ -170,6 +170,14 @@ struct GlobalView {
     int64_t* cpu;
     int64_t* mem;
     int64_t* gpu;
+    const int64_t* cmax_cpu;  // per-64-slot-chunk maxima of each dimension (upper bounds; see NodeTable::cmax)
+    const int64_t* cmax_mem;
+    const int64_t* cmax_gpu;
+    uint32_t n_chunks;
+    // can ANY slot of chunk c offer r in every dimension?  false => capacity 0 / driver does not fit, for the whole chunk
+    __device__ __forceinline__ bool chunk_may_hold(uint32_t c, int64_t r0, int64_t r1, int64_t r2) const {
+        return cmax_cpu[c] >= r0 && cmax_mem[c] >= r1 && cmax_gpu[c] >= r2;
+    }
     __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
         a0 = cpu[s];
         a1 = mem[s];
@@ -196,6 +204,13 @@ struct HybridView {
     glb_i64* cpu;  // global
     glb_i64* mem;
     glb_i64* gpu;
+    lds_i64* cmax_cpu;  // chunk maxima, LDS copy (static upper bounds: the chain only ever subtracts)
+    lds_i64* cmax_mem;
+    lds_i64* cmax_gpu;
+    uint32_t n_chunks;
+    __device__ __forceinline__ bool chunk_may_hold(uint32_t c, int64_t r0, int64_t r1, int64_t r2) const {
+        return cmax_cpu[c] >= r0 && cmax_mem[c] >= r1 && cmax_gpu[c] >= r2;
+    }
     __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
         if (s < lds_slots) {
             a0 = lcpu[s];
@@ -272,11 +287,45 @@ __device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t w
 // One wavefront evaluates one application.  SLOTS selects what is written to out[]: slot ids (FIFO kernel; translated
 // by a follow-up kernel) or the caller's node indices (independent kernel).
 
+// 64-bit mask over chunks [64g, 64g+64): bit set when the chunk may hold request r (every dimension's maximum >= r).
+// A cleared bit is a proof that every slot of the chunk has capacity 0 for an executor of size r (cap_dim: a < e -> 0;
+// reserving the driver only lowers a) resp. fails the driver-fit check for a driver of size r.
+template <class View>
+__device__ __forceinline__ uint64_t chunk_group_mask(const View& V, uint32_t g, uint32_t chunk_limit, int64_t r0,
+                                                     int64_t r1, int64_t r2, int lane) {
+    const uint32_t c = g * kWave + lane;
+    bool ok = false;
+    if (c < chunk_limit) ok = V.chunk_may_hold(c, r0, r1, r2);
+    return __ballot(ok);
+}
+
 // First position p in [from, n_d) of driverNodePriorityOrder whose node passes the driver-fit check, else -1.
 template <class View>
 __device__ __forceinline__ int64_t wave_first_fitting_driver(const View& V, const Orders& O, const App& app,
                                                              uint32_t from, int lane, unsigned long long& visited) {
-    for (uint32_t b = from < O.d_skip ? O.d_skip : from; b < O.n_d; b += kWave) {
+    if (O.d_identity) {  // position == slot: prune whole chunks with the maxima index
+        const uint32_t dc = (O.n_d + kWave - 1) / kWave;
+        for (uint32_t g = (from / kWave) / kWave; g * kWave < dc; ++g) {
+            uint64_t m = chunk_group_mask(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
+            visited += kWave;
+            while (m) {
+                const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                m &= m - 1;
+                const uint32_t i = c * kWave + lane;
+                bool fit = false;
+                if (i < O.n_d && i >= from) {
+                    int64_t a0, a1, a2;
+                    V.load(i, a0, a1, a2);
+                    fit = driver_fits(a0, a1, a2, app);
+                }
+                visited += chunk_len(O.n_d, c * kWave, kWave);
+                const uint64_t fm = __ballot(fit);
+                if (fm) return (int64_t)c * kWave + (__ffsll((unsigned long long)fm) - 1);
+            }
+        }
+        return -1;
+    }
+    for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool fit = false;
         if (i < O.n_d) {
@@ -298,7 +347,7 @@ template <class View>
 __device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, const Orders& O, const App& app,
                                                              uint32_t from, int64_t S, int lane,
                                                              unsigned long long& visited) {
-    for (uint32_t b = from < O.d_skip ? O.d_skip : from; b < O.n_d; b += kWave) {
+    for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool ok = false;
         if (i < O.n_d) {
@@ -324,38 +373,46 @@ __device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, cons
 
 // tightlyPackExecutors with the driver reserved on slot ds.  Returns the sum of clamped capacities over the visited
 // prefix (>= K  <=>  feasible; the scan stops at the first chunk where K is reached).  Writes placements.
+// Only chunks the maxima index cannot rule out are loaded; a ruled-out chunk contributes exactly 0.
 template <class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& O, const App& app, uint32_t ds,
                                                    uint32_t* __restrict__ out, int lane,
                                                    unsigned long long& visited) {
     const int64_t K = app.k;
+    const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
-    for (uint32_t b = O.x_skip; b < O.n_x; b += kWave) {
-        const uint32_t j = b + lane;
-        int32_t c = 0;
-        if (j < O.n_x) {
-            int64_t a0, a1, a2;
-            V.load(j, a0, a1, a2);
-            if (j == ds) {
-                a0 -= app.drv0;
-                a1 -= app.drv1;
-                a2 -= app.drv2;
+    for (uint32_t g = 0; g * kWave < xc; ++g) {
+        uint64_t m = chunk_group_mask(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+        visited += kWave;
+        while (m) {
+            const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+            m &= m - 1;
+            const uint32_t j = c * kWave + lane;
+            int32_t cp = 0;
+            if (j < O.n_x) {
+                int64_t a0, a1, a2;
+                V.load(j, a0, a1, a2);
+                if (j == ds) {
+                    a0 -= app.drv0;
+                    a1 -= app.drv1;
+                    a2 -= app.drv2;
+                }
+                if (cap_ge1(a0, a1, a2, app)) cp = cap3(a0, a1, a2, app);  // no division for slots that hold nothing
             }
-            c = cap3(a0, a1, a2, app);
+            visited += chunk_len(O.n_x, c * kWave, kWave);
+            const int32_t incl = wave_inclusive_scan(cp);
+            const int32_t tot = read_lane(incl, kWave - 1);
+            if (tot > 0) {
+                const int64_t start = taken + (int64_t)(incl - cp);
+                const int64_t room = K - start;
+                const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
+                uint32_t id = j;
+                if (!SLOTS && t > 0) id = O.slot_node[j];
+                emit_runs(out, start, t, id, lane);
+            }
+            taken += tot;
+            if (taken >= K) return taken;
         }
-        visited += chunk_len(O.n_x, b, kWave);
-        const int32_t incl = wave_inclusive_scan(c);
-        const int32_t tot = read_lane(incl, kWave - 1);
-        if (tot > 0) {
-            const int64_t start = taken + (int64_t)(incl - c);
-            const int64_t room = K - start;
-            const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
-            uint32_t id = j;
-            if (!SLOTS && t > 0) id = O.slot_node[j];
-            emit_runs(out, start, t, id, lane);
-        }
-        taken += tot;
-        if (taken >= K) break;
     }
     return taken;
 }
@@ -369,29 +426,36 @@ __device__ __forceinline__ int64_t wave_even_pass1(const View& V, const Orders& 
                                                    unsigned long long& visited) {
     const int64_t K = app.k;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
-    for (uint32_t b = O.x_skip; b < O.n_x; b += kWave) {
-        const uint32_t j = b + lane;
-        bool flag = false;
-        if (j < O.n_x) {
-            int64_t a0, a1, a2;
-            V.load(j, a0, a1, a2);
-            if (j == ds) {
-                a0 -= app.drv0;
-                a1 -= app.drv1;
-                a2 -= app.drv2;
+    for (uint32_t g = 0; g * kWave < xc; ++g) {
+        uint64_t cm = chunk_group_mask(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+        visited += kWave;
+        while (cm) {
+            const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)cm) - 1);
+            cm &= cm - 1;
+            const uint32_t j = c * kWave + lane;
+            bool flag = false;
+            if (j < O.n_x) {
+                int64_t a0, a1, a2;
+                V.load(j, a0, a1, a2);
+                if (j == ds) {
+                    a0 -= app.drv0;
+                    a1 -= app.drv1;
+                    a2 -= app.drv2;
+                }
+                flag = cap_ge1(a0, a1, a2, app);
             }
-            flag = cap_ge1(a0, a1, a2, app);
+            visited += chunk_len(O.n_x, c * kWave, kWave);
+            const uint64_t m = __ballot(flag);
+            const int64_t pos = taken + (int64_t)__popcll((unsigned long long)(m & lt_mask));
+            if (flag && pos < K) {
+                out[pos] = SLOTS ? j : O.slot_node[j];
+                surv[pos] = j;
+            }
+            taken += (int64_t)__popcll((unsigned long long)m);
+            if (taken >= K) return taken;
         }
-        visited += chunk_len(O.n_x, b, kWave);
-        const uint64_t m = __ballot(flag);
-        const int64_t pos = taken + (int64_t)__popcll((unsigned long long)(m & lt_mask));
-        if (flag && pos < K) {
-            out[pos] = SLOTS ? j : O.slot_node[j];
-            surv[pos] = j;
-        }
-        taken += (int64_t)__popcll((unsigned long long)m);
-        if (taken >= K) break;
     }
     return taken;
 }
@@ -571,7 +635,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     if (a >= n_apps) return;
     const App app = load_app(apps, a);
-    GlobalView V{T.cpu, T.mem, T.gpu};
+    GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, T.d_identity != 0};
     unsigned long long xvis = 0, dvis = 0;
     const Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off,
@@ -650,23 +714,26 @@ struct FifoShared {
 // State of one executor scan of the FIFO fast path (all fields workgroup-uniform except `hit`).
 struct FifoScan {
     int64_t taken;  // placements so far (tightly-pack: sum of clamped capacities)
-    uint32_t it;    // chunk index since x_skip
     uint32_t end;   // one past the last slot looked at
-    uint64_t hit;   // per thread: bit `it` set when this thread's slot in chunk `it` hosts >= 1 executor
+    uint64_t hit;   // per thread: bit s set when this thread's slot in step s (slots [s*BLOCK, (s+1)*BLOCK)) hosts an executor
 };
 
-// One step of the executor scan: BLOCK consecutive slots starting at b.  LDS_ONLY is a compile-time promise that every
-// valid slot of the step lives in LDS: that instantiation contains no global LOAD, hence no vmcnt wait — placement
-// stores still in flight (which count in vmcnt on gfx9-family ISAs) never stall the chain.
+// One step of the executor scan: BLOCK consecutive slots starting at b = step * BLOCK, one 64-slot chunk per wave.
+// `mine` (wave-uniform): the maxima index could not rule this wave's chunk out; ruled-out chunks contribute 0 unread.
+// LDS_ONLY is a compile-time promise that every valid slot of the step lives in LDS: that instantiation contains no
+// global LOAD, hence no vmcnt wait — placement stores still in flight (they count in vmcnt on gfx9-family ISAs)
+// never stall the chain.
 template <int ALGO, int NW, bool LDS_ONLY>
 __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders& O, const App& app, uint32_t ds,
-                                               uint32_t b, uint32_t tid, int wave, int lane, Exchange<NW>* X, int& xb,
-                                               uint32_t* __restrict__ out, uint32_t* __restrict__ surv, FifoScan& st) {
+                                               uint32_t step, bool mine, uint32_t tid, int wave, int lane,
+                                               Exchange<NW>* X, int& xb, uint32_t* __restrict__ out,
+                                               uint32_t* __restrict__ surv, FifoScan& st) {
     constexpr uint32_t BLOCK = kWave * NW;
     const int64_t K = app.k;
+    const uint32_t b = step * BLOCK;
     const uint32_t j = b + tid;
     int64_t a0 = -1, a1 = -1, a2 = -1;
-    if (j < O.n_x) {
+    if (mine && j < O.n_x) {
         if (LDS_ONLY)
             V.load_lds(j, a0, a1, a2);
         else
@@ -678,8 +745,10 @@ __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders
         }
     }
     st.end = b + BLOCK;
+    const bool ge1 = mine && (j < O.n_x) && cap_ge1(a0, a1, a2, app);
     if (ALGO == GF_ALGO_TIGHTLY_PACK) {
-        const int32_t c = (j < O.n_x) ? cap3(a0, a1, a2, app) : 0;
+        int32_t c = 0;
+        if (ge1) c = cap3(a0, a1, a2, app);  // no division for slots (or whole waves) that hold nothing
         const int32_t incl = wave_inclusive_scan(c);
         int64_t prefix, total;
         block_scan<NW>(X, xb, read_lane(incl, kWave - 1), wave, lane, prefix, total);
@@ -687,49 +756,49 @@ __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders
             const int64_t start = st.taken + prefix + (int64_t)(incl - c);
             const int64_t room = K - start;
             const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
-            if (t > 0 && st.it < 64) st.hit |= 1ull << st.it;
+            if (t > 0 && step < 64) st.hit |= 1ull << step;
             emit_runs(out, start, t, j, lane);
         }
         st.taken += total;
     } else {
-        const bool flag = (j < O.n_x) && cap_ge1(a0, a1, a2, app);
-        const uint64_t m = __ballot(flag);
+        const uint64_t m = __ballot(ge1);
         int64_t prefix, total;
         block_scan<NW>(X, xb, (int32_t)__popcll((unsigned long long)m), wave, lane, prefix, total);
         const int64_t pos = st.taken + prefix + (int64_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-        if (flag && pos < K) {
+        if (ge1 && pos < K) {
             out[pos] = j;
             surv[pos] = j;  // survivor list for the (rare) multi-pass path
-            if (st.it < 64) st.hit |= 1ull << st.it;
+            if (step < 64) st.hit |= 1ull << step;
         }
         st.taken += total;
     }
-    ++st.it;
 }
 
 // One step of the driver-candidate scan: returns the first fitting position of this step or INT64_MAX.
-template <int NW, bool LDS_ONLY>
-__device__ __forceinline__ int64_t fifo_driver_step(const HybridView& V, const Orders& O, const App& app, uint32_t b,
-                                                    uint32_t tid, int wave, int lane, Exchange<NW>* X, int& xb) {
-    const uint32_t i = b + tid;
+template <int NW, bool LDS_ONLY, bool DIDENT>
+__device__ __forceinline__ int64_t fifo_driver_step(const HybridView& V, const Orders& O, const App& app,
+                                                    uint32_t step, bool mine, uint32_t tid, int wave, int lane,
+                                                    Exchange<NW>* X, int& xb) {
+    constexpr uint32_t BLOCK = kWave * NW;
+    const uint32_t i = step * BLOCK + tid;
     bool fit = false;
-    if (i < O.n_d) {
+    if (mine && i < O.n_d) {
         int64_t a0, a1, a2;
         if (LDS_ONLY)
             V.load_lds(i, a0, a1, a2);  // identity mapping: position == slot
         else
-            V.load(O.driver_slot(i), a0, a1, a2);
+            V.load(DIDENT ? i : O.driver_slot(i), a0, a1, a2);
         fit = driver_fits(a0, a1, a2, app);
     }
     const uint64_t m = __ballot(fit);
-    const int64_t wfirst = m ? (int64_t)b + wave * kWave + (__ffsll((unsigned long long)m) - 1) : INT64_MAX;
+    const int64_t wfirst = m ? (int64_t)(i - lane) + (__ffsll((unsigned long long)m) - 1) : INT64_MAX;
     return block_min<NW>(X, xb, wfirst, wave, lane);
 }
 
 // FIFO replay (internal/extender/resource.go:224-262 + :321): apps strictly in order, each against the residuals its
 // predecessors left.  ONE workgroup of NW waves: nodes in parallel (NW*64 per step), apps sequential.  The working
-// table's front lives in LDS, so the per-app critical path is LDS latency + a few workgroup barriers instead of
-// global-memory round trips.  Placements are written as SLOT ids (translated by translate_kernel afterwards).
+// table's front and the chunk-maxima index live in LDS, so the per-app critical path is LDS latency + a few workgroup
+// barriers instead of global-memory round trips.  Placements are written as SLOT ids (translate_kernel maps them).
 // DIDENT: the driver order is a prefix of the executor order (position == slot), the production shape; that
 // instantiation has no driver-slot gather, i.e. no global load anywhere on the per-app fast path.
 template <int ALGO, int NW, bool DIDENT>
@@ -743,27 +812,37 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                                                                   ScanStats* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t BLOCK = kWave * NW;
+    constexpr uint32_t STEPS_PER_GROUP = kWave / NW;  // one 64-bit chunk mask covers this many steps
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long t0_cycles = __builtin_readcyclecounter();
+    const unsigned long long t0_real = wall_clock64();
 
-    // ---- LDS carve: table front | exchange | shared scalars + staged apps
+    // ---- LDS carve: table front | chunk maxima | exchange | shared scalars + staged apps
     lds_i64* lcpu = (lds_i64*)smem;
     lds_i64* lmem = lcpu + lds_slots;
     lds_i64* lgpu = lmem + lds_slots;
-    Exchange<NW>* X = reinterpret_cast<Exchange<NW>*>(smem + 24 * (size_t)lds_slots);
+    lds_i64* lmax = lgpu + lds_slots;  // [3][n_chunks]
+    Exchange<NW>* X = reinterpret_cast<Exchange<NW>*>(smem + 24 * ((size_t)lds_slots + T.n_chunks));
     FifoShared* sh = reinterpret_cast<FifoShared*>(X + 1);
     for (uint32_t s = tid; s < lds_slots; s += BLOCK) {
         lcpu[s] = T.cpu[s];
         lmem[s] = T.mem[s];
         lgpu[s] = T.gpu[s];
     }
-    HybridView V{lcpu, lmem, lgpu, lds_slots, (glb_i64*)T.cpu, (glb_i64*)T.mem, (glb_i64*)T.gpu};
+    for (uint32_t c = tid; c < 3 * T.n_chunks; c += BLOCK) lmax[c] = T.cmax[c];
+    HybridView V{lcpu, lmem, lgpu, lds_slots, (glb_i64*)T.cpu, (glb_i64*)T.mem, (glb_i64*)T.gpu,
+                 lmax, lmax + T.n_chunks, lmax + 2 * (size_t)T.n_chunks, T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, DIDENT};
-    const bool mask_commit = (O.n_x - O.x_skip) <= 64u * BLOCK;  // a 64-bit per-thread hit mask covers a whole scan
-    // a step starting at b is LDS-only when b + BLOCK <= *_lds_limit (whole order resident -> no limit)
-    const uint32_t x_lds_limit = O.n_x <= lds_slots ? 0xFFFFFFFFu - BLOCK : lds_slots;
-    const uint32_t d_lds_limit = !DIDENT ? 0u : (O.n_d <= lds_slots ? 0xFFFFFFFFu - BLOCK : lds_slots);
+    const uint32_t xc = (O.n_x + kWave - 1) / kWave;  // chunks of the executor order
+    const uint32_t dc = (O.n_d + kWave - 1) / kWave;  // chunks of the driver order (identity mapping only)
+    const uint32_t x_steps = (O.n_x + BLOCK - 1) / BLOCK;
+    const uint32_t d_steps = (O.n_d + BLOCK - 1) / BLOCK;
+    const bool mask_commit = x_steps <= 64u;  // a 64-bit per-thread hit mask covers a whole scan
+    // a step is LDS-only when (step + 1) * BLOCK <= *_lds_limit (whole order resident -> no limit)
+    const uint32_t x_lds_steps = O.n_x <= lds_slots ? 0xFFFFFFFFu : lds_slots / BLOCK;
+    const uint32_t d_lds_steps = !DIDENT ? 0u : (O.n_d <= lds_slots ? 0xFFFFFFFFu : lds_slots / BLOCK);
 
     unsigned long long xvis = 0, dvis = 0;
     int xb = 0;
@@ -772,7 +851,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     for (; a < n_apps; ++a) {
         // ---- stage the next kAppStage app records (incl. reciprocals) into LDS
         if ((a % kAppStage) == 0) {
-            lds_barrier();  // previous stage fully consumed; also publishes the table fill
+            lds_barrier();  // previous stage fully consumed; also publishes the table / index fill
             const uint32_t n_stage = (n_apps - a) < (uint32_t)kAppStage ? (n_apps - a) : (uint32_t)kAppStage;
             if (tid < n_stage) sh->apps[tid] = load_app(apps, a + tid);
             lds_barrier();
@@ -783,20 +862,28 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         uint32_t* surv = scratch + app.exec_off;
         const bool last = (a + 1 == n_apps);
 
-        // ---- (1) first fitting driver candidate, BLOCK candidates per step
+        // ---- (1) first fitting driver candidate, BLOCK candidates per step; steps whose chunks the maxima index
+        //          rules out are skipped without a barrier (every wave evaluates the same 64-chunk mask)
         int64_t p0 = -1;
         {
-            uint32_t b = O.d_skip;
             int64_t f = INT64_MAX;
-            for (; b < O.n_d && b + BLOCK <= d_lds_limit; b += BLOCK) {
-                f = fifo_driver_step<NW, true>(V, O, app, b, tid, wave, lane, X, xb);
-                dvis += chunk_len(O.n_d, b, BLOCK);
-                if (f != INT64_MAX) break;
-            }
-            if (f == INT64_MAX) {
-                for (; b < O.n_d; b += BLOCK) {
-                    f = fifo_driver_step<NW, false>(V, O, app, b, tid, wave, lane, X, xb);
-                    dvis += chunk_len(O.n_d, b, BLOCK);
+            for (uint32_t g = 0; g * STEPS_PER_GROUP < d_steps && f == INT64_MAX; ++g) {
+                uint64_t gm = ~0ull;
+                if (DIDENT) {
+                    gm = chunk_group_mask(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
+                    dvis += kWave;
+                }
+                for (uint32_t s = 0; s < STEPS_PER_GROUP; ++s) {
+                    const uint32_t step = g * STEPS_PER_GROUP + s;
+                    if (step >= d_steps) break;
+                    const uint64_t bits = NW == 64 ? gm : ((gm >> (s * NW)) & ((1ull << NW) - 1ull));
+                    if (bits == 0) continue;
+                    const bool mine = (bits >> wave) & 1ull;
+                    if (step < d_lds_steps)
+                        f = fifo_driver_step<NW, true, DIDENT>(V, O, app, step, mine, tid, wave, lane, X, xb);
+                    else
+                        f = fifo_driver_step<NW, false, DIDENT>(V, O, app, step, mine, tid, wave, lane, X, xb);
+                    dvis += chunk_len(O.n_d, step * BLOCK, BLOCK);
                     if (f != INT64_MAX) break;
                 }
             }
@@ -810,7 +897,6 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         enum { kCommitDone, kCommitMask, kCommitList } commit = kCommitDone;
         FifoScan st;
         st.taken = 0;
-        st.it = 0;
         st.end = 0;
         st.hit = 0;
         if (p0 >= 0) {
@@ -820,15 +906,25 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                 dec.feasible = true;
                 commit = kCommitMask;  // nothing placed: only the driver request is subtracted
             } else {
-                // ---- (2) executors, BLOCK slots per step, lazy stop; LDS-resident steps first
-                uint32_t b = O.x_skip;
-                for (; b < O.n_x && b + BLOCK <= x_lds_limit && st.taken < K; b += BLOCK) {
-                    fifo_scan_step<ALGO, NW, true>(V, O, app, ds, b, tid, wave, lane, X, xb, out, surv, st);
-                    xvis += chunk_len(O.n_x, b, BLOCK);
-                }
-                for (; b < O.n_x && st.taken < K; b += BLOCK) {
-                    fifo_scan_step<ALGO, NW, false>(V, O, app, ds, b, tid, wave, lane, X, xb, out, surv, st);
-                    xvis += chunk_len(O.n_x, b, BLOCK);
+                // ---- (2) executors, BLOCK slots per step, lazy stop, ruled-out steps skipped
+                for (uint32_t g = 0; g * STEPS_PER_GROUP < x_steps && st.taken < K; ++g) {
+                    const uint64_t gm = chunk_group_mask(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+                    xvis += kWave;
+                    for (uint32_t s = 0; s < STEPS_PER_GROUP; ++s) {
+                        const uint32_t step = g * STEPS_PER_GROUP + s;
+                        if (step >= x_steps) break;
+                        const uint64_t bits = NW == 64 ? gm : ((gm >> (s * NW)) & ((1ull << NW) - 1ull));
+                        if (bits == 0) continue;
+                        const bool mine = (bits >> wave) & 1ull;
+                        if (step < x_lds_steps)
+                            fifo_scan_step<ALGO, NW, true>(V, O, app, ds, step, mine, tid, wave, lane, X, xb, out, surv,
+                                                           st);
+                        else
+                            fifo_scan_step<ALGO, NW, false>(V, O, app, ds, step, mine, tid, wave, lane, X, xb, out,
+                                                            surv, st);
+                        xvis += (uint64_t)__popcll((unsigned long long)bits) * kWave;
+                        if (st.taken >= K) break;
+                    }
                 }
                 if (st.taken >= K) {
                     dec.feasible = true;
@@ -893,23 +989,23 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         if (commit == kCommitMask) {
             bool hosts = false;
             uint64_t h = st.hit;
-            // the thread that would scan slot ds knows whether an executor landed there (a slot beyond the cut or a
-            // driver-only slot >= n_x was never hit)
-            const uint32_t owner = (dec.ds >= O.x_skip && dec.ds < O.n_x) ? (dec.ds - O.x_skip) % BLOCK : 0u;
+            // thread (ds % BLOCK) is the one that looks at slot ds when its step runs; a slot whose step was skipped,
+            // lies beyond the cut, or is driver-only (>= n_x) was never hit
+            const uint32_t owner = dec.ds % BLOCK;
             if (lds_only) {
                 while (h) {
-                    const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
+                    const uint32_t step = (uint32_t)__ffsll((unsigned long long)h) - 1;
                     h &= h - 1;
-                    const uint32_t s = O.x_skip + it * BLOCK + tid;
+                    const uint32_t s = step * BLOCK + tid;
                     V.sub_lds(s, app.exe0, app.exe1, app.exe2);
                     if (s == dec.ds) hosts = true;
                 }
                 if (tid == owner && !hosts) V.sub_lds(dec.ds, app.drv0, app.drv1, app.drv2);
             } else {
                 while (h) {
-                    const uint32_t it = (uint32_t)__ffsll((unsigned long long)h) - 1;
+                    const uint32_t step = (uint32_t)__ffsll((unsigned long long)h) - 1;
                     h &= h - 1;
-                    const uint32_t s = O.x_skip + it * BLOCK + tid;
+                    const uint32_t s = step * BLOCK + tid;
                     V.sub(s, app.exe0, app.exe1, app.exe2);
                     if (s == dec.ds) hosts = true;
                 }
@@ -946,6 +1042,8 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         if (stats != nullptr) {
             atomicAdd(&stats->exec_slots_visited, xvis);
             atomicAdd(&stats->driver_slots_visited, dvis);
+            stats->fifo_shader_cycles = __builtin_readcyclecounter() - t0_cycles;
+            stats->fifo_realtime_ticks = wall_clock64() - t0_real;
         }
     }
 }
@@ -1057,7 +1155,7 @@ template <int ALGO, int NW, bool DIDENT>
 hipError_t launch_fifo_d(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
                          gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
                          int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
-    const size_t lds = 24 * (size_t)lds_slots + fifo_fixed_lds_bytes(NW);
+    const size_t lds = 24 * ((size_t)lds_slots + table.n_chunks) + fifo_fixed_lds_bytes(NW);
     auto kernel = fit_fifo_chain_kernel<ALGO, NW, DIDENT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

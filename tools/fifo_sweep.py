@@ -44,9 +44,15 @@ def main():
                     if i >= 3:
                         e2e.append(dt * 1e3)
                         kern.append(k_ms)
+                ctx.scan_stats(enable=True, reset=True)
+                ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps)
+                xv, dv = ctx.scan_stats(enable=False, reset=True)
+                cyc, ticks = ctx.last_fifo_clock
                 key = ("congested" if congested else "nominal") + "_" + name
                 out[key] = {"e2e_p50_ms": round(pct(e2e, 0.5), 4), "e2e_p99_ms": round(pct(e2e, 0.99), 4),
-                            "stream_p50_ms": round(pct(kern, 0.5), 4)}
+                            "stream_p50_ms": round(pct(kern, 0.5), 4), "exec_slots": xv, "driver_slots": dv,
+                            "kernel_cycles": cyc, "kernel_us": ticks / 100.0,
+                            "sclk_mhz": round(cyc / max(ticks, 1) * 100.0, 1)}
     print(json.dumps(out))
 
 
