@@ -151,9 +151,10 @@ int gf_timer_end(gf_ctx *ctx, float *elapsed_ms);
  * the reference's loops: they stop once K executors are placed).  enable != 0 makes subsequent launches count
  * (one atomic pair per app); out[0] = executor-order slots whose capacity was evaluated, out[1] = driver-order
  * positions whose fit was evaluated, accumulated since the last reset; out[2] / out[3] = shader-clock cycles and
- * 100 MHz real-time ticks spent inside the last FIFO-chain kernel (their ratio is the effective shader clock).
+ * 100 MHz real-time ticks spent inside the last FIFO-chain kernel (their ratio is the effective shader clock);
+ * out[4..9] = that kernel's shader cycles by phase (app staging, driver scan, executor scan, slow path, commit, spare).
  * out may be NULL. */
-int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[4]);
+int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[10]);
 
 /* On-device self-test of the wave primitives (DPP prefix scan, exact clamped 64-bit division) against plain
  * reference code on n_cases adversarial inputs per lane.  *mismatches == 0 means pass. */

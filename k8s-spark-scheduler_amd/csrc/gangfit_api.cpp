@@ -101,7 +101,7 @@ struct gf_ctx {
     bool work_valid = false;
     bool d_identity = false;
     uint32_t x_skip = 0, d_skip = 0;  // dead prefixes of the two orders (see NodeTable)
-    int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
+    int fifo_waves = 4;        // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
     // batch buffers
@@ -172,7 +172,7 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
         // as much of the table front as fits next to the kernel's fixed LDS needs stays in LDS for the whole chain
-        const size_t fixed = gangfit::fifo_fixed_lds_bytes(ctx->fifo_waves) + 24 * (size_t)ctx->n_chunks;
+        const size_t fixed = gangfit::fifo_fixed_lds_bytes(ctx->fifo_waves) + 25 * (size_t)ctx->n_chunks + 16;
         uint32_t lds_slots = ctx->lds_budget > fixed ? (uint32_t)((ctx->lds_budget - fixed) / 24) : 0;
         lds_slots &= ~63u;
         if (lds_slots > ctx->n_slots) lds_slots = ctx->n_slots;
@@ -507,7 +507,7 @@ int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
     return GF_OK;
 }
 
-int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[4]) {
+int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -519,6 +519,7 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[4]) {
         out[1] = s.driver_slots_visited;
         out[2] = s.fifo_shader_cycles;
         out[3] = s.fifo_realtime_ticks;
+        for (int i = 0; i < 6; ++i) out[4 + i] = s.fifo_phase_cycles[i];
     }
     if (reset) GF_HIP(ctx, hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)));
     ctx->stats_on = enable != 0;

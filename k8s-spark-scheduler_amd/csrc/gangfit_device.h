@@ -42,6 +42,7 @@ struct ScanStats {
     unsigned long long driver_slots_visited;  // driver-order positions whose fit was evaluated
     unsigned long long fifo_shader_cycles;    // s_memtime delta over the last FIFO chain kernel (shader clock)
     unsigned long long fifo_realtime_ticks;   // s_memrealtime delta over the same span (constant 100 MHz)
+    unsigned long long fifo_phase_cycles[6];  // wave-0 shader cycles: stage | driver scan | executor scan | slow path | commit | steps
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).

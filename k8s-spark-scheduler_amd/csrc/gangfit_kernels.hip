@@ -71,6 +71,27 @@ __device__ __forceinline__ int64_t read_lane(int64_t v, int src) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// Maximum of a signed 64-bit value over the 64 lanes (wave-uniform result): row-wise running max with row_shr 1/2/4/8,
+// then row_bcast15 / row_bcast31 carry the row maxima to lane 63.  ~30 VALU instructions, no LDS.
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+#define GF_MAX_STEP(ctrl, rmask)                                                                              \
+    {                                                                                                         \
+        const int32_t lo = (int32_t)(uint32_t)v, hi = (int32_t)(v >> 32);                                     \
+        const uint32_t tlo = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, ctrl, rmask, 0xf, false);          \
+        const int32_t thi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rmask, 0xf, false);                     \
+        const int64_t t = (int64_t)(((uint64_t)(uint32_t)thi << 32) | tlo);                                   \
+        v = t > v ? t : v;                                                                                    \
+    }
+    GF_MAX_STEP(GF_DPP_ROW_SHR(1), 0xf)
+    GF_MAX_STEP(GF_DPP_ROW_SHR(2), 0xf)
+    GF_MAX_STEP(GF_DPP_ROW_SHR(4), 0xf)
+    GF_MAX_STEP(GF_DPP_ROW_SHR(8), 0xf)
+    GF_MAX_STEP(GF_DPP_ROW_BCAST15, 0xa)
+    GF_MAX_STEP(GF_DPP_ROW_BCAST31, 0xc)
+#undef GF_MAX_STEP
+    return read_lane(v, kWave - 1);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): with placement stores in
 // flight every barrier would stall for a global-memory round trip (measured: ~2 us per app in the FIFO chain).
 // Data exchanged through this barrier must live in LDS.
@@ -657,32 +678,40 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
 
 // ------------------------------------------------------------------------------------------------ FIFO chain
 
-// Workgroup-level exchange of one value per wave through LDS.  Two alternating buffers: one __syncthreads per
-// exchange is enough (a wave can only be one exchange ahead of the slowest wave).
-template <int NW>
+// Workgroup-level exchange of one 32-bit value per wave through LDS.  Two alternating buffers: one barrier per
+// exchange is enough (a wave can only be one exchange ahead of the slowest wave).  16 entries regardless of NW (entries
+// >= NW hold the identity) so that lanes 0..15 of every wave can combine them with 4 DPP steps instead of a serial loop.
 struct Exchange {
-    int64_t first[2][NW];
-    int32_t tot[2][NW];
+    uint32_t first[2][16];
+    int32_t tot[2][16];
 };
+constexpr uint32_t kNoPos = 0xFFFFFFFFu;
 
+// Minimum over the waves of a wave-uniform position (kNoPos = none).
 template <int NW>
-__device__ __forceinline__ int64_t block_min(Exchange<NW>* X, int& xb, int64_t wave_value, int wave, int lane) {
+__device__ __forceinline__ uint32_t block_min(Exchange* X, int& xb, uint32_t wave_value, int wave, int lane) {
     if (NW == 1) return wave_value;
     if (lane == 0) X->first[xb][wave] = wave_value;
     lds_barrier();
-    int64_t m = X->first[xb][0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) {
-        const int64_t v = X->first[xb][w];
-        m = v < m ? v : m;
+    int32_t x = (int32_t)X->first[xb][lane & 15];
+#define GF_MIN_STEP(n)                                                                                  \
+    {                                                                                                   \
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(-1, x, GF_DPP_ROW_SHR(n), 0xf, 0xf, false); \
+        x = (int32_t)(t < (uint32_t)x ? t : (uint32_t)x);                                               \
     }
+    GF_MIN_STEP(1)
+    GF_MIN_STEP(2)
+    GF_MIN_STEP(4)
+    GF_MIN_STEP(8)
+#undef GF_MIN_STEP
     xb ^= 1;
-    return m;
+    return (uint32_t)read_lane(x, 15);
 }
 
+// Exclusive prefix over the waves (in wave order) and total of a wave-uniform count.
 template <int NW>
-__device__ __forceinline__ void block_scan(Exchange<NW>* X, int& xb, int32_t wave_total, int wave, int lane,
-                                           int64_t& prefix, int64_t& total) {
+__device__ __forceinline__ void block_scan(Exchange* X, int& xb, int32_t wave_total, int wave, int lane,
+                                           int32_t& prefix, int32_t& total) {
     if (NW == 1) {
         prefix = 0;
         total = wave_total;
@@ -690,19 +719,18 @@ __device__ __forceinline__ void block_scan(Exchange<NW>* X, int& xb, int32_t wav
     }
     if (lane == 0) X->tot[xb][wave] = wave_total;
     lds_barrier();
-    int64_t p = 0, t = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int32_t v = X->tot[xb][w];
-        t += v;
-        if (w < wave) p += v;
-    }
+    int32_t x = X->tot[xb][lane & 15];
+    x += __builtin_amdgcn_update_dpp(0, x, GF_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, GF_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, GF_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, GF_DPP_ROW_SHR(8), 0xf, 0xf, false);
     xb ^= 1;
-    prefix = p;
-    total = t;
+    prefix = read_lane(x, wave) - wave_total;
+    total = read_lane(x, 15);
 }
 
 constexpr int kAppStage = 32;  // app records staged into LDS per refill
+constexpr int kRefresh = 8;    // apps between refreshes of the dirty entries of the chunk-maxima index
 
 struct FifoShared {
     App apps[kAppStage];
@@ -713,7 +741,7 @@ struct FifoShared {
 
 // State of one executor scan of the FIFO fast path (all fields workgroup-uniform except `hit`).
 struct FifoScan {
-    int64_t taken;  // placements so far (tightly-pack: sum of clamped capacities)
+    int32_t taken;  // placements so far (tightly-pack: sum of clamped capacities); < K + 2^30
     uint32_t end;   // one past the last slot looked at
     uint64_t hit;   // per thread: bit s set when this thread's slot in step s (slots [s*BLOCK, (s+1)*BLOCK)) hosts an executor
 };
@@ -726,10 +754,10 @@ struct FifoScan {
 template <int ALGO, int NW, bool LDS_ONLY>
 __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders& O, const App& app, uint32_t ds,
                                                uint32_t step, bool mine, uint32_t tid, int wave, int lane,
-                                               Exchange<NW>* X, int& xb, uint32_t* __restrict__ out,
+                                               Exchange* X, int& xb, uint32_t* __restrict__ out,
                                                uint32_t* __restrict__ surv, FifoScan& st) {
     constexpr uint32_t BLOCK = kWave * NW;
-    const int64_t K = app.k;
+    const int32_t K = app.k;
     const uint32_t b = step * BLOCK;
     const uint32_t j = b + tid;
     int64_t a0 = -1, a1 = -1, a2 = -1;
@@ -750,21 +778,21 @@ __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders
         int32_t c = 0;
         if (ge1) c = cap3(a0, a1, a2, app);  // no division for slots (or whole waves) that hold nothing
         const int32_t incl = wave_inclusive_scan(c);
-        int64_t prefix, total;
+        int32_t prefix, total;
         block_scan<NW>(X, xb, read_lane(incl, kWave - 1), wave, lane, prefix, total);
         if (total > 0) {
-            const int64_t start = st.taken + prefix + (int64_t)(incl - c);
-            const int64_t room = K - start;
-            const int32_t t = room <= 0 ? 0 : (room < (int64_t)c ? (int32_t)room : c);
+            const int32_t start = st.taken + prefix + (incl - c);
+            const int32_t room = K - start;
+            const int32_t t = room <= 0 ? 0 : (room < c ? room : c);
             if (t > 0 && step < 64) st.hit |= 1ull << step;
             emit_runs(out, start, t, j, lane);
         }
         st.taken += total;
     } else {
         const uint64_t m = __ballot(ge1);
-        int64_t prefix, total;
+        int32_t prefix, total;
         block_scan<NW>(X, xb, (int32_t)__popcll((unsigned long long)m), wave, lane, prefix, total);
-        const int64_t pos = st.taken + prefix + (int64_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+        const int32_t pos = st.taken + prefix + (int32_t)__popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
         if (ge1 && pos < K) {
             out[pos] = j;
             surv[pos] = j;  // survivor list for the (rare) multi-pass path
@@ -774,11 +802,11 @@ __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders
     }
 }
 
-// One step of the driver-candidate scan: returns the first fitting position of this step or INT64_MAX.
+// One step of the driver-candidate scan: returns the first fitting position of this step or kNoPos.
 template <int NW, bool LDS_ONLY, bool DIDENT>
-__device__ __forceinline__ int64_t fifo_driver_step(const HybridView& V, const Orders& O, const App& app,
+__device__ __forceinline__ uint32_t fifo_driver_step(const HybridView& V, const Orders& O, const App& app,
                                                     uint32_t step, bool mine, uint32_t tid, int wave, int lane,
-                                                    Exchange<NW>* X, int& xb) {
+                                                    Exchange* X, int& xb) {
     constexpr uint32_t BLOCK = kWave * NW;
     const uint32_t i = step * BLOCK + tid;
     bool fit = false;
@@ -791,7 +819,7 @@ __device__ __forceinline__ int64_t fifo_driver_step(const HybridView& V, const O
         fit = driver_fits(a0, a1, a2, app);
     }
     const uint64_t m = __ballot(fit);
-    const int64_t wfirst = m ? (int64_t)(i - lane) + (__ffsll((unsigned long long)m) - 1) : INT64_MAX;
+    const uint32_t wfirst = m ? (i - (uint32_t)lane) + (uint32_t)(__ffsll((unsigned long long)m) - 1) : kNoPos;
     return block_min<NW>(X, xb, wfirst, wave, lane);
 }
 
@@ -824,14 +852,17 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     lds_i64* lmem = lcpu + lds_slots;
     lds_i64* lgpu = lmem + lds_slots;
     lds_i64* lmax = lgpu + lds_slots;  // [3][n_chunks]
-    Exchange<NW>* X = reinterpret_cast<Exchange<NW>*>(smem + 24 * ((size_t)lds_slots + T.n_chunks));
+    Exchange* X = reinterpret_cast<Exchange*>(smem + 24 * ((size_t)lds_slots + T.n_chunks));
     FifoShared* sh = reinterpret_cast<FifoShared*>(X + 1);
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    lds_u8* dirty = (lds_u8*)(sh + 1);  // [n_chunks] chunk touched by a commit since the last maxima refresh
     for (uint32_t s = tid; s < lds_slots; s += BLOCK) {
         lcpu[s] = T.cpu[s];
         lmem[s] = T.mem[s];
         lgpu[s] = T.gpu[s];
     }
     for (uint32_t c = tid; c < 3 * T.n_chunks; c += BLOCK) lmax[c] = T.cmax[c];
+    for (uint32_t c = tid; c < T.n_chunks; c += BLOCK) dirty[c] = 0;
     HybridView V{lcpu, lmem, lgpu, lds_slots, (glb_i64*)T.cpu, (glb_i64*)T.mem, (glb_i64*)T.gpu,
                  lmax, lmax + T.n_chunks, lmax + 2 * (size_t)T.n_chunks, T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, DIDENT};
@@ -845,10 +876,39 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     const uint32_t d_lds_steps = !DIDENT ? 0u : (O.n_d <= lds_slots ? 0xFFFFFFFFu : lds_slots / BLOCK);
 
     unsigned long long xvis = 0, dvis = 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};  // per-phase cycle accounting (only when stats are requested)
+    const bool prof = stats != nullptr;
+    unsigned long long tp = prof ? __builtin_readcyclecounter() : 0;
+#define GF_PHASE(idx)                                             \
+    if (prof) {                                                   \
+        const unsigned long long tn = __builtin_readcyclecounter(); \
+        ph[idx] += tn - tp;                                       \
+        tp = tn;                                                  \
+    }
     int xb = 0;
     int32_t failed_at = -1;
     uint32_t a = 0;
     for (; a < n_apps; ++a) {
+        // ---- keep the maxima index tight: recompute the chunks that commits touched since the last refresh (the
+        //      entries are upper bounds, so a stale one is only a missed skip, never a wrong answer)
+        if ((a % kRefresh) == 0 && a != 0) {
+            for (uint32_t c = (uint32_t)wave; c < T.n_chunks; c += NW) {
+                if (!dirty[c]) continue;  // wave-uniform
+                const uint32_t s = c * kWave + lane;
+                int64_t a0 = INT64_MIN, a1 = INT64_MIN, a2 = INT64_MIN;
+                if (s < T.n_slots) V.load(s, a0, a1, a2);
+                a0 = wave_max_i64(a0);
+                a1 = wave_max_i64(a1);
+                a2 = wave_max_i64(a2);
+                if (lane == 0) {
+                    lmax[c] = a0;
+                    lmax[T.n_chunks + c] = a1;
+                    lmax[2 * (size_t)T.n_chunks + c] = a2;
+                    dirty[c] = 0;
+                }
+            }
+            __syncthreads();
+        }
         // ---- stage the next kAppStage app records (incl. reciprocals) into LDS
         if ((a % kAppStage) == 0) {
             lds_barrier();  // previous stage fully consumed; also publishes the table / index fill
@@ -857,17 +917,18 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
             lds_barrier();
         }
         const App app = sh->apps[a % kAppStage];
-        const int64_t K = app.k;
+        const int32_t K = app.k;
         uint32_t* out = exec_nodes + app.exec_off;
         uint32_t* surv = scratch + app.exec_off;
         const bool last = (a + 1 == n_apps);
+        GF_PHASE(0)
 
         // ---- (1) first fitting driver candidate, BLOCK candidates per step; steps whose chunks the maxima index
         //          rules out are skipped without a barrier (every wave evaluates the same 64-chunk mask)
         int64_t p0 = -1;
         {
-            int64_t f = INT64_MAX;
-            for (uint32_t g = 0; g * STEPS_PER_GROUP < d_steps && f == INT64_MAX; ++g) {
+            uint32_t f = kNoPos;
+            for (uint32_t g = 0; g * STEPS_PER_GROUP < d_steps && f == kNoPos; ++g) {
                 uint64_t gm = ~0ull;
                 if (DIDENT) {
                     gm = chunk_group_mask(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
@@ -884,11 +945,12 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                     else
                         f = fifo_driver_step<NW, false, DIDENT>(V, O, app, step, mine, tid, wave, lane, X, xb);
                     dvis += chunk_len(O.n_d, step * BLOCK, BLOCK);
-                    if (f != INT64_MAX) break;
+                    if (f != kNoPos) break;
                 }
             }
-            if (f != INT64_MAX) p0 = f;
+            if (f != kNoPos) p0 = (int64_t)f;
         }
+        GF_PHASE(1)
 
         Decision dec;
         dec.feasible = false;
@@ -926,6 +988,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                         if (st.taken >= K) break;
                     }
                 }
+                GF_PHASE(2)
                 if (st.taken >= K) {
                     dec.feasible = true;
                     dec.pass1 = st.taken;
@@ -960,6 +1023,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                     dec.ds = sh->slow_ds;
                     dec.pass1 = sh->slow_pass1;
                     commit = kCommitDone;
+                    GF_PHASE(3)
                 }
             }
         }
@@ -998,18 +1062,26 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                     h &= h - 1;
                     const uint32_t s = step * BLOCK + tid;
                     V.sub_lds(s, app.exe0, app.exe1, app.exe2);
+                    dirty[s / kWave] = 1;
                     if (s == dec.ds) hosts = true;
                 }
-                if (tid == owner && !hosts) V.sub_lds(dec.ds, app.drv0, app.drv1, app.drv2);
+                if (tid == owner && !hosts) {
+                    V.sub_lds(dec.ds, app.drv0, app.drv1, app.drv2);
+                    dirty[dec.ds / kWave] = 1;
+                }
             } else {
                 while (h) {
                     const uint32_t step = (uint32_t)__ffsll((unsigned long long)h) - 1;
                     h &= h - 1;
                     const uint32_t s = step * BLOCK + tid;
                     V.sub(s, app.exe0, app.exe1, app.exe2);
+                    dirty[s / kWave] = 1;
                     if (s == dec.ds) hosts = true;
                 }
-                if (tid == owner && !hosts) V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+                if (tid == owner && !hosts) {
+                    V.sub(dec.ds, app.drv0, app.drv1, app.drv2);
+                    dirty[dec.ds / kWave] = 1;
+                }
             }
         } else if (commit == kCommitList) {
             __syncthreads();  // every wave's placements are written
@@ -1020,7 +1092,9 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
             lds_barrier();
         else
             __syncthreads();
+        GF_PHASE(4)
     }
+#undef GF_PHASE
     // apps behind an abort are reported as not evaluated
     for (uint32_t r = a + tid; r < n_apps; r += BLOCK) {
         gf_result z;
@@ -1044,6 +1118,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
             atomicAdd(&stats->driver_slots_visited, dvis);
             stats->fifo_shader_cycles = __builtin_readcyclecounter() - t0_cycles;
             stats->fifo_realtime_ticks = wall_clock64() - t0_real;
+            for (int i = 0; i < 6; ++i) stats->fifo_phase_cycles[i] = ph[i];
         }
     }
 }
@@ -1146,8 +1221,8 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
 }
 
 size_t fifo_fixed_lds_bytes(int n_waves) {
-    const size_t ex = n_waves == 16 ? sizeof(Exchange<16>) : (n_waves == 4 ? sizeof(Exchange<4>) : sizeof(Exchange<1>));
-    return ex + sizeof(FifoShared) + 64;
+    (void)n_waves;
+    return sizeof(Exchange) + sizeof(FifoShared) + 64;
 }
 
 namespace {
@@ -1155,7 +1230,7 @@ template <int ALGO, int NW, bool DIDENT>
 hipError_t launch_fifo_d(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
                          gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
                          int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
-    const size_t lds = 24 * ((size_t)lds_slots + table.n_chunks) + fifo_fixed_lds_bytes(NW);
+    const size_t lds = 24 * ((size_t)lds_slots + table.n_chunks) + fifo_fixed_lds_bytes(NW) + ((table.n_chunks + 15) & ~15u);
     auto kernel = fit_fifo_chain_kernel<ALGO, NW, DIDENT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

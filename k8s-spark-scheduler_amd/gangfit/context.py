@@ -145,9 +145,10 @@ class Context:
         return float(ms.value)
 
     def scan_stats(self, enable: bool = True, reset: bool = False):
-        out = np.zeros(4, dtype=np.uint64)
+        out = np.zeros(10, dtype=np.uint64)
         self._check(self._lib.gf_scan_stats(self._h, int(enable), int(reset), N.ptr(out)))
         self.last_fifo_clock = (int(out[2]), int(out[3]))  # (shader cycles, 100 MHz ticks) of the last FIFO kernel
+        self.last_fifo_phases = [int(v) for v in out[4:10]]  # stage, driver scan, executor scan, slow path, commit
         return int(out[0]), int(out[1])
 
     def selftest(self, seed: int = 1, n_cases: int = 256) -> int:

@@ -52,7 +52,7 @@ def main():
                 out[key] = {"e2e_p50_ms": round(pct(e2e, 0.5), 4), "e2e_p99_ms": round(pct(e2e, 0.99), 4),
                             "stream_p50_ms": round(pct(kern, 0.5), 4), "exec_slots": xv, "driver_slots": dv,
                             "kernel_cycles": cyc, "kernel_us": ticks / 100.0,
-                            "sclk_mhz": round(cyc / max(ticks, 1) * 100.0, 1)}
+                            "sclk_mhz": round(cyc / max(ticks, 1) * 100.0, 1), "phase_cycles": ctx.last_fifo_phases}
     print(json.dumps(out))
 
 
