@@ -863,6 +863,10 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     }
     for (uint32_t c = tid; c < 3 * T.n_chunks; c += BLOCK) lmax[c] = T.cmax[c];
     for (uint32_t c = tid; c < T.n_chunks; c += BLOCK) dirty[c] = 0;
+    if (tid < 32) {  // exchange entries of waves that do not exist must hold the identity
+        X->first[tid >> 4][tid & 15] = kNoPos;
+        X->tot[tid >> 4][tid & 15] = 0;
+    }
     HybridView V{lcpu, lmem, lgpu, lds_slots, (glb_i64*)T.cpu, (glb_i64*)T.mem, (glb_i64*)T.gpu,
                  lmax, lmax + T.n_chunks, lmax + 2 * (size_t)T.n_chunks, T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, DIDENT};
