@@ -101,7 +101,7 @@ struct gf_ctx {
     bool work_valid = false;
     bool d_identity = false;
     uint32_t x_skip = 0, d_skip = 0;  // dead prefixes of the two orders (see NodeTable)
-    int fifo_waves = 4;        // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
+    int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
     // batch buffers
@@ -521,7 +521,10 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
         out[3] = s.fifo_realtime_ticks;
         for (int i = 0; i < 6; ++i) out[4 + i] = s.fifo_phase_cycles[i];
     }
-    if (reset) GF_HIP(ctx, hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)));
+    if (reset) {  // on the context's stream: a null-stream memset is not ordered against a non-blocking stream
+        GF_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, sizeof(ScanStats), ctx->stream));
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->stats_on = enable != 0;
     return GF_OK;
 }

@@ -26,7 +26,10 @@ namespace gangfit {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;  // independent-batch kernel: 4 apps per 256-thread workgroup
+#ifndef GF_WAVES_PER_BLOCK
+#define GF_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = GF_WAVES_PER_BLOCK;  // independent-batch kernel: apps (= waves) per workgroup
 
 // ------------------------------------------------------------------------------------------------ wave primitives
 

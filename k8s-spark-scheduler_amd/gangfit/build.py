@@ -44,6 +44,8 @@ def build_native(force: bool = False, extra_flags=()) -> str:
 def build_host(force: bool = False) -> str:
     """C++ host mirror of the reference's plug-in interface (string node names, Quantity parsing) on top of the C ABI."""
     host_dir = os.path.join(_PKG_ROOT, "host")
+    if not os.path.isdir(host_dir):
+        return ""
     srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
     hdrs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".hpp")]
     if not srcs:

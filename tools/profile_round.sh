@@ -1,0 +1,21 @@
+#!/bin/bash
+# Profiling recipe of one round (run on the MI355X box through gpurun; outputs under gpurun_out/prof_<tag>/).
+#   1. rocprofv3 --kernel-trace --stats of the default bench command        -> kernel durations
+#   2. rocprofv3 --pmc FETCH_SIZE   (own pass, kernel-trace only)            -> HBM read bytes per launch
+#   3. rocprofv3 --pmc WRITE_SIZE   (own pass)                               -> HBM write bytes per launch
+# PMC passes are never combined with sys/runtime/hip/hsa trace domains.
+set -u
+TAG=${1:-r1}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-}"
+timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -T -f csv -d "$OUT/pmc_fetch" -o pmc -- $BENCH --no-extras > "$OUT/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -T -f csv -d "$OUT/pmc_write" -o pmc -- $BENCH --no-extras > "$OUT/pmc_write.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -T -f csv -d "$OUT/pmc_l2" -o pmc -- $BENCH --no-extras > "$OUT/pmc_l2.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -T -f csv -d "$OUT/pmc_sq" -o pmc -- $BENCH --no-extras > "$OUT/pmc_sq.log" 2>&1
+find "$OUT" -name '*.csv' | head -40
+grep -h '^{' "$OUT"/*.log | head -5
