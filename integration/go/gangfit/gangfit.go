@@ -1,0 +1,275 @@
+// Package gangfit is the cgo binding of libgangfit (include/gangfit.h) that a maintainer of
+// palantir/k8s-spark-scheduler drops into the reference tree as internal/gangfit/gangfit.go.
+//
+// NOT COMPILED IN THE BUILD CONTAINER (no Go toolchain there): this file is the reference-side stub that
+// INTEGRATION.md describes.  Build with CGO_ENABLED=1 (the reference's dist config sets it to 0,
+// godel/config/dist-plugin.yml:7,26) and -lgangfit on the linker path.
+//
+// cgo pointer rules: every slice handed to C is a flat []int64 / []uint32 / []C.gf_app without Go pointers; the
+// library copies inputs before returning and writes only into caller-allocated flat slices.
+package gangfit
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -lgangfit
+#include <stdlib.h>
+#include "gangfit.h"
+*/
+import "C"
+
+import (
+	"context"
+	"errors"
+	"fmt"
+	"math"
+	"sync"
+	"unsafe"
+
+	"github.com/palantir/k8s-spark-scheduler-lib/pkg/binpack"
+	"github.com/palantir/k8s-spark-scheduler-lib/pkg/resources"
+	"k8s.io/apimachinery/pkg/api/resource"
+)
+
+// ErrNotRepresentable makes the caller fall back to the Go packer: the value is not an exact canonical int64
+// (sub-milli cpu, fractional bytes, |v| >= 2^62).  MilliValue()/Value() round UP (quantity.go:732-755), hence the
+// explicit round-trip checks.
+var ErrNotRepresentable = errors.New("gangfit: quantity is not exactly representable as canonical int64")
+
+const maxAbs = int64(1) << 62
+
+func milli(q resource.Quantity) (int64, error) {
+	v := q.MilliValue()
+	if v >= maxAbs || v <= -maxAbs || resource.NewMilliQuantity(v, q.Format).Cmp(q) != 0 {
+		return 0, ErrNotRepresentable
+	}
+	return v, nil
+}
+
+func whole(q resource.Quantity) (int64, error) {
+	v := q.Value()
+	if v >= maxAbs || v <= -maxAbs || resource.NewQuantity(v, q.Format).Cmp(q) != 0 {
+		return 0, ErrNotRepresentable
+	}
+	return v, nil
+}
+
+func canonical(r *resources.Resources) (out [3]int64, err error) {
+	if out[0], err = milli(r.CPU); err != nil {
+		return
+	}
+	if out[1], err = whole(r.Memory); err != nil {
+		return
+	}
+	out[2], err = whole(r.NvidiaGPU)
+	return
+}
+
+// Context owns one gf_ctx (one MI355X).  Created right after SelectBinpacker (cmd/server.go:145), destroyed in the
+// server's cleanup func.
+type Context struct {
+	mu  sync.Mutex // snapshot+orders+fit must not interleave between goroutines (Predicate vs UnschedulablePodMarker)
+	ctx *C.gf_ctx
+}
+
+func New(device int) (*Context, error) {
+	var h *C.gf_ctx
+	id := C.int(device)
+	if rc := C.gf_init(&id, 1, &h); rc != C.GF_OK {
+		return nil, fmt.Errorf("gf_init: %d", int(rc))
+	}
+	return &Context{ctx: h}, nil
+}
+
+func (c *Context) Close() {
+	if c.ctx != nil {
+		C.gf_destroy(c.ctx)
+		c.ctx = nil
+	}
+}
+
+func (c *Context) err(rc C.int) error {
+	return fmt.Errorf("libgangfit %d: %s", int(rc), C.GoString(C.gf_last_error(c.ctx)))
+}
+
+// App is one pending application (types.SparkApplicationResources + the FIFO skip flag).
+type App struct {
+	Driver, Executor *resources.Resources
+	ExecutorCount    int  // MinExecutorCount (resource.go:242,325)
+	Skippable        bool // shouldSkipDriverFifo(driver, instanceGroup) (resource.go:264-270)
+}
+
+// Result mirrors binpack.PackingResult without the efficiency map.
+type Result struct {
+	HasCapacity   bool
+	DriverNode    string
+	ExecutorNodes []string
+	Evaluated     bool
+}
+
+// table flattens nodesSchedulingMetadata + the two priority orders into the dense-index form of the C ABI.
+type table struct {
+	names        []string
+	index        map[string]uint32
+	avail, sched [3][]int64
+	dOrder       []uint32
+	xOrder       []uint32
+}
+
+func flatten(meta resources.NodeGroupSchedulingMetadata, driverOrder, execOrder []string) (*table, error) {
+	t := &table{index: make(map[string]uint32, len(meta))}
+	for name, m := range meta {
+		a, err := canonical(m.AvailableResources)
+		if err != nil {
+			return nil, err
+		}
+		s := [3]int64{math.MaxInt64 >> 2, math.MaxInt64 >> 2, math.MaxInt64 >> 2}
+		if m.SchedulableResources != nil {
+			if s2, err := canonical(m.SchedulableResources); err == nil {
+				s = s2
+			}
+		}
+		t.index[name] = uint32(len(t.names))
+		t.names = append(t.names, name)
+		for j := 0; j < 3; j++ {
+			t.avail[j] = append(t.avail[j], a[j])
+			t.sched[j] = append(t.sched[j], s[j])
+		}
+	}
+	unknown := uint32(len(t.names)) // a name that is not a key of the metadata map: index >= n_nodes
+	conv := func(order []string) []uint32 {
+		out := make([]uint32, len(order))
+		for i, n := range order {
+			if ix, ok := t.index[n]; ok {
+				out[i] = ix
+			} else {
+				out[i] = unknown
+				unknown++
+			}
+		}
+		return out
+	}
+	t.dOrder, t.xOrder = conv(driverOrder), conv(execOrder)
+	return t, nil
+}
+
+func p64(s []int64) *C.int64_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.int64_t)(unsafe.Pointer(&s[0]))
+}
+func p32(s []uint32) *C.uint32_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint32_t)(unsafe.Pointer(&s[0]))
+}
+
+// FitBatch is the batched replacement of the BinpackFunc call sites: mode GF_MODE_FIFO_CHAIN for
+// fitEarlierDrivers + the final pack (resource.go:309-328), GF_MODE_INDEPENDENT for the unschedulable-pod scan
+// (unschedulablepods.go:93-166).  failedAt is the index of the earlier driver that aborts the chain or -1.
+func (c *Context) FitBatch(fifo bool, algo int, apps []App, driverOrder, execOrder []string,
+	meta resources.NodeGroupSchedulingMetadata) (results []Result, failedAt int, err error) {
+	t, err := flatten(meta, driverOrder, execOrder)
+	if err != nil {
+		return nil, -1, err
+	}
+	capps := make([]C.gf_app, len(apps))
+	total := 0
+	for i, a := range apps {
+		d, err := canonical(a.Driver)
+		if err != nil {
+			return nil, -1, err
+		}
+		e, err := canonical(a.Executor)
+		if err != nil {
+			return nil, -1, err
+		}
+		if a.ExecutorCount < 0 || a.ExecutorCount > C.GF_MAX_K {
+			return nil, -1, ErrNotRepresentable
+		}
+		for j := 0; j < 3; j++ {
+			capps[i].drv[j], capps[i].exe[j] = C.int64_t(d[j]), C.int64_t(e[j])
+		}
+		capps[i].k = C.int32_t(a.ExecutorCount)
+		if a.Skippable {
+			capps[i].flags = C.GF_APP_SKIPPABLE
+		}
+		total += a.ExecutorCount
+	}
+	cres := make([]C.gf_result, len(apps))
+	execNodes := make([]uint32, total+1)
+	var failed C.int32_t = -1
+	mode := C.gf_mode(C.GF_MODE_INDEPENDENT)
+	if fifo {
+		mode = C.GF_MODE_FIFO_CHAIN
+	}
+
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	if rc := C.gf_snapshot_set(c.ctx, C.uint32_t(len(t.names)), p64(t.avail[0]), p64(t.avail[1]), p64(t.avail[2]),
+		p64(t.sched[0]), p64(t.sched[1]), p64(t.sched[2])); rc != C.GF_OK {
+		return nil, -1, c.err(rc)
+	}
+	if rc := C.gf_orders_set(c.ctx, p32(t.dOrder), C.uint32_t(len(t.dOrder)), p32(t.xOrder), C.uint32_t(len(t.xOrder))); rc != C.GF_OK {
+		return nil, -1, c.err(rc)
+	}
+	var pa *C.gf_app
+	var pr *C.gf_result
+	if len(apps) > 0 {
+		pa, pr = &capps[0], &cres[0]
+	}
+	if rc := C.gf_fit_batch(c.ctx, mode, C.gf_algo(algo), C.uint32_t(len(apps)), pa, pr, p32(execNodes),
+		C.uint64_t(total), &failed); rc != C.GF_OK {
+		return nil, -1, c.err(rc)
+	}
+	results = make([]Result, len(apps))
+	off := 0
+	for i := range apps {
+		r := &results[i]
+		r.Evaluated = cres[i].evaluated != 0
+		r.HasCapacity = cres[i].has_capacity != 0
+		r.ExecutorNodes = make([]string, 0, int(cres[i].exec_len))
+		if r.HasCapacity {
+			r.DriverNode = t.names[cres[i].driver_node]
+			for _, ix := range execNodes[off : off+int(cres[i].exec_len)] {
+				r.ExecutorNodes = append(r.ExecutorNodes, t.names[ix])
+			}
+		}
+		off += apps[i].ExecutorCount
+	}
+	return results, int(failed), nil
+}
+
+// SparkBinPackFunction returns a binpack.SparkBinPackFunction (LIB/binpack/binpack.go:43-48) served by the device,
+// with `fallback` (binpack.TightlyPack / binpack.DistributeEvenly) taking over on ANY accelerator error so that Filter
+// semantics never change.  PackingEfficiencies are recomputed on the host exactly like binpack.go:77.
+func (c *Context) SparkBinPackFunction(algo int, fallback binpack.SparkBinPackFunction) binpack.SparkBinPackFunction {
+	return func(ctx context.Context, driverResources, executorResources *resources.Resources, executorCount int,
+		driverNodePriorityOrder, executorNodePriorityOrder []string,
+		nodesSchedulingMetadata resources.NodeGroupSchedulingMetadata) *binpack.PackingResult {
+		res, _, err := c.FitBatch(false, algo, []App{{driverResources, executorResources, executorCount, false}},
+			driverNodePriorityOrder, executorNodePriorityOrder, nodesSchedulingMetadata)
+		if err != nil {
+			return fallback(ctx, driverResources, executorResources, executorCount, driverNodePriorityOrder,
+				executorNodePriorityOrder, nodesSchedulingMetadata)
+		}
+		if !res[0].HasCapacity {
+			return binpack.EmptyPackingResult()
+		}
+		reserved := make(resources.NodeGroupResources, len(res[0].ExecutorNodes)+1)
+		reserved[res[0].DriverNode] = driverResources.Copy()
+		for _, n := range res[0].ExecutorNodes {
+			if reserved[n] == nil {
+				reserved[n] = resources.Zero()
+			}
+			reserved[n].Add(executorResources)
+		}
+		return &binpack.PackingResult{
+			DriverNode:          res[0].DriverNode,
+			ExecutorNodes:       res[0].ExecutorNodes,
+			HasCapacity:         true,
+			PackingEfficiencies: binpack.ComputePackingEfficiencies(nodesSchedulingMetadata, reserved),
+		}
+	}
+}
