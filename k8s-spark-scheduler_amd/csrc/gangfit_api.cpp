@@ -100,7 +100,20 @@ struct gf_ctx {
     PinnedBuf<uint32_t> h_index;
     bool work_valid = false;
     bool d_identity = false;
-    uint32_t x_skip = 0, d_skip = 0;  // dead prefixes of the two orders (see NodeTable)
+    bool merged = false;       // slot space is the merged order (see NodeTable)
+    DeviceBuf<uint64_t> d_masks;  // xmask | dmask, n_chunks each
+    PinnedBuf<uint64_t> h_masks;
+    DeviceBuf<gangfit::DevApp> d_dev_apps;  // FIFO chain: app records with reciprocals (prepare_apps_kernel)
+    DeviceBuf<gangfit::NApp> d_napps;       // the same in the narrow domain
+    DeviceBuf<int32_t> d_wide_needed;       // set by prepare_apps_kernel when a request has no narrow form
+    // narrow (scaled int32) form of the table: value = scaled * unit[dim]; exists when every |value / unit| < 2^30
+    bool narrow_ok = false;
+    int64_t unit[3] = {1, 1, 1};
+    DeviceBuf<int32_t> d_nsnap, d_nwork, d_ncmax;
+    PinnedBuf<int32_t> h_ntable;
+    // GANGFIT_FIFO_KERNEL: "narrow" (default: narrow first, v2 as its wide fallback), "fused" (wide fused only),
+    // "v2" (general-layout kernel only), "narrow+fused" (narrow first, wide fused as the fallback)
+    bool fifo_use_narrow = true, fifo_wide_fused = false;
     int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
@@ -150,8 +163,8 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     t.n_slots = ctx->n_slots;
     t.n_nodes = ctx->n_nodes;
     t.d_identity = ctx->d_identity ? 1u : 0u;
-    t.x_skip = ctx->x_skip;
-    t.d_skip = ctx->d_skip;
+    t.xmask = ctx->d_masks.ptr;
+    t.dmask = ctx->d_masks.ptr + ctx->n_chunks;
     return t;
 }
 
@@ -171,14 +184,37 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
-        // as much of the table front as fits next to the kernel's fixed LDS needs stays in LDS for the whole chain
-        const size_t fixed = gangfit::fifo_fixed_lds_bytes(ctx->fifo_waves) + 25 * (size_t)ctx->n_chunks + 16;
-        uint32_t lds_slots = ctx->lds_budget > fixed ? (uint32_t)((ctx->lds_budget - fixed) / 24) : 0;
-        lds_slots &= ~63u;
-        if (lds_slots > ctx->n_slots) lds_slots = ctx->n_slots;
-        GF_HIP(ctx, gangfit::launch_fit_fifo_chain(algo, ctx->fifo_waves, make_table(ctx, ctx->d_work.ptr), lds_slots,
-                                                   n_apps, d_apps, d_results, d_exec_nodes, ctx->d_scratch.ptr, half,
-                                                   d_failed, stats, stream));
+        // as much of the table front as fits next to each kernel's fixed LDS needs stays in LDS for the whole chain
+        gangfit::FifoPlan plan{};
+        plan.n_waves = ctx->fifo_waves;
+        plan.narrow = ctx->merged && ctx->narrow_ok && ctx->fifo_use_narrow;
+        plan.wide_fused = ctx->merged && ctx->fifo_wide_fused;
+        const uint32_t block = 64u * (uint32_t)(ctx->fifo_waves <= 4 ? 4 : (ctx->fifo_waves <= 8 ? 8 : 16));
+        auto front = [&](size_t fixed, size_t per_slot, uint32_t round) {
+            uint32_t n = ctx->lds_budget > fixed ? (uint32_t)((ctx->lds_budget - fixed) / per_slot) : 0;
+            const uint32_t whole = (ctx->n_slots + round - 1) / round * round;  // the whole table, padded to full steps
+            if (n >= whole) return whole;
+            return n / round * round;
+        };
+        plan.lds_slots_v2 = front(gangfit::fifo_v2_lds_bytes(0, ctx->n_chunks), 24, 64);
+        if (plan.lds_slots_v2 > ctx->n_slots) plan.lds_slots_v2 = ctx->n_slots;
+        plan.lds_slots_fused = front(gangfit::fifo_fused_lds_bytes(0, ctx->n_chunks), 24, block);
+        plan.lds_slots_narrow = front(gangfit::fifo_narrow_lds_bytes(0, ctx->n_chunks), 12, block);
+        gangfit::NarrowTable nt{};
+        if (plan.narrow) {
+            GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
+                                       hipMemcpyDeviceToDevice, stream));
+            nt.cpu = ctx->d_nwork.ptr;
+            nt.mem = nt.cpu + ctx->n_slots;
+            nt.gpu = nt.mem + ctx->n_slots;
+            nt.cmax = ctx->d_ncmax.ptr;
+            for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+        }
+        if (plan.wide_fused) GF_HIP(ctx, ctx->d_dev_apps.reserve(n_apps));
+        GF_HIP(ctx, gangfit::launch_fit_fifo(algo, plan, make_table(ctx, ctx->d_work.ptr), nt, n_apps, d_apps,
+                                             ctx->d_dev_apps.ptr, ctx->d_napps.ptr, ctx->d_wide_needed.ptr, d_results,
+                                             d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, stats, stream));
     } else {
         return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
     }
@@ -217,7 +253,11 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     ctx->lds_budget = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
     if (const char* w = std::getenv("GANGFIT_FIFO_WAVES")) {
         const int v = std::atoi(w);
-        if (v == 1 || v == 4 || v == 16) ctx->fifo_waves = v;
+        if (v == 1 || v == 4 || v == 8 || v == 16) ctx->fifo_waves = v;
+    }
+    if (const char* k = std::getenv("GANGFIT_FIFO_KERNEL")) {
+        ctx->fifo_use_narrow = std::strncmp(k, "narrow", 6) == 0;
+        ctx->fifo_wide_fused = std::strstr(k, "fused") != nullptr;
     }
     if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
         const long v = std::atol(l);
@@ -230,6 +270,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess ||
         ctx->d_stats.reserve(1) != hipSuccess || ctx->d_failed.reserve(1) != hipSuccess ||
+        ctx->d_wide_needed.reserve(1) != hipSuccess ||
         ctx->h_failed.reserve(1) != hipSuccess ||
         hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)) != hipSuccess) {
         gf_destroy(ctx);
@@ -249,6 +290,15 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_dslot.release();
     ctx->d_node_slot.release();
     ctx->d_cmax.release();
+    ctx->d_masks.release();
+    ctx->h_masks.release();
+    ctx->d_dev_apps.release();
+    ctx->d_napps.release();
+    ctx->d_wide_needed.release();
+    ctx->d_nsnap.release();
+    ctx->d_nwork.release();
+    ctx->d_ncmax.release();
+    ctx->h_ntable.release();
     ctx->h_cmax.release();
     ctx->d_apps.release();
     ctx->d_results.release();
@@ -315,36 +365,98 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     const uint32_t n_nodes = ctx->n_nodes;
     std::vector<uint32_t>& node_slot = ctx->h_node_slot;
     node_slot.assign(n_nodes, GF_NO_NODE);
+    // ---- positions of the known nodes in the two orders.  Unknown names (index >= n_nodes) never host anything
+    //      (binpack.go:68, pack_tightly.go:51, distribute_evenly.go:59) and a repeated driver candidate can only repeat
+    //      the failure of its first occurrence, so both are dropped from the slot space without changing any result.
+    std::vector<uint32_t> xpos(n_nodes, GF_NO_NODE), dpos(n_nodes, GF_NO_NODE);
+    std::vector<uint32_t> xs, ds;
+    xs.reserve(n_x);
+    ds.reserve(n_d);
     for (uint32_t i = 0; i < n_x; ++i) {
         const uint32_t n = exec_order[i];
         if (n >= n_nodes) continue;
-        if (node_slot[n] != GF_NO_NODE)
+        if (xpos[n] != GF_NO_NODE)
             return fail(ctx, GF_ERR_INVALID, "node %u appears twice in the executor priority order", n);
-        node_slot[n] = i;
+        xpos[n] = (uint32_t)xs.size();
+        xs.push_back(n);
     }
-    uint32_t extra = 0;
+    bool d_has_unknown_or_dup = false;
     for (uint32_t i = 0; i < n_d; ++i) {
         const uint32_t n = driver_order[i];
-        if (n < n_nodes && node_slot[n] == GF_NO_NODE) node_slot[n] = n_x + extra++;
+        if (n >= n_nodes || dpos[n] != GF_NO_NODE) {
+            d_has_unknown_or_dup = true;
+            continue;
+        }
+        dpos[n] = (uint32_t)ds.size();
+        ds.push_back(n);
     }
-    const uint64_t n_slots64 = (uint64_t)n_x + extra + 1;
-    if (n_slots64 >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "order vectors too long");
-    const uint32_t n_slots = (uint32_t)n_slots64;
+    (void)d_has_unknown_or_dup;
+    // ---- merged layout: one order that has both (cleaned) orders as subsequences, if it exists
+    std::vector<uint32_t> merged;
+    std::vector<uint8_t> mflags;  // bit 0: executor candidate, bit 1: driver candidate
+    bool mergeable = std::getenv("GANGFIT_FORCE_GENERAL_LAYOUT") == nullptr;
+    if (mergeable) {
+        merged.reserve(xs.size() + ds.size());
+        size_t i = 0, j = 0;
+        while (i < ds.size() || j < xs.size()) {
+            if (i < ds.size() && j < xs.size() && ds[i] == xs[j]) {
+                merged.push_back(ds[i]);
+                mflags.push_back(3);
+                ++i;
+                ++j;
+            } else if (i < ds.size() && xpos[ds[i]] == GF_NO_NODE) {
+                merged.push_back(ds[i++]);
+                mflags.push_back(2);
+            } else if (j < xs.size() && dpos[xs[j]] == GF_NO_NODE) {
+                merged.push_back(xs[j++]);
+                mflags.push_back(1);
+            } else {  // two nodes present in both orders, in opposite relative order
+                mergeable = false;
+                break;
+            }
+        }
+    }
+    uint32_t n_slots, n_x_slots, n_d_pos;
+    if (mergeable) {
+        n_x_slots = n_d_pos = (uint32_t)merged.size();
+        const uint64_t n_slots64 = (uint64_t)merged.size() + 1;
+        if (n_slots64 >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "order vectors too long");
+        n_slots = (uint32_t)n_slots64;
+        for (uint32_t sl = 0; sl < merged.size(); ++sl) node_slot[merged[sl]] = sl;
+    } else {
+        // general layout: executor order (with its unknown names, which stay empty slots), then driver-only nodes
+        for (uint32_t i = 0; i < n_x; ++i)
+            if (exec_order[i] < n_nodes) node_slot[exec_order[i]] = i;
+        uint32_t extra = 0;
+        for (uint32_t i = 0; i < n_d; ++i) {
+            const uint32_t n = driver_order[i];
+            if (n < n_nodes && node_slot[n] == GF_NO_NODE) node_slot[n] = n_x + extra++;
+        }
+        const uint64_t n_slots64 = (uint64_t)n_x + extra + 1;
+        if (n_slots64 >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "order vectors too long");
+        n_slots = (uint32_t)n_slots64;
+        n_x_slots = n_x;
+        n_d_pos = n_d;
+    }
     const uint32_t sentinel = n_slots - 1;
+    const uint32_t n_chunks = (n_slots + 63) / 64;
 
     GF_HIP(ctx, ctx->h_table.reserve(3 * (size_t)n_slots));
-    GF_HIP(ctx, ctx->h_index.reserve((size_t)n_slots + n_d + n_nodes + 1));
+    GF_HIP(ctx, ctx->h_index.reserve((size_t)n_slots + n_d_pos + n_nodes + 1));
+    GF_HIP(ctx, ctx->h_masks.reserve(2 * (size_t)n_chunks));
     int64_t* tcpu = ctx->h_table.ptr;
     int64_t* tmem = tcpu + n_slots;
     int64_t* tgpu = tmem + n_slots;
     uint32_t* slot_node = ctx->h_index.ptr;
     uint32_t* dslot = slot_node + n_slots;
-    uint32_t* nslot = dslot + n_d;
+    uint32_t* nslot = dslot + n_d_pos;
+    uint64_t* xmask = ctx->h_masks.ptr;
+    uint64_t* dmask = xmask + n_chunks;
     for (uint32_t s = 0; s < n_slots; ++s) {
         tcpu[s] = tmem[s] = tgpu[s] = kSentinelAvail;
         slot_node[s] = GF_NO_NODE;
     }
-    for (uint32_t i = 0; i < n_x; ++i) slot_node[i] = exec_order[i];  // unknown names keep their raw index; never emitted
+    for (uint32_t c = 0; c < n_chunks; ++c) xmask[c] = dmask[c] = 0;
     for (uint32_t n = 0; n < n_nodes; ++n) {
         const uint32_t s = node_slot[n];
         nslot[n] = s;
@@ -355,24 +467,25 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         tgpu[s] = ctx->avail[2][n];
     }
     bool identity = true;
-    for (uint32_t i = 0; i < n_d; ++i) {
-        const uint32_t n = driver_order[i];
-        dslot[i] = n < n_nodes ? node_slot[n] : sentinel;
-        identity = identity && dslot[i] == i;
+    if (mergeable) {
+        for (uint32_t s = 0; s < merged.size(); ++s) {
+            dslot[s] = s;
+            if (mflags[s] & 1) xmask[s >> 6] |= 1ull << (s & 63);
+            if (mflags[s] & 2) dmask[s >> 6] |= 1ull << (s & 63);
+        }
+    } else {
+        for (uint32_t i = 0; i < n_d; ++i) {
+            const uint32_t n = driver_order[i];
+            dslot[i] = n < n_nodes ? node_slot[n] : sentinel;
+        }
+        identity = false;
+        for (uint32_t i = 0; i < n_x; ++i)
+            if (exec_order[i] < n_nodes) xmask[i >> 6] |= 1ull << (i & 63);
+        for (uint32_t c = 0; c < n_chunks; ++c) dmask[c] = ~0ull;  // not consulted: positions go through dslot[]
     }
     ctx->d_identity = identity;
-    // Dead prefix: a slot with any negative component has capacity 0 for every app (cap_dim: a < 0 -> 0) and fails
-    // every driver-fit check (requests are >= 0); FIFO commits only ever subtract, so it stays dead for the whole
-    // chain.  The reference's priority order (least free memory first) puts overcommitted nodes right at the front.
-    auto dead = [&](uint32_t s) { return tcpu[s] < 0 || tmem[s] < 0 || tgpu[s] < 0; };
-    uint32_t xs = 0, dsk = 0;
-    while (xs < n_x && dead(xs)) ++xs;
-    while (dsk < n_d && dead(dslot[dsk])) ++dsk;
-    ctx->x_skip = xs;
-    ctx->d_skip = dsk;
 
     // chunk-maxima index over all slots (see NodeTable::cmax)
-    const uint32_t n_chunks = (n_slots + 63) / 64;
     GF_HIP(ctx, ctx->h_cmax.reserve(3 * (size_t)n_chunks));
     {
         const int64_t* cols[3] = {tcpu, tmem, tgpu};
@@ -384,30 +497,83 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
                 ctx->h_cmax.ptr[(size_t)j * n_chunks + c] = m;
             }
     }
+    // narrow form: unit[j] = gcd of dimension j over the real slots; scaled magnitudes must stay below 2^30
+    {
+        const int64_t* cols[3] = {tcpu, tmem, tgpu};
+        bool ok = true;
+        for (int j = 0; j < 3; ++j) {
+            uint64_t g = 0;
+            for (uint32_t s2 = 0; s2 + 1 < n_slots; ++s2) {
+                if (slot_node[s2] == GF_NO_NODE) continue;
+                uint64_t v = (uint64_t)(cols[j][s2] < 0 ? -cols[j][s2] : cols[j][s2]);
+                while (v) {  // Euclid
+                    const uint64_t t = g % v;
+                    g = v;
+                    v = t;
+                }
+                if (g == 1) break;
+            }
+            ctx->unit[j] = g ? (int64_t)g : 1;
+        }
+        GF_HIP(ctx, ctx->h_ntable.reserve(3 * (size_t)n_slots + 3 * (size_t)n_chunks));
+        int32_t* nt = ctx->h_ntable.ptr;
+        int32_t* ncm = nt + 3 * (size_t)n_slots;
+        for (int j = 0; j < 3 && ok; ++j) {
+            for (uint32_t c = 0; c < n_chunks; ++c) ncm[(size_t)j * n_chunks + c] = INT32_MIN;
+            for (uint32_t s2 = 0; s2 < n_slots; ++s2) {
+                int32_t v32 = INT32_MIN / 2;  // sentinel / empty slot: never fits, never hosts
+                if (s2 + 1 < n_slots && slot_node[s2] != GF_NO_NODE) {
+                    const int64_t q = cols[j][s2] / ctx->unit[j];
+                    if (q >= (INT64_C(1) << 30) || q <= -(INT64_C(1) << 30)) {
+                        ok = false;
+                        break;
+                    }
+                    v32 = (int32_t)q;
+                }
+                nt[(size_t)j * n_slots + s2] = v32;
+                int32_t& m = ncm[(size_t)j * n_chunks + (s2 >> 6)];
+                m = v32 > m ? v32 : m;
+            }
+        }
+        ctx->narrow_ok = ok;
+    }
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still read the old tables
+    if (ctx->narrow_ok) {
+        GF_HIP(ctx, ctx->d_nsnap.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_nwork.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_ncmax.reserve(3 * (size_t)n_chunks));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nsnap.ptr, ctx->h_ntable.ptr, 3 * (size_t)n_slots * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, ctx->stream));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_ncmax.ptr, ctx->h_ntable.ptr + 3 * (size_t)n_slots,
+                                   3 * (size_t)n_chunks * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
     GF_HIP(ctx, ctx->d_cmax.reserve(3 * (size_t)n_chunks));
     GF_HIP(ctx, hipMemcpyAsync(ctx->d_cmax.ptr, ctx->h_cmax.ptr, 3 * (size_t)n_chunks * sizeof(int64_t),
                                hipMemcpyHostToDevice, ctx->stream));
     ctx->n_chunks = n_chunks;
+    GF_HIP(ctx, ctx->d_masks.reserve(2 * (size_t)n_chunks));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_masks.ptr, ctx->h_masks.ptr, 2 * (size_t)n_chunks * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, ctx->stream));
     GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));
     GF_HIP(ctx, ctx->d_work.reserve(3 * (size_t)n_slots));
     GF_HIP(ctx, ctx->d_slot_node.reserve(n_slots));
-    GF_HIP(ctx, ctx->d_dslot.reserve(n_d + 1));
+    GF_HIP(ctx, ctx->d_dslot.reserve(n_d_pos + 1));
     GF_HIP(ctx, ctx->d_node_slot.reserve(n_nodes + 1));
     GF_HIP(ctx, hipMemcpyAsync(ctx->d_snap.ptr, tcpu, 3 * (size_t)n_slots * sizeof(int64_t), hipMemcpyHostToDevice,
                                ctx->stream));
     GF_HIP(ctx, hipMemcpyAsync(ctx->d_slot_node.ptr, slot_node, (size_t)n_slots * sizeof(uint32_t),
                                hipMemcpyHostToDevice, ctx->stream));
-    if (n_d)
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_dslot.ptr, dslot, (size_t)n_d * sizeof(uint32_t), hipMemcpyHostToDevice,
+    if (n_d_pos)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_dslot.ptr, dslot, (size_t)n_d_pos * sizeof(uint32_t), hipMemcpyHostToDevice,
                                    ctx->stream));
     if (n_nodes)
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_node_slot.ptr, nslot, (size_t)n_nodes * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, ctx->stream));
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->n_x = n_x;
-    ctx->n_d = n_d;
+    ctx->n_x = n_x_slots;
+    ctx->n_d = n_d_pos;
     ctx->n_slots = n_slots;
+    ctx->merged = mergeable;
     ctx->have_orders = true;
     ctx->work_valid = false;
     return GF_OK;

@@ -9,31 +9,71 @@
 
 namespace gangfit {
 
-// The node table as the kernels see it.  "Slot" space: slots [0, n_x) are the executor priority order
-// (executorNodePriorityOrder, already permuted so that a wave scanning slots b..b+63 issues three coalesced
-// 512-byte loads); slots [n_x, n_slots-1) hold driver candidates that are not executor candidates; the last slot
-// is a sentinel (available = -2^62) that every unknown node name maps to.  SoA, int64, one array per dimension.
+// The node table as the kernels see it, in "slot" space.  SoA, int64, one array per dimension; a wave scanning slots
+// b..b+63 issues three coalesced 512-byte loads.  Two layouts (gf_orders_set picks one):
+//   merged  — driverNodePriorityOrder and executorNodePriorityOrder are subsequences of one common order (they both
+//             derive from getNodeNamesInPriorityOrder, internal/sort/nodesorting.go:41-64, so this is the production
+//             shape): slots [0, n_x) are that common order, n_d == n_x, driver position == slot (d_identity), and the
+//             per-chunk bit masks say which slots are driver / executor candidates.
+//   general — the two orders disagree (different label-priority re-sorts for drivers and executors): slots [0, n_x)
+//             are the executor order, driver-only nodes follow, dslot[] maps driver positions to slots.
+// The last slot is a sentinel (available = -2^62) that unknown node names map to.
 struct NodeTable {
     int64_t* cpu;  // milli-cores   [n_slots]
     int64_t* mem;  // bytes         [n_slots]
     int64_t* gpu;  // devices       [n_slots]
     const uint32_t* slot_node;  // [n_slots] slot -> caller's node index (what is written to exec_nodes)
-    const uint32_t* dslot;      // [n_d]     position in driverNodePriorityOrder -> slot
+    const uint32_t* dslot;      // [n_d]     position in driverNodePriorityOrder -> slot (general layout only)
     const uint32_t* node_slot;  // [n_nodes] caller's node index -> slot
     // Chunk-maxima index: cmax[d * n_chunks + c] = max over slots [64c, 64c+64) of dimension d, taken on the SNAPSHOT.
     // Upper bounds stay valid while a FIFO chain subtracts, so "cmax < request in some dimension" proves that no slot
     // of the chunk can host the request: the scans skip such chunks without loading them.  The reference's priority
     // order (least free memory first) makes this skip the whole front of the order for large executors.
     const int64_t* cmax;        // [3][n_chunks]
+    const uint64_t* xmask;      // [n_chunks] bit l of xmask[c]: slot 64c+l is an executor candidate
+    const uint64_t* dmask;      // [n_chunks] bit l of dmask[c]: slot 64c+l is a driver candidate (merged layout)
     uint32_t n_chunks;          // ceil(n_slots / 64)
-    uint32_t n_x;
-    uint32_t n_d;
+    uint32_t n_x;               // slots scanned by the executor packers
+    uint32_t n_d;               // driver candidates (positions)
     uint32_t n_slots;
     uint32_t n_nodes;
-    uint32_t d_identity;  // 1 when dslot[i] == i for all i (driver order is a prefix of the executor order)
-    uint32_t x_skip;      // leading executor-order slots with a negative component (dead for every app: cap == 0)
-    uint32_t d_skip;      // leading driver-order positions that sit on dead slots / unknown nodes
+    uint32_t d_identity;        // 1: driver position == slot (merged layout)
 };
+
+// App record as the FIFO-chain kernel consumes it: gf_app + the per-dimension reciprocals of the executor request
+// (prepare_apps_kernel computes them once per launch).  128 bytes = 8 lanes x 16 bytes.
+struct DevApp {
+    int64_t drv[3];
+    int64_t exe[3];
+    double rcp[3];
+    int32_t k;
+    uint32_t flags;
+    uint64_t exec_off;
+    uint64_t pad[5];
+};
+static_assert(sizeof(DevApp) == 128, "DevApp must be 128 bytes");
+
+// Narrow (scaled int32) domain of the FIFO chain — see gangfit_fifo_narrow.inc.
+struct NApp {  // 64 bytes, produced by prepare_apps_kernel: requests divided by the table's units
+    int32_t drv[3];
+    int32_t k;
+    int32_t exe[3];  // >= 0
+    uint32_t flags;
+    float rcp[3];    // 1.0f / exe (0 when exe == 0)
+    float kf1;       // (float)(k + 1)
+    uint64_t exec_off;
+    uint64_t pad;
+};
+static_assert(sizeof(NApp) == 64, "NApp must be 64 bytes");
+
+struct NarrowTable {  // value = scaled value * unit[dimension]
+    int32_t* cpu;  // [n_slots] working copy, scaled
+    int32_t* mem;
+    int32_t* gpu;
+    const int32_t* cmax;  // [3][n_chunks] scaled chunk maxima of the snapshot
+    int64_t unit[3];
+};
+
 
 // Kernel-visible counters used by tests/bench to report visited bytes honestly (SURVEY.md section 8d
 // "early-exit note").  One uint64 pair per launch, accumulated with a single atomic per app.
@@ -50,13 +90,27 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
                                   gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
 
-// FIFO chain: one workgroup of n_waves (1, 4 or 16) wavefronts; the first lds_slots slots of the working table are
-// kept in LDS (24 bytes per slot + fifo_fixed_lds_bytes).  Followed by the slot->node translation kernel.
-size_t fifo_fixed_lds_bytes(int n_waves);
-hipError_t launch_fit_fifo_chain(gf_algo algo, int n_waves, const NodeTable& table, uint32_t lds_slots,
-                                 uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
-                                 uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
-                                 ScanStats* d_stats, hipStream_t stream);
+// FIFO chain (fitEarlierDrivers + final pack).  One workgroup walks the chain; three kernels:
+//   v2     (gangfit_kernels.hip)      — any layout, wide (int64) table, separate driver / executor scans
+//   fused  (gangfit_fifo_fused.inc)   — merged layout, wide table, fused scan
+//   narrow (gangfit_fifo_narrow.inc)  — merged layout, scaled int32 table: the fast path; when a request of the batch is not
+//                                       representable it returns at once and the wide kernel (guarded the other way) runs
+// followed by expand_translate_kernel (run heads -> placement list, slot ids -> node indices).
+struct FifoPlan {
+    int n_waves;                // wavefronts of the workgroup (1 / 4 / 16 for v2; 4 / 8 / 16 for fused and narrow)
+    bool narrow;                // launch the narrow kernel first (merged layout and the table has a narrow form)
+    bool wide_fused;            // wide kernel = fused instead of v2 (merged layout only)
+    uint32_t lds_slots_v2;      // table slots each kernel keeps in LDS
+    uint32_t lds_slots_fused;
+    uint32_t lds_slots_narrow;
+};
+size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
+size_t fifo_fused_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
+size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
+hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
+                           uint32_t n_apps, const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps,
+                           int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                           uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream);
 
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
 // Writes the number of mismatching lanes/cases to *d_mismatch.

@@ -197,11 +197,17 @@ struct GlobalView {
     const int64_t* cmax_cpu;  // per-64-slot-chunk maxima of each dimension (upper bounds; see NodeTable::cmax)
     const int64_t* cmax_mem;
     const int64_t* cmax_gpu;
+    const uint64_t* xm;  // executor-candidate bits per chunk
+    const uint64_t* dm;  // driver-candidate bits per chunk (merged layout)
     uint32_t n_chunks;
     // can ANY slot of chunk c offer r in every dimension?  false => capacity 0 / driver does not fit, for the whole chunk
     __device__ __forceinline__ bool chunk_may_hold(uint32_t c, int64_t r0, int64_t r1, int64_t r2) const {
         return cmax_cpu[c] >= r0 && cmax_mem[c] >= r1 && cmax_gpu[c] >= r2;
     }
+    __device__ __forceinline__ uint64_t chunk_xmask(uint32_t c) const { return xm[c]; }
+    __device__ __forceinline__ uint64_t chunk_dmask(uint32_t c) const { return dm[c]; }
+    __device__ __forceinline__ bool xcand(uint32_t s) const { return (xm[s >> 6] >> (s & 63)) & 1ull; }
+    __device__ __forceinline__ bool dcand(uint32_t s) const { return (dm[s >> 6] >> (s & 63)) & 1ull; }
     __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
         a0 = cpu[s];
         a1 = mem[s];
@@ -220,6 +226,7 @@ struct GlobalView {
 // of a selected address, and every flat access waits on vmcnt(0) — i.e. on all placement stores still in flight.
 typedef __attribute__((address_space(3))) int64_t lds_i64;
 typedef __attribute__((address_space(1))) int64_t glb_i64;
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
 struct HybridView {
     lds_i64* lcpu;  // LDS, SoA: consecutive lanes read consecutive 8-byte words (ds_read_b64, conflict-free)
     lds_i64* lmem;
@@ -231,10 +238,16 @@ struct HybridView {
     lds_i64* cmax_cpu;  // chunk maxima, LDS copy (static upper bounds: the chain only ever subtracts)
     lds_i64* cmax_mem;
     lds_i64* cmax_gpu;
+    lds_u64* xm;  // candidate bit masks, LDS copies
+    lds_u64* dm;
     uint32_t n_chunks;
     __device__ __forceinline__ bool chunk_may_hold(uint32_t c, int64_t r0, int64_t r1, int64_t r2) const {
         return cmax_cpu[c] >= r0 && cmax_mem[c] >= r1 && cmax_gpu[c] >= r2;
     }
+    __device__ __forceinline__ uint64_t chunk_xmask(uint32_t c) const { return xm[c]; }
+    __device__ __forceinline__ uint64_t chunk_dmask(uint32_t c) const { return dm[c]; }
+    __device__ __forceinline__ bool xcand(uint32_t s) const { return (xm[s >> 6] >> (s & 63)) & 1ull; }
+    __device__ __forceinline__ bool dcand(uint32_t s) const { return (dm[s >> 6] >> (s & 63)) & 1ull; }
     __device__ __forceinline__ void load(uint32_t s, int64_t& a0, int64_t& a1, int64_t& a2) const {
         if (s < lds_slots) {
             a0 = lcpu[s];
@@ -277,9 +290,7 @@ struct Orders {
     const uint32_t* dslot;
     uint32_t n_x;
     uint32_t n_d;
-    uint32_t x_skip;  // leading executor-order slots with a negative component: capacity 0 for every app, forever
-    uint32_t d_skip;  // leading driver-order positions on such slots (or on unknown nodes): never pass the fit check
-    bool d_identity;  // dslot[i] == i for every i (driver order == a prefix of the executor order): skip the gather
+    bool d_identity;  // merged layout: driver position == slot, candidates flagged by the dmask bits
     __device__ __forceinline__ uint32_t driver_slot(uint32_t i) const { return d_identity ? i : dslot[i]; }
 };
 
@@ -314,12 +325,14 @@ __device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t w
 // 64-bit mask over chunks [64g, 64g+64): bit set when the chunk may hold request r (every dimension's maximum >= r).
 // A cleared bit is a proof that every slot of the chunk has capacity 0 for an executor of size r (cap_dim: a < e -> 0;
 // reserving the driver only lowers a) resp. fails the driver-fit check for a driver of size r.
-template <class View>
+// DRV selects which candidate mask must be non-empty (driver scan vs executor scan).
+template <bool DRV, class View>
 __device__ __forceinline__ uint64_t chunk_group_mask(const View& V, uint32_t g, uint32_t chunk_limit, int64_t r0,
                                                      int64_t r1, int64_t r2, int lane) {
     const uint32_t c = g * kWave + lane;
     bool ok = false;
-    if (c < chunk_limit) ok = V.chunk_may_hold(c, r0, r1, r2);
+    if (c < chunk_limit)
+        ok = V.chunk_may_hold(c, r0, r1, r2) && (DRV ? V.chunk_dmask(c) : V.chunk_xmask(c)) != 0;
     return __ballot(ok);
 }
 
@@ -330,14 +343,14 @@ __device__ __forceinline__ int64_t wave_first_fitting_driver(const View& V, cons
     if (O.d_identity) {  // position == slot: prune whole chunks with the maxima index
         const uint32_t dc = (O.n_d + kWave - 1) / kWave;
         for (uint32_t g = (from / kWave) / kWave; g * kWave < dc; ++g) {
-            uint64_t m = chunk_group_mask(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
+            uint64_t m = chunk_group_mask<true>(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
             visited += kWave;
             while (m) {
                 const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)m) - 1);
                 m &= m - 1;
                 const uint32_t i = c * kWave + lane;
                 bool fit = false;
-                if (i < O.n_d && i >= from) {
+                if (i < O.n_d && i >= from && V.dcand(i)) {
                     int64_t a0, a1, a2;
                     V.load(i, a0, a1, a2);
                     fit = driver_fits(a0, a1, a2, app);
@@ -374,13 +387,13 @@ __device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, cons
     for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool ok = false;
-        if (i < O.n_d) {
+        if (i < O.n_d && (!O.d_identity || V.dcand(i))) {
             const uint32_t s = O.driver_slot(i);
             int64_t a0, a1, a2;
             V.load(s, a0, a1, a2);
             if (driver_fits(a0, a1, a2, app)) {
                 int64_t total = S;
-                if (s < O.n_x) {
+                if (s < O.n_x && V.xcand(s)) {
                     const int32_t c0 = cap3(a0, a1, a2, app);
                     const int32_t cd = cap3(a0 - app.drv0, a1 - app.drv1, a2 - app.drv2, app);
                     total = S - c0 + cd;
@@ -406,14 +419,14 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
     for (uint32_t g = 0; g * kWave < xc; ++g) {
-        uint64_t m = chunk_group_mask(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+        uint64_t m = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
         visited += kWave;
         while (m) {
             const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)m) - 1);
             m &= m - 1;
             const uint32_t j = c * kWave + lane;
             int32_t cp = 0;
-            if (j < O.n_x) {
+            if (j < O.n_x && V.xcand(j)) {
                 int64_t a0, a1, a2;
                 V.load(j, a0, a1, a2);
                 if (j == ds) {
@@ -453,14 +466,14 @@ __device__ __forceinline__ int64_t wave_even_pass1(const View& V, const Orders& 
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
     for (uint32_t g = 0; g * kWave < xc; ++g) {
-        uint64_t cm = chunk_group_mask(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+        uint64_t cm = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
         visited += kWave;
         while (cm) {
             const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)cm) - 1);
             cm &= cm - 1;
             const uint32_t j = c * kWave + lane;
             bool flag = false;
-            if (j < O.n_x) {
+            if (j < O.n_x && V.xcand(j)) {
                 int64_t a0, a1, a2;
                 V.load(j, a0, a1, a2);
                 if (j == ds) {
@@ -568,7 +581,7 @@ __device__ __forceinline__ Decision wave_fallback(const View& V, const Orders& O
     dec.pass1 = 0;
     const int64_t K = app.k;
     int64_t S = S_d;
-    if (ds0 < O.n_x) {  // undo the driver reservation: S = S_d + cap(ds0, 0) - cap(ds0, drv)
+    if (ds0 < O.n_x && V.xcand(ds0)) {  // undo the driver reservation: S = S_d + cap(ds0, 0) - cap(ds0, drv)
         int64_t a0, a1, a2;
         V.load(ds0, a0, a1, a2);
         S = S_d + cap3(a0, a1, a2, app) - cap3(a0 - app.drv0, a1 - app.drv1, a2 - app.drv2, app);
@@ -659,8 +672,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     if (a >= n_apps) return;
     const App app = load_app(apps, a);
-    GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.n_chunks};
-    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, T.d_identity != 0};
+    GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
+                 T.n_chunks};
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
     unsigned long long xvis = 0, dvis = 0;
     const Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off,
                                                               scratch + app.exec_off,
@@ -764,7 +778,8 @@ __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders
     const uint32_t b = step * BLOCK;
     const uint32_t j = b + tid;
     int64_t a0 = -1, a1 = -1, a2 = -1;
-    if (mine && j < O.n_x) {
+    const bool cand = mine && j < O.n_x && V.xcand(j);
+    if (cand) {
         if (LDS_ONLY)
             V.load_lds(j, a0, a1, a2);
         else
@@ -776,7 +791,7 @@ __device__ __forceinline__ void fifo_scan_step(const HybridView& V, const Orders
         }
     }
     st.end = b + BLOCK;
-    const bool ge1 = mine && (j < O.n_x) && cap_ge1(a0, a1, a2, app);
+    const bool ge1 = cand && cap_ge1(a0, a1, a2, app);
     if (ALGO == GF_ALGO_TIGHTLY_PACK) {
         int32_t c = 0;
         if (ge1) c = cap3(a0, a1, a2, app);  // no division for slots (or whole waves) that hold nothing
@@ -813,7 +828,7 @@ __device__ __forceinline__ uint32_t fifo_driver_step(const HybridView& V, const 
     constexpr uint32_t BLOCK = kWave * NW;
     const uint32_t i = step * BLOCK + tid;
     bool fit = false;
-    if (mine && i < O.n_d) {
+    if (mine && i < O.n_d && (!DIDENT || V.dcand(i))) {
         int64_t a0, a1, a2;
         if (LDS_ONLY)
             V.load_lds(i, a0, a1, a2);  // identity mapping: position == slot
@@ -829,7 +844,7 @@ __device__ __forceinline__ uint32_t fifo_driver_step(const HybridView& V, const 
 // FIFO replay (internal/extender/resource.go:224-262 + :321): apps strictly in order, each against the residuals its
 // predecessors left.  ONE workgroup of NW waves: nodes in parallel (NW*64 per step), apps sequential.  The working
 // table's front and the chunk-maxima index live in LDS, so the per-app critical path is LDS latency + a few workgroup
-// barriers instead of global-memory round trips.  Placements are written as SLOT ids (translate_kernel maps them).
+// barriers instead of global-memory round trips.  Placements are written as SLOT ids (expand_translate_kernel maps them).
 // DIDENT: the driver order is a prefix of the executor order (position == slot), the production shape; that
 // instantiation has no driver-slot gather, i.e. no global load anywhere on the per-app fast path.
 template <int ALGO, int NW, bool DIDENT>
@@ -840,10 +855,12 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
                                                                   uint32_t* __restrict__ scratch,
                                                                   uint64_t scratch_half,
                                                                   int32_t* __restrict__ chain_failed_at,
-                                                                  ScanStats* __restrict__ stats) {
+                                                                  ScanStats* __restrict__ stats,
+                                                                  const int32_t* __restrict__ run_if_set) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t BLOCK = kWave * NW;
     constexpr uint32_t STEPS_PER_GROUP = kWave / NW;  // one 64-bit chunk mask covers this many steps
+    if (run_if_set != nullptr && *run_if_set == 0) return;  // the narrow kernel served this launch
     const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
     const int wave = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -855,7 +872,8 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     lds_i64* lmem = lcpu + lds_slots;
     lds_i64* lgpu = lmem + lds_slots;
     lds_i64* lmax = lgpu + lds_slots;  // [3][n_chunks]
-    Exchange* X = reinterpret_cast<Exchange*>(smem + 24 * ((size_t)lds_slots + T.n_chunks));
+    lds_u64* lxm = (lds_u64*)(lmax + 3 * (size_t)T.n_chunks);  // [2][n_chunks] candidate masks
+    Exchange* X = reinterpret_cast<Exchange*>(smem + 24 * ((size_t)lds_slots + T.n_chunks) + 16 * (size_t)T.n_chunks);
     FifoShared* sh = reinterpret_cast<FifoShared*>(X + 1);
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     lds_u8* dirty = (lds_u8*)(sh + 1);  // [n_chunks] chunk touched by a commit since the last maxima refresh
@@ -865,14 +883,18 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         lgpu[s] = T.gpu[s];
     }
     for (uint32_t c = tid; c < 3 * T.n_chunks; c += BLOCK) lmax[c] = T.cmax[c];
-    for (uint32_t c = tid; c < T.n_chunks; c += BLOCK) dirty[c] = 0;
+    for (uint32_t c = tid; c < T.n_chunks; c += BLOCK) {
+        dirty[c] = 0;
+        lxm[c] = T.xmask[c];
+        lxm[T.n_chunks + c] = T.dmask[c];
+    }
     if (tid < 32) {  // exchange entries of waves that do not exist must hold the identity
         X->first[tid >> 4][tid & 15] = kNoPos;
         X->tot[tid >> 4][tid & 15] = 0;
     }
     HybridView V{lcpu, lmem, lgpu, lds_slots, (glb_i64*)T.cpu, (glb_i64*)T.mem, (glb_i64*)T.gpu,
-                 lmax, lmax + T.n_chunks, lmax + 2 * (size_t)T.n_chunks, T.n_chunks};
-    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.x_skip, T.d_skip, DIDENT};
+                 lmax, lmax + T.n_chunks, lmax + 2 * (size_t)T.n_chunks, lxm, lxm + T.n_chunks, T.n_chunks};
+    Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, DIDENT};
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;  // chunks of the executor order
     const uint32_t dc = (O.n_d + kWave - 1) / kWave;  // chunks of the driver order (identity mapping only)
     const uint32_t x_steps = (O.n_x + BLOCK - 1) / BLOCK;
@@ -938,7 +960,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
             for (uint32_t g = 0; g * STEPS_PER_GROUP < d_steps && f == kNoPos; ++g) {
                 uint64_t gm = ~0ull;
                 if (DIDENT) {
-                    gm = chunk_group_mask(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
+                    gm = chunk_group_mask<true>(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
                     dvis += kWave;
                 }
                 for (uint32_t s = 0; s < STEPS_PER_GROUP; ++s) {
@@ -977,7 +999,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
             } else {
                 // ---- (2) executors, BLOCK slots per step, lazy stop, ruled-out steps skipped
                 for (uint32_t g = 0; g * STEPS_PER_GROUP < x_steps && st.taken < K; ++g) {
-                    const uint64_t gm = chunk_group_mask(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+                    const uint64_t gm = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
                     xvis += kWave;
                     for (uint32_t s = 0; s < STEPS_PER_GROUP; ++s) {
                         const uint32_t step = g * STEPS_PER_GROUP + s;
@@ -1038,7 +1060,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
         if (tid == 0) {
             gf_result r;
             r.has_capacity = dec.feasible ? 1 : 0;
-            r.driver_node = dec.feasible ? dec.ds : GF_NO_NODE;  // SLOT id; translate_kernel maps it to the node index
+            r.driver_node = dec.feasible ? dec.ds : GF_NO_NODE;  // SLOT id; expand_translate_kernel maps it to the node index
             r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
             r.evaluated = 1;
             results[a] = r;
@@ -1130,22 +1152,8 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     }
 }
 
-// Placements and driver ids written by the FIFO kernel are SLOT ids; map them to the caller's node indices.
-// One wave per app (only evaluated, feasible apps own valid slices).
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void translate_kernel(const uint32_t* __restrict__ slot_node,
-                                                                         uint32_t n_apps,
-                                                                         const gf_app* __restrict__ apps,
-                                                                         gf_result* __restrict__ results,
-                                                                         uint32_t* __restrict__ exec_nodes) {
-    const int lane = lane_id();
-    const uint32_t a = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (a >= n_apps) return;
-    const gf_result r = results[a];
-    if (!r.evaluated || !r.has_capacity) return;
-    uint32_t* out = exec_nodes + apps[a].exec_off;
-    for (uint32_t i = lane; i < r.exec_len; i += kWave) out[i] = slot_node[out[i]];
-    if (lane == 0) results[a].driver_node = slot_node[r.driver_node];
-}
+#include "gangfit_fifo_fused.inc"
+#include "gangfit_fifo_narrow.inc"
 
 // ------------------------------------------------------------------------------------------------ self-test
 
@@ -1227,72 +1235,141 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
     return hipGetLastError();
 }
 
-size_t fifo_fixed_lds_bytes(int n_waves) {
-    (void)n_waves;
-    return sizeof(Exchange) + sizeof(FifoShared) + 64;
+size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
+    return 24 * ((size_t)lds_slots + n_chunks) + 16 * (size_t)n_chunks + sizeof(Exchange) + sizeof(FifoShared) + 64 +
+           ((n_chunks + 15) & ~15u);
+}
+size_t fifo_fused_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
+    return kFusedStage * sizeof(DevApp) + ((sizeof(FusedShared) + 15) & ~(size_t)15) + 24 * (size_t)lds_slots +
+           40 * (size_t)n_chunks + 16;
+}
+size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
+    return kFusedStage * sizeof(NApp) + ((sizeof(NarrowShared) + 15) & ~(size_t)15) + 12 * (size_t)lds_slots +
+           28 * (size_t)n_chunks + 16;
 }
 
 namespace {
-template <int ALGO, int NW, bool DIDENT>
-hipError_t launch_fifo_d(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
-                         gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
-                         int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
-    const size_t lds = 24 * ((size_t)lds_slots + table.n_chunks) + fifo_fixed_lds_bytes(NW) + ((table.n_chunks + 15) & ~15u);
-    auto kernel = fit_fifo_chain_kernel<ALGO, NW, DIDENT>;
+template <class Kernel, class... Args>
+hipError_t launch_one_workgroup(Kernel kernel, int n_waves, size_t lds, hipStream_t stream, Args... args) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave * NW), lds, stream, table, lds_slots, n_apps, d_apps, d_results,
-                       d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at, d_stats);
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave * n_waves), lds, stream, args...);
     return hipGetLastError();
 }
-template <int ALGO, int NW>
-hipError_t launch_fifo_t(const NodeTable& table, uint32_t lds_slots, uint32_t n_apps, const gf_app* d_apps,
-                         gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
-                         int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
-    if (table.d_identity)
-        return launch_fifo_d<ALGO, NW, true>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
-                                             scratch_half, d_chain_failed_at, d_stats, stream);
-    return launch_fifo_d<ALGO, NW, false>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
-                                          scratch_half, d_chain_failed_at, d_stats, stream);
-}
-template <int ALGO>
-hipError_t launch_fifo_a(int n_waves, const NodeTable& table, uint32_t lds_slots, uint32_t n_apps,
-                         const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                         uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
-    switch (n_waves) {
-    case 1:
-        return launch_fifo_t<ALGO, 1>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
-                                      scratch_half, d_chain_failed_at, d_stats, stream);
-    case 4:
-        return launch_fifo_t<ALGO, 4>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
-                                      scratch_half, d_chain_failed_at, d_stats, stream);
-    default:
-        return launch_fifo_t<ALGO, 16>(table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
-                                       scratch_half, d_chain_failed_at, d_stats, stream);
-    }
-}
-}  // namespace
 
-hipError_t launch_fit_fifo_chain(gf_algo algo, int n_waves, const NodeTable& table, uint32_t lds_slots,
-                                 uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
-                                 uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
-                                 ScanStats* d_stats, hipStream_t stream) {
-    if (n_apps == 0) return hipSuccess;
-    hipError_t e;
-    if (algo == GF_ALGO_TIGHTLY_PACK)
-        e = launch_fifo_a<GF_ALGO_TIGHTLY_PACK>(n_waves, table, lds_slots, n_apps, d_apps, d_results, d_exec_nodes,
-                                                d_scratch, scratch_half, d_chain_failed_at, d_stats, stream);
+template <int ALGO>
+hipError_t launch_v2(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
+                     uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, int32_t* d_failed, ScanStats* d_stats,
+                     const int32_t* guard, hipStream_t stream) {
+    const size_t lds = fifo_v2_lds_bytes(P.lds_slots_v2, T.n_chunks);
+#define GF_V2(NW, DI)                                                                                              \
+    return launch_one_workgroup(fit_fifo_chain_kernel<ALGO, NW, DI>, NW, lds, stream, T, P.lds_slots_v2, n_apps, d_apps, \
+                                d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard)
+    if (T.d_identity) {
+        if (P.n_waves <= 1) GF_V2(1, true);
+        if (P.n_waves <= 4) GF_V2(4, true);
+        GF_V2(16, true);
+    }
+    if (P.n_waves <= 1) GF_V2(1, false);
+    if (P.n_waves <= 4) GF_V2(4, false);
+    GF_V2(16, false);
+#undef GF_V2
+}
+
+template <int ALGO>
+hipError_t launch_fused(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, const DevApp* d_dev_apps,
+                        gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half,
+                        int32_t* d_failed, ScanStats* d_stats, const int32_t* guard, hipStream_t stream) {
+    const size_t lds = fifo_fused_lds_bytes(P.lds_slots_fused, T.n_chunks);
+#define GF_FU(NW)                                                                                                     \
+    return launch_one_workgroup(fit_fifo_fused_kernel<ALGO, NW>, NW, lds, stream, T, P.lds_slots_fused, n_apps, d_dev_apps, \
+                                d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard)
+    if (P.n_waves <= 4) GF_FU(4);
+    if (P.n_waves <= 8) GF_FU(8);
+    GF_FU(16);
+#undef GF_FU
+}
+
+template <int ALGO>
+hipError_t launch_narrow(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
+                         const NApp* d_napps, const int32_t* d_wide_needed, gf_result* d_results,
+                         uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, int32_t* d_failed,
+                         ScanStats* d_stats, hipStream_t stream) {
+    const size_t lds = fifo_narrow_lds_bytes(P.lds_slots_narrow, T.n_chunks);
+#define GF_NA(NW)                                                                                                       \
+    {                                                                                                                   \
+        if (d_stats != nullptr)                                                                                         \
+            return launch_one_workgroup(fit_fifo_narrow_kernel<ALGO, NW, true>, NW, lds, stream, T, NT, P.lds_slots_narrow, \
+                                        n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,       \
+                                        d_failed, d_stats);                                                            \
+        return launch_one_workgroup(fit_fifo_narrow_kernel<ALGO, NW, false>, NW, lds, stream, T, NT, P.lds_slots_narrow, \
+                                    n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, \
+                                    d_stats);                                                                          \
+    }
+    if (P.n_waves <= 4) GF_NA(4);
+    if (P.n_waves <= 8) GF_NA(8);
+    GF_NA(16);
+#undef GF_NA
+}
+
+template <int ALGO>
+hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
+                            const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps, int32_t* d_wide_needed,
+                            gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half,
+                            int32_t* d_failed, ScanStats* d_stats, hipStream_t stream) {
+    hipError_t e = hipSuccess;
+    const bool fused = P.wide_fused && T.d_identity;
+    const int32_t* guard = nullptr;
+    if (P.narrow || fused) {
+        if (P.narrow) {
+            e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
+            if (e != hipSuccess) return e;
+            // run heads of the tightly-pack fast path: "no head here"
+            if (ALGO == GF_ALGO_TIGHTLY_PACK && half > 1) {
+                e = hipMemsetAsync(d_scratch, 0xFF, (half - 1) * sizeof(uint32_t), stream);
+                if (e != hipSuccess) return e;
+            }
+            guard = d_wide_needed;
+        }
+        hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
+                           fused ? d_dev_apps : (DevApp*)nullptr, P.narrow ? d_napps : (NApp*)nullptr, NT.unit[0],
+                           NT.unit[1], NT.unit[2], d_wide_needed);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (P.narrow) {
+        e = launch_narrow<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,
+                                d_failed, d_stats, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (fused)
+        e = launch_fused<ALGO>(P, T, n_apps, d_dev_apps, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats,
+                               guard, stream);
     else
-        e = launch_fifo_a<GF_ALGO_DISTRIBUTE_EVENLY>(n_waves, table, lds_slots, n_apps, d_apps, d_results,
-                                                     d_exec_nodes, d_scratch, scratch_half, d_chain_failed_at, d_stats,
-                                                     stream);
+        e = launch_v2<ALGO>(P, T, n_apps, d_apps, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard,
+                            stream);
     if (e != hipSuccess) return e;
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(translate_kernel, grid, block, 0, stream, table.slot_node, n_apps, d_apps, d_results,
-                       d_exec_nodes);
+    hipLaunchKernelGGL(expand_translate_kernel, grid, block, 0, stream, T.slot_node, n_apps, d_apps, d_results,
+                       d_exec_nodes, d_scratch);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
+                           uint32_t n_apps, const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps,
+                           int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                           uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    if (algo == GF_ALGO_TIGHTLY_PACK)
+        return launch_fifo_algo<GF_ALGO_TIGHTLY_PACK>(plan, table, ntable, n_apps, d_apps, d_dev_apps, d_napps,
+                                                      d_wide_needed, d_results, d_exec_nodes, d_scratch, scratch_half,
+                                                      d_chain_failed_at, d_stats, stream);
+    return launch_fifo_algo<GF_ALGO_DISTRIBUTE_EVENLY>(plan, table, ntable, n_apps, d_apps, d_dev_apps, d_napps,
+                                                       d_wide_needed, d_results, d_exec_nodes, d_scratch, scratch_half,
+                                                       d_chain_failed_at, d_stats, stream);
 }
 
 hipError_t launch_selftest(uint64_t seed, uint32_t n_cases, uint32_t* d_mismatch, hipStream_t stream) {

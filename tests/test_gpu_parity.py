@@ -66,15 +66,35 @@ def test_fifo_quirk_k7(gf_ctx):
     assert out.failed_at == -1 and not out.placement(1)[0]
 
 
-def _random_problem(rng, n, a, tight_cluster):
+def _random_problem(rng, n, a, tight_cluster, layout="general"):
+    """layout: "general" = driver and executor orders are independent permutations (the two orders disagree);
+    "merged" = both are subsequences of one priority order, as NodeSorter.PotentialNodes produces them (driver-only and
+    executor-only nodes, unknown names and a repeated driver candidate included); "identical" = D == X."""
     hi = 40 if tight_cluster else 4000
     avail = rng.integers(-3, hi, size=(n, 3)).astype(np.int64)
     avail[:, 2] = rng.integers(-1, 9, size=n)
     unknown = np.array([n + 5, n + 1000], dtype=np.int64)
-    X = np.concatenate([rng.permutation(n)[: int(rng.integers(max(1, n // 2), n + 1))], unknown[:1]])
-    X = rng.permutation(X).astype(np.uint32)
-    D = np.concatenate([rng.permutation(n)[: int(rng.integers(1, n + 1))], unknown])
-    D = rng.permutation(D).astype(np.uint32)
+    if layout == "general":
+        X = np.concatenate([rng.permutation(n)[: int(rng.integers(max(1, n // 2), n + 1))], unknown[:1]])
+        X = rng.permutation(X).astype(np.uint32)
+        D = np.concatenate([rng.permutation(n)[: int(rng.integers(1, n + 1))], unknown])
+        D = rng.permutation(D).astype(np.uint32)
+    else:
+        base = rng.permutation(n)
+        if layout == "identical":
+            X = base.astype(np.uint32)
+            D = X.copy()
+        else:
+            X = base[rng.random(n) < 0.8]
+            D = base[rng.random(n) < 0.7]
+            if len(X) == 0:
+                X = base[:1]
+            if len(D) == 0:
+                D = base[-1:]
+            # unknown names anywhere, one repeated driver candidate at the end
+            X = np.insert(X, int(rng.integers(0, len(X) + 1)), unknown[0]).astype(np.uint32)
+            D = np.insert(D, int(rng.integers(0, len(D) + 1)), unknown[1])
+            D = np.append(D, D[0]).astype(np.uint32)
     drv = rng.integers(0, 9, size=(a, 3)).astype(np.int64)
     exe = rng.integers(0, 7, size=(a, 3)).astype(np.int64)
     exe[rng.random(a) < 0.5, 2] = 0
@@ -86,30 +106,32 @@ def _random_problem(rng, n, a, tight_cluster):
     return avail, D, X, drv, exe, k
 
 
+@pytest.mark.parametrize("layout", ["general", "merged", "identical"])
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129, 500, 1000])
-def test_independent_batch_random(gf_ctx, algo, n):
-    rng = np.random.default_rng(1000 * algo + n)
+def test_independent_batch_random(gf_ctx, algo, n, layout):
+    rng = np.random.default_rng(1000 * algo + n + 7 * len(layout))
     for tight_cluster in (True, False):
         a = 257
-        avail, D, X, drv, exe, k = _random_problem(rng, n, a, tight_cluster)
+        avail, D, X, drv, exe, k = _random_problem(rng, n, a, tight_cluster, layout)
         gf_ctx.set_snapshot(avail)
         gf_ctx.set_orders(D, X)
         apps = _gpu_apps(drv, exe, k)
         gpu = gf_ctx.fit_batch(IND, algo, apps)
         ref = ob.fit_independent(algo, avail, ob.make_apps(drv, exe, k), D, X)
         _assert_same(gpu, ref, apps)
-        if n >= 63:  # the generator must exercise both outcomes
+        if n >= 63 and layout != "merged":  # the generator must exercise both outcomes
             assert ref.results["has_capacity"].any()
 
 
+@pytest.mark.parametrize("layout", ["general", "merged", "identical"])
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
-@pytest.mark.parametrize("n", [3, 64, 200, 1000])
-def test_fifo_chain_random(gf_ctx, algo, n):
-    rng = np.random.default_rng(77 * (algo + 1) + n)
+@pytest.mark.parametrize("n", [3, 64, 200, 1000, 1500, 5000])
+def test_fifo_chain_random(gf_ctx, algo, n, layout):
+    rng = np.random.default_rng(77 * (algo + 1) + n + 7 * len(layout))
     for rep in range(3):
         a = 120
-        avail, D, X, drv, exe, k = _random_problem(rng, n, a, tight_cluster=False)
+        avail, D, X, drv, exe, k = _random_problem(rng, n, a, tight_cluster=(rep == 2), layout=layout)
         exe = np.maximum(exe, 1)  # keep chains long: every placement consumes something
         k = np.minimum(k, 40).astype(np.int32)
         flags = (rng.random(a) < (0.9 if rep else 1.0)).astype(np.uint32)  # rep 0: nothing aborts the chain
