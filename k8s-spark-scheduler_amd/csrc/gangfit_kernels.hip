@@ -1244,8 +1244,10 @@ size_t fifo_fused_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
            40 * (size_t)n_chunks + 16;
 }
 size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
-    return kFusedStage * sizeof(NApp) + ((sizeof(NarrowShared) + 15) & ~(size_t)15) + 12 * (size_t)lds_slots +
-           28 * (size_t)n_chunks + 16;
+    const size_t nw = (n_chunks + 63u) / 64u;
+    return kFusedStage * sizeof(NApp) + ((sizeof(NarrowShared) + 15) & ~(size_t)15) + 16 * (size_t)n_chunks +
+           16 * (size_t)kMaxShapes * nw + 16 + sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 +
+           12 * (size_t)n_chunks + 12 * (size_t)lds_slots + 16;
 }
 
 namespace {
@@ -1293,7 +1295,7 @@ hipError_t launch_fused(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, 
 
 template <int ALGO>
 hipError_t launch_narrow(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
-                         const NApp* d_napps, const int32_t* d_wide_needed, gf_result* d_results,
+                         NApp* d_napps, const int32_t* d_wide_needed, gf_result* d_results,
                          uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, int32_t* d_failed,
                          ScanStats* d_stats, hipStream_t stream) {
     const size_t lds = fifo_narrow_lds_bytes(P.lds_slots_narrow, T.n_chunks);
