@@ -18,6 +18,9 @@ _LIB_PATH = os.path.join(_HERE, "libgangfit_oracle.so")
 ALGO_TIGHTLY_PACK = 0
 ALGO_DISTRIBUTE_EVENLY = 1
 ALGO_MINIMAL_FRAGMENTATION = 2
+ALGO_AZ_AWARE_TIGHTLY_PACK = 3
+ALGO_SINGLE_AZ_TIGHTLY_PACK = 4
+ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION = 5
 NO_NODE = 0xFFFFFFFF
 APP_SKIPPABLE = 1
 
@@ -62,6 +65,14 @@ def lib() -> C.CDLL:
                                          C.c_uint32, p, p, p]
         L.go_fit_fifo_chain.restype = C.c_int32
         L.go_fit_fifo_chain.argtypes = L.go_fit_independent.argtypes
+        L.go_fit_independent_ex.restype = None
+        L.go_fit_independent_ex.argtypes = [C.c_int, C.c_int, p, p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p,
+                                            C.c_uint32, p, p, p, p]
+        L.go_fit_fifo_chain_ex.restype = C.c_int32
+        L.go_fit_fifo_chain_ex.argtypes = [C.c_int, C.c_int, p, p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p,
+                                           C.c_uint32, p, p, p]
+        L.go_avg_packing_efficiency_list.restype = None
+        L.go_avg_packing_efficiency_list.argtypes = [p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, C.c_int, p]
         L.go_node_capacity.restype = C.c_int64
         L.go_node_capacity.argtypes = [p, p, p]
         L.go_packing_efficiency.restype = None
@@ -102,6 +113,7 @@ class BatchOut:
     exec_nodes: np.ndarray  # uint32, concatenated
     failed_at: int = -1
     avail_after: Optional[np.ndarray] = None
+    avg_eff: Optional[np.ndarray] = None  # (A, 4) AvgPackingEfficiency over [driver] ++ executors (zeros if infeasible)
 
     def placement(self, a: int) -> Tuple[bool, int, np.ndarray]:
         r = self.results[a]
@@ -117,33 +129,65 @@ def _prep(avail, driver_order, exec_order):
     return avail, d, x
 
 
-def fit_independent(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False) -> BatchOut:
+def _aux(avail, sched, zone):
+    if sched is not None:
+        sched = np.ascontiguousarray(sched, dtype=np.int64).reshape(-1, 3)
+        assert len(sched) == len(avail)
+    if zone is not None:
+        zone = np.ascontiguousarray(zone, dtype=np.uint32)
+        assert len(zone) == len(avail)
+    return sched, zone
+
+
+def fit_independent(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False,
+                    sched=None, zone=None) -> BatchOut:
+    """sched / zone: SchedulableResources (A x 3) and zone ids per node — needed by the single-AZ packers; with sched
+    the per-result AvgPackingEfficiency over [driver] ++ executors is returned in BatchOut.avg_eff."""
     avail, d, x = _prep(avail, driver_order, exec_order)
+    sched, zone = _aux(avail, sched, zone)
     apps = np.ascontiguousarray(apps)
     res = np.zeros(len(apps), dtype=RESULT_DTYPE)
     off = exec_offsets(apps["k"])
     out = np.zeros(int(apps["k"].astype(np.int64).sum()) + 1, dtype=np.uint32)
-    lib().go_fit_independent(algo, int(closed_form), _ptr(avail), len(avail), _ptr(apps), len(apps), _ptr(d), len(d),
-                             _ptr(x), len(x), _ptr(res), _ptr(off), _ptr(out))
-    return BatchOut(res, off, out[:-1])
+    avg = np.zeros((len(apps), 4), dtype=np.float64) if sched is not None else None
+    lib().go_fit_independent_ex(algo, int(closed_form), _ptr(avail), _ptr(sched), _ptr(zone), len(avail), _ptr(apps),
+                                len(apps), _ptr(d), len(d), _ptr(x), len(x), _ptr(res), _ptr(off), _ptr(out), _ptr(avg))
+    return BatchOut(res, off, out[:-1], avg_eff=avg)
 
 
-def fit_fifo_chain(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False) -> BatchOut:
+def fit_fifo_chain(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False,
+                   sched=None, zone=None) -> BatchOut:
     avail, d, x = _prep(avail, driver_order, exec_order)
+    sched, zone = _aux(avail, sched, zone)
     avail = avail.copy()
     apps = np.ascontiguousarray(apps)
     res = np.zeros(len(apps), dtype=RESULT_DTYPE)
     off = exec_offsets(apps["k"])
     out = np.zeros(int(apps["k"].astype(np.int64).sum()) + 1, dtype=np.uint32)
-    failed = lib().go_fit_fifo_chain(algo, int(closed_form), _ptr(avail), len(avail), _ptr(apps), len(apps), _ptr(d),
-                                     len(d), _ptr(x), len(x), _ptr(res), _ptr(off), _ptr(out))
+    failed = lib().go_fit_fifo_chain_ex(algo, int(closed_form), _ptr(avail), _ptr(sched), _ptr(zone), len(avail),
+                                        _ptr(apps), len(apps), _ptr(d), len(d), _ptr(x), len(x), _ptr(res), _ptr(off),
+                                        _ptr(out))
     return BatchOut(res, off, out[:-1], int(failed), avail)
 
 
-def spark_binpack(algo: int, avail, drv, exe, k: int, driver_order, exec_order, closed_form: bool = False):
+def avg_packing_efficiency_list(avail, sched, drv, exe, driver_node: int, exec_nodes,
+                                reserved_includes_executors: bool = True) -> np.ndarray:
+    """ComputeAvgPackingEfficiency over [driver] ++ exec_nodes in slice order -> [CPU, Memory, GPU, Max]."""
+    avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3)
+    sched = np.ascontiguousarray(sched, dtype=np.int64).reshape(-1, 3)
+    app = make_apps([drv], [exe], [len(exec_nodes)])
+    en = np.ascontiguousarray(exec_nodes, dtype=np.uint32)
+    avg = np.zeros(4, dtype=np.float64)
+    lib().go_avg_packing_efficiency_list(_ptr(avail), _ptr(sched), len(avail), _ptr(app), driver_node, _ptr(en),
+                                         len(en), int(reserved_includes_executors), _ptr(avg))
+    return avg
+
+
+def spark_binpack(algo: int, avail, drv, exe, k: int, driver_order, exec_order, closed_form: bool = False,
+                  sched=None, zone=None):
     """One decision. Returns (has_capacity, driver_node, exec_nodes ndarray)."""
     apps = make_apps([drv], [exe], [k])
-    out = fit_independent(algo, avail, apps, driver_order, exec_order, closed_form)
+    out = fit_independent(algo, avail, apps, driver_order, exec_order, closed_form, sched=sched, zone=zone)
     return out.placement(0)
 
 

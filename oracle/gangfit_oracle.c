@@ -431,33 +431,278 @@ int go_spark_binpack_closed_form(int algo, const int64_t *avail, uint32_t n_node
                                 exec_out);
 }
 
-/* ---------------------------------------------------------------- batch drivers */
+/* ---------------------------------------------------------------- efficiencies (LIB/binpack/efficiency.go) */
 
-static int binpack_any(int algo, int closed_form, const int64_t *avail, uint32_t n_nodes, const go_app *app,
-                       const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
-                       uint32_t *driver_out, uint32_t *exec_out, reserved_map *rm) {
-    if (closed_form && algo != GO_ALGO_MINIMAL_FRAGMENTATION)
-        return spark_binpack_closed(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out,
-                                    exec_out);
-    return spark_binpack_rm(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out, exec_out,
-                            rm);
+/* Quantity.Value(): rounded to the nearest integer AWAY from zero (K8S apimachinery quantity.go:731-734,
+ * math.go:169-199).  unit = 1000 for cpu (canonical milli), 1 for memory bytes and gpu count. */
+static int64_t value_round_away(int64_t v, int64_t unit) {
+    if (unit == 1) return v;
+    int64_t q = v / unit, r = v % unit;
+    if (r > 0) return q + 1;
+    if (r < 0) return q - 1;
+    return q;
+}
+static int64_t normalize_resource(int64_t v) { return v == 0 ? 1 : v; } /* efficiency.go:105-110 */
+
+static const int64_t k_value_unit[3] = {1000, 1, 1};
+
+/* computePackingEfficiency, efficiency.go:79-103, for one node given its entry of the `reserved` map (zeros if absent).
+ * Returns whether the node has gpus (SchedulableResources.NvidiaGPU.Value() != 0). */
+static int node_efficiency(const int64_t avail[3], const int64_t sched[3], const int64_t rsv[3], double e[3]) {
+    for (int j = 0; j < 3; ++j) {
+        int64_t used = sched[j] - avail[j] + rsv[j];                       /* :84-88 */
+        int64_t sv = value_round_away(sched[j], k_value_unit[j]);
+        e[j] = (double)value_round_away(used, k_value_unit[j]) / (double)normalize_resource(sv);
+    }
+    int has_gpu = value_round_away(sched[2], 1) != 0;
+    if (!has_gpu) e[2] = 0.0; /* :91-94 */
+    return has_gpu;
 }
 
-void go_fit_independent(int algo, int closed_form, const int64_t *avail, uint32_t n_nodes, const go_app *apps,
-                        uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
-                        uint32_t n_x, go_result *results, const uint64_t *exec_off, uint32_t *exec_out) {
+/* Running state of ComputeAvgPackingEfficiency (efficiency.go:114-156): sums in the order entries are pushed. */
+typedef struct {
+    double cpu_sum, mem_sum, gpu_sum, max_sum;
+    uint64_t with_gpu, len;
+} avg_acc;
+static void avg_push(avg_acc *a, const double e[3], int has_gpu) {
+    a->cpu_sum += e[0];                      /* :128 */
+    a->mem_sum += e[1];                      /* :129 */
+    if (has_gpu) {                           /* :131-134 */
+        a->gpu_sum += e[2];
+        ++a->with_gpu;
+    }
+    double m = e[0] > e[1] ? e[0] : e[1];    /* :136 math.Max (no NaNs: every divisor is >= 1 in magnitude) */
+    a->max_sum += e[2] > m ? e[2] : m;
+    ++a->len;
+}
+static void avg_finish(const avg_acc *a, double out[4]) {
+    if (a->len == 0) { /* WorstAvgPackingEfficiency, :119-121 */
+        out[0] = out[1] = out[2] = out[3] = 0.0;
+        return;
+    }
+    double len = (double)a->len;             /* :139 */
+    out[0] = a->cpu_sum / len;
+    out[1] = a->mem_sum / len;
+    out[2] = a->with_gpu == 0 ? 1.0 : a->gpu_sum / (double)a->with_gpu; /* :141-145 */
+    out[3] = a->max_sum / len;
+}
+
+void go_packing_efficiency(const int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *app,
+                           uint32_t driver_node, const uint32_t *exec_nodes, uint32_t n_exec, double *eff_out,
+                           double avg_out[4]) {
+    int64_t *reserved = (int64_t *)calloc((size_t)n_nodes * 3 + 3, sizeof(int64_t));
+    avg_acc acc;
+    memset(&acc, 0, sizeof acc);
+    if (!reserved) return;
+    /* `reserved` as left by SparkBinPack: driver + one executorResources per placed executor */
+    if (driver_node < n_nodes) res_add(&reserved[3 * driver_node], app->drv);
+    for (uint32_t i = 0; i < n_exec; ++i)
+        if (exec_nodes[i] < n_nodes) res_add(&reserved[3 * exec_nodes[i]], app->exe);
+    for (uint32_t n = 0; n < n_nodes; ++n) {
+        double e[3];
+        int has_gpu = node_efficiency(&avail[3 * n], &sched[3 * n], &reserved[3 * n], e);
+        if (eff_out) {
+            eff_out[3 * n] = e[0];
+            eff_out[3 * n + 1] = e[1];
+            eff_out[3 * n + 2] = e[2];
+        }
+        avg_push(&acc, e, has_gpu);
+    }
+    avg_finish(&acc, avg_out);
+    free(reserved);
+}
+
+/* chooseBestResult's average (single_az.go:83-89): ComputeAvgPackingEfficiency over nodeNames = [driver] ++ executors,
+ * duplicates counted, summed in slice order, read from the per-node efficiencies of the given `reserved` map. */
+static void avg_efficiency_of_list(const int64_t *avail, const int64_t *sched, uint32_t n_nodes,
+                                   const reserved_map *reserved, uint32_t driver_node, const uint32_t *exec_nodes,
+                                   uint32_t n_exec, double avg_out[4]) {
+    static const int64_t zero[3] = {0, 0, 0};
+    avg_acc acc;
+    memset(&acc, 0, sizeof acc);
+    for (uint32_t i = 0; i <= n_exec; ++i) {
+        uint32_t n = i == 0 ? driver_node : exec_nodes[i - 1];
+        double e[3];
+        if (n >= n_nodes) continue; /* cannot happen for a feasible result: every placed node is a metadata key */
+        const int64_t *rsv = reserved->present[n] ? &reserved->r[3 * n] : zero;
+        int has_gpu = node_efficiency(&avail[3 * n], &sched[3 * n], rsv, e);
+        avg_push(&acc, e, has_gpu);
+    }
+    avg_finish(&acc, avg_out);
+}
+
+void go_avg_packing_efficiency_list(const int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *app,
+                                    uint32_t driver_node, const uint32_t *exec_nodes, uint32_t n_exec,
+                                    int reserved_includes_executors, double avg_out[4]) {
     reserved_map rm;
+    avg_out[0] = avg_out[1] = avg_out[2] = avg_out[3] = 0.0;
+    if (!rm_init(&rm, n_nodes)) {
+        rm_free(&rm);
+        return;
+    }
+    if (driver_node < n_nodes) res_add(rm_get_or_zero(&rm, driver_node), app->drv);
+    if (reserved_includes_executors)
+        for (uint32_t i = 0; i < n_exec; ++i)
+            if (exec_nodes[i] < n_nodes) res_add(rm_get_or_zero(&rm, exec_nodes[i]), app->exe);
+    avg_efficiency_of_list(avail, sched, n_nodes, &rm, driver_node, exec_nodes, n_exec, avg_out);
+    rm_free(&rm);
+}
+
+/* ---------------------------------------------------------------- single-AZ wrappers (LIB/binpack/single_az.go) */
+
+static int is_single_az(int algo) {
+    return algo == GO_ALGO_SINGLE_AZ_TIGHTLY_PACK || algo == GO_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ||
+           algo == GO_ALGO_AZ_AWARE_TIGHTLY_PACK;
+}
+static int inner_packer(int algo) {
+    return algo == GO_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ? GO_ALGO_MINIMAL_FRAGMENTATION : GO_ALGO_TIGHTLY_PACK;
+}
+
+/* groupNodesByZone, single_az.go:57-72: zones in order of first appearance, names per zone in order; names that
+ * are not metadata keys are dropped.  Returns the number of zones; zones_in_order[] receives them; the caller
+ * filters per zone with zone_filter(). */
+static uint32_t zones_in_order(const uint32_t *order, uint32_t n, const uint32_t *zone, uint32_t n_nodes,
+                               uint32_t *zones_out /* room for n */) {
+    uint32_t nz = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (order[i] >= n_nodes) continue;
+        uint32_t z = zone ? zone[order[i]] : 0, seen = 0;
+        for (uint32_t q = 0; q < nz && !seen; ++q) seen = zones_out[q] == z;
+        if (!seen) zones_out[nz++] = z;
+    }
+    return nz;
+}
+static uint32_t zone_filter(const uint32_t *order, uint32_t n, const uint32_t *zone, uint32_t n_nodes, uint32_t z,
+                            uint32_t *out) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (order[i] < n_nodes && (zone ? zone[order[i]] : 0) == z) out[m++] = order[i];
+    return m;
+}
+
+/* getSingleAZSparkBinFunction (single_az.go:23-55) + chooseBestResult (:75-97).  The per-zone packs and their
+ * efficiencies follow the literal path (reserved map as the packer left it) or, with closed_form, the array path
+ * with `reserved` rebuilt from the placement (tightly-pack only). */
+static int single_az_binpack(int algo, int closed_form, const int64_t *avail, const int64_t *sched,
+                             const uint32_t *zone, uint32_t n_nodes, const go_app *app, const uint32_t *driver_order,
+                             uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, uint32_t *driver_out,
+                             uint32_t *exec_out, reserved_map *rm, double avg_out[4]) {
+    const int inner = inner_packer(algo);
+    uint32_t *dz = (uint32_t *)malloc(((size_t)n_d + 1) * sizeof(uint32_t));
+    uint32_t *xz = (uint32_t *)malloc(((size_t)n_x + 1) * sizeof(uint32_t));
+    uint32_t *d_f = (uint32_t *)malloc(((size_t)n_d + 1) * sizeof(uint32_t));
+    uint32_t *x_f = (uint32_t *)malloc(((size_t)n_x + 1) * sizeof(uint32_t));
+    uint32_t *tmp = (uint32_t *)malloc(((size_t)(app->k > 0 ? app->k : 0) + 1) * sizeof(uint32_t));
+    int best_ok = 0;
+    double best_avg[4] = {0.0, 0.0, 0.0, 0.0}; /* WorstAvgPackingEfficiency, single_az.go:80 */
+    *driver_out = GO_NO_NODE;
+    if (avg_out) avg_out[0] = avg_out[1] = avg_out[2] = avg_out[3] = 0.0;
+    if (!dz || !xz || !d_f || !x_f || !tmp) goto done;
+    {
+        const uint32_t n_dz = zones_in_order(driver_order, n_d, zone, n_nodes, dz);   /* :31 */
+        const uint32_t n_xz = zones_in_order(exec_order, n_x, zone, n_nodes, xz);     /* :32 */
+        for (uint32_t q = 0; q < n_dz; ++q) {                                         /* :36 */
+            uint32_t z = dz[q], has_x = 0;
+            for (uint32_t r = 0; r < n_xz && !has_x; ++r) has_x = xz[r] == z;
+            if (!has_x) continue;                                                     /* :38-41 */
+            uint32_t nd = zone_filter(driver_order, n_d, zone, n_nodes, z, d_f);
+            uint32_t nx = zone_filter(exec_order, n_x, zone, n_nodes, z, x_f);
+            uint32_t d = GO_NO_NODE;
+            int ok;
+            if (closed_form && inner != GO_ALGO_MINIMAL_FRAGMENTATION) {
+                ok = spark_binpack_closed(inner, avail, n_nodes, app, d_f, nd, x_f, nx, &d, tmp);
+                if (ok) { /* rebuild `reserved`: driver + one executor request per placement */
+                    rm_clear(rm);
+                    res_add(rm_get_or_zero(rm, d), app->drv);
+                    for (int32_t i = 0; i < app->k; ++i) res_add(rm_get_or_zero(rm, tmp[i]), app->exe);
+                }
+            } else {
+                ok = spark_binpack_rm(inner, avail, n_nodes, app, d_f, nd, x_f, nx, &d, tmp, rm); /* :42 */
+            }
+            if (!ok) continue;                                                        /* :44-46 */
+            double avg[4];
+            avg_efficiency_of_list(avail, sched, n_nodes, rm, d, tmp, (uint32_t)app->k, avg);
+            if (best_avg[3] < avg[3]) { /* LessThan, efficiency.go:37-39: strictly higher Max replaces */
+                best_ok = 1;
+                *driver_out = d;
+                memcpy(exec_out, tmp, (size_t)app->k * sizeof(uint32_t));
+                memcpy(best_avg, avg, sizeof avg);
+            }
+        }
+    }
+    if (best_ok && avg_out) memcpy(avg_out, best_avg, sizeof best_avg);
+done:
+    free(dz);
+    free(xz);
+    free(d_f);
+    free(x_f);
+    free(tmp);
+    return best_ok; /* no feasible zone, or no zone with Max > 0: EmptyPackingResult (:49-51, :78) */
+}
+
+/* ---------------------------------------------------------------- batch drivers */
+
+typedef struct {
+    const int64_t *sched;  /* n_nodes x 3 SchedulableResources; needed by the single-AZ packers (efficiencies) */
+    const uint32_t *zone;  /* n_nodes zone ids (NodeSchedulingMetadata.ZoneLabel); NULL = one zone */
+} cluster_aux;
+
+/* One decision by packer name (internal/binpacker/binpack.go:43-49).  avg_out (nullable, 4 doubles) receives the
+ * AvgPackingEfficiency over [driver] ++ executors of the returned result (zeros when infeasible). */
+static int binpack_any(int algo, int closed_form, const int64_t *avail, const cluster_aux *aux, uint32_t n_nodes,
+                       const go_app *app, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                       uint32_t n_x, uint32_t *driver_out, uint32_t *exec_out, reserved_map *rm, double *avg_out) {
+    int ok;
+    if (is_single_az(algo)) {
+        ok = aux && aux->sched &&
+             single_az_binpack(algo, closed_form, avail, aux->sched, aux->zone, n_nodes, app, driver_order, n_d,
+                               exec_order, n_x, driver_out, exec_out, rm, avg_out);
+        if (ok || algo != GO_ALGO_AZ_AWARE_TIGHTLY_PACK) return ok;
+        algo = GO_ALGO_TIGHTLY_PACK; /* az_aware_pack_tightly.go:33-37: fall back to plain TightlyPack */
+    }
+    if (closed_form && algo != GO_ALGO_MINIMAL_FRAGMENTATION) {
+        ok = spark_binpack_closed(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out, exec_out);
+        if (ok && avg_out && aux && aux->sched) {
+            rm_clear(rm);
+            res_add(rm_get_or_zero(rm, *driver_out), app->drv);
+            for (int32_t i = 0; i < app->k; ++i) res_add(rm_get_or_zero(rm, exec_out[i]), app->exe);
+        }
+    } else {
+        ok = spark_binpack_rm(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out, exec_out, rm);
+    }
+    if (avg_out) {
+        avg_out[0] = avg_out[1] = avg_out[2] = avg_out[3] = 0.0;
+        if (ok && aux && aux->sched)
+            avg_efficiency_of_list(avail, aux->sched, n_nodes, rm, *driver_out, exec_out, (uint32_t)app->k, avg_out);
+    }
+    return ok;
+}
+
+void go_fit_independent_ex(int algo, int closed_form, const int64_t *avail, const int64_t *sched,
+                           const uint32_t *zone, uint32_t n_nodes, const go_app *apps, uint32_t n_apps,
+                           const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
+                           go_result *results, const uint64_t *exec_off, uint32_t *exec_out, double *avg_out) {
+    reserved_map rm;
+    cluster_aux aux = {sched, zone};
     int have_rm = rm_init(&rm, n_nodes);
     for (uint32_t a = 0; a < n_apps; ++a) {
         uint32_t d = GO_NO_NODE;
-        int ok = have_rm && binpack_any(algo, closed_form, avail, n_nodes, &apps[a], driver_order, n_d,
-                                        exec_order, n_x, &d, exec_out + exec_off[a], &rm);
+        int ok = have_rm && binpack_any(algo, closed_form, avail, &aux, n_nodes, &apps[a], driver_order, n_d,
+                                        exec_order, n_x, &d, exec_out + exec_off[a], &rm,
+                                        avg_out ? avg_out + 4 * (size_t)a : NULL);
         results[a].has_capacity = ok;
         results[a].driver_node = ok ? d : GO_NO_NODE;
         results[a].exec_len = ok ? (uint32_t)apps[a].k : 0;
         results[a].evaluated = 1;
     }
     rm_free(&rm);
+}
+
+void go_fit_independent(int algo, int closed_form, const int64_t *avail, uint32_t n_nodes, const go_app *apps,
+                        uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                        uint32_t n_x, go_result *results, const uint64_t *exec_off, uint32_t *exec_out) {
+    go_fit_independent_ex(algo, closed_form, avail, NULL, NULL, n_nodes, apps, n_apps, driver_order, n_d, exec_order,
+                          n_x, results, exec_off, exec_out, NULL);
 }
 
 /* sparkResourceUsage + SubtractUsageIfExists (internal/extender/sparkpods.go:139-146, LIB/resources/resources.go:129-135):
@@ -478,11 +723,12 @@ static void subtract_usage(int64_t *avail, uint32_t n_nodes, const go_app *app, 
     if (!driver_overwritten && driver_node < n_nodes) res_sub(&avail[3 * driver_node], app->drv);
 }
 
-int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_nodes, const go_app *apps,
-                          uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d,
-                          const uint32_t *exec_order, uint32_t n_x, go_result *results,
-                          const uint64_t *exec_off, uint32_t *exec_out) {
+int32_t go_fit_fifo_chain_ex(int algo, int closed_form, int64_t *avail, const int64_t *sched, const uint32_t *zone,
+                             uint32_t n_nodes, const go_app *apps, uint32_t n_apps, const uint32_t *driver_order,
+                             uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                             const uint64_t *exec_off, uint32_t *exec_out) {
     reserved_map rm;
+    cluster_aux aux = {sched, zone};
     int have_rm = rm_init(&rm, n_nodes);
     uint8_t *mark = (uint8_t *)calloc((size_t)n_nodes + 1, 1);
     int32_t failed_at = -1;
@@ -495,8 +741,8 @@ int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_
     if (!have_rm || !mark) goto done;
     for (uint32_t a = 0; a < n_apps; ++a) { /* resource.go:229 over earlier drivers, then :321 for the last */
         uint32_t d = GO_NO_NODE;
-        int ok = binpack_any(algo, closed_form, avail, n_nodes, &apps[a], driver_order, n_d, exec_order, n_x, &d,
-                             exec_out + exec_off[a], &rm);
+        int ok = binpack_any(algo, closed_form, avail, &aux, n_nodes, &apps[a], driver_order, n_d, exec_order, n_x, &d,
+                             exec_out + exec_off[a], &rm, NULL);
         results[a].evaluated = 1;
         results[a].has_capacity = ok;
         results[a].driver_node = ok ? d : GO_NO_NODE;
@@ -515,65 +761,12 @@ done:
     return failed_at;
 }
 
-/* ---------------------------------------------------------------- efficiencies (LIB/binpack/efficiency.go) */
-
-/* Quantity.Value(): rounded to the nearest integer AWAY from zero (K8S apimachinery quantity.go:731-734,
- * math.go:169-199).  unit = 1000 for cpu (canonical milli), 1 for memory bytes and gpu count. */
-static int64_t value_round_away(int64_t v, int64_t unit) {
-    if (unit == 1) return v;
-    int64_t q = v / unit, r = v % unit;
-    if (r > 0) return q + 1;
-    if (r < 0) return q - 1;
-    return q;
-}
-static int64_t normalize_resource(int64_t v) { return v == 0 ? 1 : v; } /* efficiency.go:105-110 */
-
-void go_packing_efficiency(const int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *app,
-                           uint32_t driver_node, const uint32_t *exec_nodes, uint32_t n_exec, double *eff_out,
-                           double avg_out[4]) {
-    static const int64_t unit[3] = {1000, 1, 1};
-    int64_t *reserved = (int64_t *)calloc((size_t)n_nodes * 3 + 3, sizeof(int64_t));
-    double cpu_sum = 0, mem_sum = 0, gpu_sum = 0, max_sum = 0;
-    uint32_t with_gpu = 0;
-    if (!reserved) return;
-    /* `reserved` as left by SparkBinPack: driver + one executorResources per placed executor */
-    if (driver_node < n_nodes) res_add(&reserved[3 * driver_node], app->drv);
-    for (uint32_t i = 0; i < n_exec; ++i)
-        if (exec_nodes[i] < n_nodes) res_add(&reserved[3 * exec_nodes[i]], app->exe);
-    for (uint32_t n = 0; n < n_nodes; ++n) {
-        double e[3];
-        for (int j = 0; j < 3; ++j) { /* computePackingEfficiency, efficiency.go:79-103 */
-            int64_t used = sched[3 * n + j] - avail[3 * n + j] + reserved[3 * n + j];
-            int64_t sv = value_round_away(sched[3 * n + j], unit[j]);
-            e[j] = (double)value_round_away(used, unit[j]) / (double)normalize_resource(sv);
-        }
-        int has_gpu = value_round_away(sched[3 * n + 2], 1) != 0;
-        if (!has_gpu) e[2] = 0.0; /* :91-94 */
-        if (eff_out) {
-            eff_out[3 * n] = e[0];
-            eff_out[3 * n + 1] = e[1];
-            eff_out[3 * n + 2] = e[2];
-        }
-        /* ComputeAvgPackingEfficiency, efficiency.go:114-156 */
-        cpu_sum += e[0];
-        mem_sum += e[1];
-        if (has_gpu) {
-            gpu_sum += e[2];
-            ++with_gpu;
-        }
-        double m = e[0] > e[1] ? e[0] : e[1];
-        max_sum += e[2] > m ? e[2] : m;
-    }
-    if (n_nodes == 0) { /* WorstAvgPackingEfficiency, :119-121 */
-        avg_out[0] = avg_out[1] = avg_out[2] = avg_out[3] = 0.0;
-    } else {
-        double len = (double)n_nodes;
-        avg_out[0] = cpu_sum / len;
-        avg_out[1] = mem_sum / len;
-        avg_out[2] = with_gpu == 0 ? 1.0 : gpu_sum / (double)with_gpu;
-        avg_out[3] = max_sum / len;
-    }
-    free(reserved);
+int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_nodes, const go_app *apps,
+                          uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d,
+                          const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                          const uint64_t *exec_off, uint32_t *exec_out) {
+    return go_fit_fifo_chain_ex(algo, closed_form, avail, NULL, NULL, n_nodes, apps, n_apps, driver_order, n_d,
+                                exec_order, n_x, results, exec_off, exec_out);
 }
 
 /* ---------------------------------------------------------------- executor first-fit */

@@ -30,6 +30,9 @@ extern "C" {
 #define GO_ALGO_TIGHTLY_PACK 0      /* LIB/binpack/pack_tightly.go:25-63 */
 #define GO_ALGO_DISTRIBUTE_EVENLY 1 /* LIB/binpack/distribute_evenly.go:25-73 */
 #define GO_ALGO_MINIMAL_FRAGMENTATION 2 /* LIB/binpack/minimal_fragmentation.go:33-137 */
+#define GO_ALGO_AZ_AWARE_TIGHTLY_PACK 3 /* LIB/binpack/az_aware_pack_tightly.go:27-38 */
+#define GO_ALGO_SINGLE_AZ_TIGHTLY_PACK 4 /* LIB/binpack/single_az_pack_tightly.go:21 + single_az.go:23-97 */
+#define GO_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION 5 /* LIB/binpack/single_az_minimal_fragmentation.go:20 */
 
 #define GO_NO_NODE 0xFFFFFFFFu
 #define GO_APP_SKIPPABLE 1u /* shouldSkipDriverFifo() is true for this earlier driver, resource.go:264-270 */
@@ -77,6 +80,27 @@ int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_
                           uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d,
                           const uint32_t *exec_order, uint32_t n_x, go_result *results,
                           const uint64_t *exec_off, uint32_t *exec_out);
+
+/* The same two batch shapes for EVERY registered packer (internal/binpacker/binpack.go:43-49), including the
+ * zone-aware wrappers: sched = n_nodes x 3 SchedulableResources (efficiencies), zone = n_nodes zone ids
+ * (NodeSchedulingMetadata.ZoneLabel; NULL = a single zone).  avg_out (nullable): n_apps x 4 doubles
+ * {CPU, Memory, GPU, Max} = ComputeAvgPackingEfficiency over [driver] ++ executors of each returned result, in
+ * slice order (what chooseBestResult compares, single_az.go:83-93); zeros for infeasible apps. */
+void go_fit_independent_ex(int algo, int closed_form, const int64_t *avail, const int64_t *sched,
+                           const uint32_t *zone, uint32_t n_nodes, const go_app *apps, uint32_t n_apps,
+                           const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
+                           go_result *results, const uint64_t *exec_off, uint32_t *exec_out, double *avg_out);
+int32_t go_fit_fifo_chain_ex(int algo, int closed_form, int64_t *avail, const int64_t *sched, const uint32_t *zone,
+                             uint32_t n_nodes, const go_app *apps, uint32_t n_apps, const uint32_t *driver_order,
+                             uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                             const uint64_t *exec_off, uint32_t *exec_out);
+
+/* ComputeAvgPackingEfficiency (efficiency.go:114-156) over nodeNames = [driver] ++ exec_nodes, duplicates counted,
+ * summed in slice order.  reserved_includes_executors = 0 reproduces minimalFragmentation, which never writes its
+ * placements into the `reserved` map (minimal_fragmentation.go:59-91): only the driver entry exists there. */
+void go_avg_packing_efficiency_list(const int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *app,
+                                    uint32_t driver_node, const uint32_t *exec_nodes, uint32_t n_exec,
+                                    int reserved_includes_executors, double avg_out[4]);
 
 /* capacity.GetNodeCapacity (LIB/capacity/capacity.go:36-75) on canonical int64; INT64_MAX stands for math.MaxInt. */
 int64_t go_node_capacity(const int64_t avail[3], const int64_t reserved[3], const int64_t required[3]);

@@ -110,6 +110,98 @@ def distribute_evenly(drv, exe, count, driver_order, exec_order, avail) -> Packi
     return spark_binpack(drv, exe, count, driver_order, exec_order, avail, distribute_executors_evenly)
 
 
+def _value(v: int, unit: int) -> int:
+    """Quantity.Value(): rounded away from zero to whole units (K8S apimachinery quantity.go:731-734, math.go:169-199)."""
+    if unit == 1:
+        return v
+    q, r = divmod(abs(v), unit)
+    q += 1 if r else 0
+    return q if v >= 0 else -q
+
+
+_UNITS = (1000, 1, 1)  # canonical cpu is milli-cores; memory bytes and gpu devices are whole units already
+
+
+def compute_packing_efficiency(name, avail, sched, reserved):
+    """computePackingEfficiency — LIB/binpack/efficiency.go:79-103. Returns (cpu, memory, gpu) as float64."""
+    eff = []
+    for j in range(3):
+        used = sched[name][j] - avail[name][j] + (reserved[name][j] if name in reserved else 0)
+        denom = _value(sched[name][j], _UNITS[j]) or 1  # normalizeResource, :105-110
+        eff.append(float(_value(used, _UNITS[j])) / float(denom))
+    if _value(sched[name][2], 1) == 0:
+        eff[2] = 0.0
+    return tuple(eff)
+
+
+def compute_avg_packing_efficiency(sched, effs):
+    """ComputeAvgPackingEfficiency — efficiency.go:114-156. effs: list of (name, (cpu, mem, gpu)) in slice order."""
+    if not effs:
+        return (0.0, 0.0, 0.0, 0.0)
+    cpu = mem = gpu = mx = 0.0
+    with_gpu = 0
+    for name, e in effs:
+        cpu += e[0]
+        mem += e[1]
+        if _value(sched[name][2], 1) != 0:
+            gpu += e[2]
+            with_gpu += 1
+        mx += max(e[2], max(e[0], e[1]))
+    length = float(max(len(effs), 1))
+    return (cpu / length, mem / length, 1.0 if with_gpu == 0 else gpu / with_gpu, mx / length)
+
+
+def group_nodes_by_zone(names, zone):
+    """groupNodesByZone — LIB/binpack/single_az.go:57-72 (zone: dict name -> label for metadata keys only)."""
+    zones_in_order: List[str] = []
+    by_zone: Dict[str, List[str]] = {}
+    for n in names:
+        if n not in zone:
+            continue
+        z = zone[n]
+        if z not in by_zone:
+            zones_in_order.append(z)
+            by_zone[z] = []
+        by_zone[z].append(n)
+    return zones_in_order, by_zone
+
+
+def single_az(packer: Packer):
+    """getSingleAZSparkBinFunction + chooseBestResult — LIB/binpack/single_az.go:23-55, 75-97."""
+
+    def fn(drv, exe, count, driver_order, exec_order, avail, sched, zone) -> PackingResult:
+        zones, d_by_zone = group_nodes_by_zone(driver_order, zone)
+        _, x_by_zone = group_nodes_by_zone(exec_order, zone)
+        results = []
+        for z in zones:
+            if z not in x_by_zone:
+                continue
+            r = spark_binpack(drv, exe, count, d_by_zone[z], x_by_zone[z], avail, packer)
+            if r.has_capacity:
+                results.append(r)
+        best, best_max = PackingResult(), 0.0
+        for r in results:
+            names = [r.driver_node] + r.executor_nodes
+            avg = compute_avg_packing_efficiency(
+                sched, [(n, compute_packing_efficiency(n, avail, sched, r.reserved)) for n in names])
+            if best_max < avg[3]:
+                best, best_max = r, avg[3]
+        return best
+
+    return fn
+
+
+single_az_tightly_pack = single_az(tightly_pack_executors)
+
+
+def az_aware_tightly_pack(drv, exe, count, driver_order, exec_order, avail, sched, zone) -> PackingResult:
+    """AzAwareTightlyPack — LIB/binpack/az_aware_pack_tightly.go:27-38."""
+    r = single_az_tightly_pack(drv, exe, count, driver_order, exec_order, avail, sched, zone)
+    if r.has_capacity:
+        return r
+    return tightly_pack(drv, exe, count, driver_order, exec_order, avail)
+
+
 BINPACK_FUNCTIONS = {  # internal/binpacker/binpack.go:43-49 (the two north-star entries)
     "tightly-pack": tightly_pack,
     "distribute-evenly": distribute_evenly,
