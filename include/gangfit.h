@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GF_VERSION 100 /* 0.1.0 */
+#define GF_VERSION 110 /* 0.1.1 */
 
 /* ---- status codes ---- */
 #define GF_OK 0
@@ -53,6 +53,14 @@ extern "C" {
 typedef enum gf_algo {
     GF_ALGO_TIGHTLY_PACK = 0,      /* "tightly-pack"      LIB/binpack/pack_tightly.go:25-63 */
     GF_ALGO_DISTRIBUTE_EVENLY = 1, /* "distribute-evenly" LIB/binpack/distribute_evenly.go:25-73 */
+    GF_ALGO_MINIMAL_FRAGMENTATION = 2, /* binpack.MinimalFragmentation (not in the registry; the zone-less inner packer)
+                                          LIB/binpack/minimal_fragmentation.go:27-137 */
+    /* zone-aware packers: need gf_zones_set and the schedulable columns of gf_snapshot_set */
+    GF_ALGO_AZ_AWARE_TIGHTLY_PACK = 3,  /* "az-aware-tightly-pack"  LIB/binpack/az_aware_pack_tightly.go:27-38 */
+    GF_ALGO_SINGLE_AZ_TIGHTLY_PACK = 4, /* "single-az-tightly-pack" LIB/binpack/single_az_pack_tightly.go:21,
+                                           single_az.go:23-97 — what every reference test selects */
+    GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION = 5, /* "single-az-minimal-fragmentation"
+                                           LIB/binpack/single_az_minimal_fragmentation.go:20 */
 } gf_algo;
 
 typedef enum gf_mode {
@@ -109,6 +117,11 @@ int gf_snapshot_set(gf_ctx *ctx, uint32_t n_nodes, const int64_t *avail_cpu_mill
                     const int64_t *avail_gpu, const int64_t *sched_cpu_milli, const int64_t *sched_mem_bytes,
                     const int64_t *sched_gpu);
 
+/* Zone label of every node (NodeSchedulingMetadata.ZoneLabel, LIB/resources/resources.go:78-81, 158-166) as a dense id
+ * the caller assigns per distinct label string.  Optional: without it every node is in one zone (the reference's
+ * "default" label).  Call after gf_snapshot_set and before gf_orders_set (a new snapshot drops the zones). */
+int gf_zones_set(gf_ctx *ctx, const uint32_t *zone_of_node /* n_nodes */);
+
 /* Upload driverNodePriorityOrder / executorNodePriorityOrder (the two results of NodeSorter.PotentialNodes,
  * internal/sort/nodesorting.go:41-64) as node indices.  A known node may appear at most once in exec_order
  * (both vectors derive from map keys in the reference, nodesorting.go:153-159); violating this is GF_ERR_INVALID.
@@ -137,6 +150,25 @@ int gf_fit_batch_dev(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
  * (LIB/binpack/binpack.go:43-48) for registry entries "gpu-tightly-pack" / "gpu-distribute-evenly". */
 int gf_spark_binpack(gf_ctx *ctx, gf_algo algo, const gf_app *app, gf_result *result, uint32_t *exec_nodes,
                      uint64_t exec_nodes_cap);
+
+/* binpack.AvgPackingEfficiency (LIB/binpack/efficiency.go:25-31). */
+typedef struct gf_avg_efficiency {
+    double cpu, memory, gpu, max;
+} gf_avg_efficiency;
+
+/* ComputeAvgPackingEfficiency (LIB/binpack/efficiency.go:114-156) over nodeNames = [DriverNode] ++ ExecutorNodes of
+ * each of n_apps results of an INDEPENDENT batch, duplicates counted, summed in slice order — the value
+ * chooseBestResult compares (LIB/binpack/single_az.go:83-93) — computed on the device against the current snapshot
+ * (needs the schedulable columns).  `algo` selects how the packer left the `reserved` map: the minimal-fragmentation
+ * packers never write executor placements into it (minimal_fragmentation.go:59-91).  Infeasible results give zeros
+ * (WorstAvgPackingEfficiency).  float64 values are bit-identical to the reference's. */
+int gf_avg_packing_efficiency(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, const gf_result *results,
+                              const uint32_t *exec_nodes, uint64_t exec_nodes_len, gf_avg_efficiency *out);
+
+/* ComputePackingEfficiencies (LIB/binpack/efficiency.go:66-103): PackingResult.PackingEfficiencies of ONE result as a
+ * dense n_nodes x 3 array {CPU, Memory, GPU} in node-index order (the Go map has one entry per metadata key). */
+int gf_packing_efficiencies(gf_ctx *ctx, gf_algo algo, const gf_app *app, const gf_result *result,
+                            const uint32_t *exec_nodes, double *eff_out /* n_nodes * 3 */);
 
 /* Working copy of the available table after the last GF_MODE_FIFO_CHAIN call (n_nodes x 3, row-major) — lets tests
  * compare the replayed residuals with availableNodesSchedulingMetadata after fitEarlierDrivers. */

@@ -117,6 +117,22 @@ struct gf_ctx {
     int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
+    // zone views + efficiency tables (single-AZ packers, LIB/binpack/single_az.go; efficiency.go)
+    std::vector<uint32_t> zone;        // per node; empty = one zone
+    DeviceBuf<int64_t> d_sched;        // 3 * n_slots SchedulableResources in slot order (0 on empty slots)
+    DeviceBuf<int64_t> d_node_tab;     // 6 * n_nodes: avail cpu|mem|gpu, sched cpu|mem|gpu by node index
+    DeviceBuf<uint64_t> d_zmasks;      // [2][n_zones][zstride]: executor masks, then driver masks
+    PinnedBuf<uint64_t> h_zmasks;
+    uint32_t n_zones = 0, zstride = 0;
+    DeviceBuf<gf_result> d_zres;
+    DeviceBuf<uint32_t> d_zexec;
+    DeviceBuf<double> d_zavg, d_avg;
+    DeviceBuf<uint32_t> d_cnt;         // [cnt_rows][cnt_slots], all-zero between launches
+    uint32_t cnt_rows = 0, cnt_slots = 0;
+    DeviceBuf<int64_t> d_reserved;
+    DeviceBuf<double> d_eff;
+    PinnedBuf<double> h_avg;
+
     // batch buffers
     DeviceBuf<gf_app> d_apps;
     DeviceBuf<gf_result> d_results;
@@ -168,13 +184,77 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     return t;
 }
 
+gangfit::EffTables slot_eff_tables(gf_ctx* ctx, const int64_t* avail_base) {
+    gangfit::EffTables e;
+    for (int j = 0; j < 3; ++j) {
+        e.avail[j] = avail_base + (size_t)j * ctx->n_slots;
+        e.sched[j] = ctx->d_sched.ptr + (size_t)j * ctx->n_slots;
+    }
+    return e;
+}
+
+// minimalFragmentation never records its placements in `reserved` (minimal_fragmentation.go:59-91)
+bool reserves_executors(gf_algo algo) {
+    return algo != GF_ALGO_MINIMAL_FRAGMENTATION && algo != GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION;
+}
+bool is_zone_algo(gf_algo algo) {
+    return algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK || algo == GF_ALGO_SINGLE_AZ_TIGHTLY_PACK ||
+           algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION;
+}
+
+// Rows of the per-wave multiplicity scratch: enough waves to fill the chip, bounded to 256 MiB.
+int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
+    uint64_t rows = n_decisions < 1024 ? n_decisions : 1024;
+    const uint64_t cap = (UINT64_C(256) << 20) / (4 * (uint64_t)ctx->n_slots);
+    if (rows > cap) rows = cap;
+    if (rows < 1) rows = 1;
+    if (rows <= ctx->cnt_rows && ctx->cnt_slots == ctx->n_slots) return GF_OK;
+    if (rows < ctx->cnt_rows) rows = ctx->cnt_rows;
+    GF_HIP(ctx, hipStreamSynchronize(stream));
+    GF_HIP(ctx, ctx->d_cnt.reserve(rows * ctx->n_slots));
+    GF_HIP(ctx, hipMemsetAsync(ctx->d_cnt.ptr, 0, rows * ctx->n_slots * sizeof(uint32_t), stream));
+    ctx->cnt_rows = (uint32_t)rows;
+    ctx->cnt_slots = ctx->n_slots;
+    return GF_OK;
+}
+
+int launch_zoned(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
+                 uint32_t* d_exec_nodes, uint64_t exec_nodes_len, hipStream_t stream) {
+    if (!ctx->have_sched)
+        return fail(ctx, GF_ERR_STATE, "zone-aware packers compare packing efficiencies: gf_snapshot_set needs the schedulable columns");
+    if (algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "single-az-minimal-fragmentation is not served by the device path yet");
+    const uint64_t half = exec_nodes_len + 1;
+    const uint32_t nz = ctx->n_zones;
+    const uint64_t n_dec = (uint64_t)n_apps * (nz ? nz : 1);
+    GF_HIP(ctx, ctx->d_zres.reserve(n_dec));
+    GF_HIP(ctx, ctx->d_zexec.reserve((nz ? nz : 1) * half));
+    GF_HIP(ctx, ctx->d_zavg.reserve(4 * n_dec));
+    GF_HIP(ctx, ctx->d_avg.reserve(4 * (size_t)n_apps));
+    int rc = ensure_cnt(ctx, n_dec, stream);
+    if (rc != GF_OK) return rc;
+    gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)nz * ctx->zstride, nz, ctx->zstride};
+    gangfit::ZoneBuffers zb{ctx->d_zres.ptr, ctx->d_zexec.ptr, half, ctx->d_zavg.ptr, ctx->d_cnt.ptr, ctx->cnt_rows,
+                            ctx->d_avg.ptr};
+    GF_HIP(ctx, gangfit::launch_fit_zoned(GF_ALGO_TIGHTLY_PACK, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
+                                          reserves_executors(algo), make_table(ctx, ctx->d_snap.ptr), zt,
+                                          slot_eff_tables(ctx, ctx->d_snap.ptr), zb, n_apps, d_apps, d_results,
+                                          d_exec_nodes, ctx->d_scratch.ptr, half, stream));
+    return GF_OK;
+}
+
 int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
            uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
-    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY)
-        return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_algo %d", (int)algo);
     const uint64_t half = exec_nodes_len + 1;
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
+    if (is_zone_algo(algo)) {
+        if (mode != GF_MODE_INDEPENDENT)
+            return fail(ctx, GF_ERR_UNSUPPORTED, "zone-aware packers are served in GF_MODE_INDEPENDENT only");
+        return launch_zoned(ctx, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, stream);
+    }
+    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "gf_algo %d is not served by the device path", (int)algo);
     ScanStats* stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
     if (mode == GF_MODE_INDEPENDENT) {
         GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), n_apps, d_apps, d_results,
@@ -300,6 +380,18 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_ncmax.release();
     ctx->h_ntable.release();
     ctx->h_cmax.release();
+    ctx->d_sched.release();
+    ctx->d_node_tab.release();
+    ctx->d_zmasks.release();
+    ctx->h_zmasks.release();
+    ctx->d_zres.release();
+    ctx->d_zexec.release();
+    ctx->d_zavg.release();
+    ctx->d_avg.release();
+    ctx->d_cnt.release();
+    ctx->d_reserved.release();
+    ctx->d_eff.release();
+    ctx->h_avg.release();
     ctx->d_apps.release();
     ctx->d_results.release();
     ctx->d_exec.release();
@@ -341,6 +433,12 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
             if (av[j][n] >= GF_MAX_ABS_QUANTITY || av[j][n] <= -GF_MAX_ABS_QUANTITY)
                 return fail(ctx, GF_ERR_INVALID, "available[%d][%u] outside (-2^62, 2^62)", j, n);
     ctx->have_sched = sc[0] && sc[1] && sc[2];
+    if (ctx->have_sched)
+        for (int j = 0; j < 3; ++j)
+            for (uint32_t n = 0; n < n_nodes; ++n)
+                if (sc[j][n] < 0 || sc[j][n] >= GF_MAX_ABS_QUANTITY)
+                    return fail(ctx, GF_ERR_INVALID, "schedulable[%d][%u] outside [0, 2^62)", j, n);
+    ctx->zone.clear();
     for (int j = 0; j < 3; ++j) {
         ctx->avail[j].assign(av[j], av[j] + n_nodes);
         if (ctx->have_sched)
@@ -352,6 +450,27 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
     ctx->have_snapshot = true;
     ctx->have_orders = false;
     ctx->work_valid = false;
+    // node-indexed copy for the per-node efficiency map (gf_packing_efficiencies)
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, ctx->d_node_tab.reserve(6 * (size_t)n_nodes + 1));
+    for (int j = 0; j < 3 && n_nodes; ++j) {
+        GF_HIP(ctx, hipMemcpy(ctx->d_node_tab.ptr + (size_t)j * n_nodes, av[j], (size_t)n_nodes * sizeof(int64_t),
+                              hipMemcpyHostToDevice));
+        if (ctx->have_sched)
+            GF_HIP(ctx, hipMemcpy(ctx->d_node_tab.ptr + (size_t)(3 + j) * n_nodes, sc[j],
+                                  (size_t)n_nodes * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    return GF_OK;
+}
+
+int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_zones_set");
+    if (ctx->n_nodes > 0 && !zone_of_node) return fail(ctx, GF_ERR_INVALID, "zone array must not be NULL");
+    ctx->zone.assign(zone_of_node, zone_of_node + ctx->n_nodes);
+    ctx->have_orders = false;  // the zone views are built by gf_orders_set
     return GF_OK;
 }
 
@@ -569,6 +688,71 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     if (n_nodes)
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_node_slot.ptr, nslot, (size_t)n_nodes * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, ctx->stream));
+    // ---- SchedulableResources in slot order (efficiencies); empty slots read 0
+    GF_HIP(ctx, ctx->d_sched.reserve(3 * (size_t)n_slots));
+    if (ctx->have_sched) {
+        // h_table is free again only after the snapshot copy above has completed
+        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int j = 0; j < 3; ++j)
+            for (uint32_t s2 = 0; s2 < n_slots; ++s2)
+                ctx->h_table.ptr[(size_t)j * n_slots + s2] = slot_node[s2] == GF_NO_NODE ? 0 : ctx->sched[j][slot_node[s2]];
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_sched.ptr, ctx->h_table.ptr, 3 * (size_t)n_slots * sizeof(int64_t),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        GF_HIP(ctx, hipMemsetAsync(ctx->d_sched.ptr, 0, 3 * (size_t)n_slots * sizeof(int64_t), ctx->stream));
+    }
+    // ---- zone views (single_az.go:23-72): evaluation list = zones in order of first appearance in the driver order
+    //      that own at least one executor candidate; per zone, candidate masks over the same slot table
+    {
+        auto zone_of = [&](uint32_t n) { return ctx->zone.empty() ? 0u : ctx->zone[n]; };
+        std::vector<uint32_t> zlist;
+        for (uint32_t n : ds) {
+            const uint32_t z = zone_of(n);
+            bool seen = false;
+            for (uint32_t q : zlist) seen = seen || q == z;
+            if (!seen) zlist.push_back(z);
+        }
+        std::vector<uint32_t> eval;
+        for (uint32_t z : zlist) {
+            bool has_x = false;
+            for (uint32_t n : xs)
+                if (zone_of(n) == z) {
+                    has_x = true;
+                    break;
+                }
+            if (has_x) eval.push_back(z);
+        }
+        const uint32_t d_words = (n_d_pos + 63) / 64;
+        const uint32_t zstride = n_chunks > d_words ? n_chunks : d_words;
+        const uint32_t nz = (uint32_t)eval.size();
+        GF_HIP(ctx, ctx->h_zmasks.reserve(2 * (size_t)nz * zstride + 1));
+        GF_HIP(ctx, ctx->d_zmasks.reserve(2 * (size_t)nz * zstride + 1));
+        uint64_t* zx = ctx->h_zmasks.ptr;
+        uint64_t* zd = zx + (size_t)nz * zstride;
+        for (size_t i = 0; i < 2 * (size_t)nz * zstride; ++i) zx[i] = 0;
+        for (uint32_t zi = 0; zi < nz; ++zi) {
+            const uint32_t z = eval[zi];
+            uint64_t* rx = zx + (size_t)zi * zstride;
+            uint64_t* rd = zd + (size_t)zi * zstride;
+            if (mergeable) {
+                for (uint32_t s2 = 0; s2 < merged.size(); ++s2) {
+                    if (zone_of(merged[s2]) != z) continue;
+                    if (mflags[s2] & 1) rx[s2 >> 6] |= 1ull << (s2 & 63);
+                    if (mflags[s2] & 2) rd[s2 >> 6] |= 1ull << (s2 & 63);
+                }
+            } else {
+                for (uint32_t i = 0; i < n_x; ++i)
+                    if (exec_order[i] < n_nodes && zone_of(exec_order[i]) == z) rx[i >> 6] |= 1ull << (i & 63);
+                for (uint32_t i = 0; i < n_d; ++i)  // by driver POSITION (Orders::dpos_mask)
+                    if (driver_order[i] < n_nodes && zone_of(driver_order[i]) == z) rd[i >> 6] |= 1ull << (i & 63);
+            }
+        }
+        if (nz)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_zmasks.ptr, zx, 2 * (size_t)nz * zstride * sizeof(uint64_t),
+                                       hipMemcpyHostToDevice, ctx->stream));
+        ctx->n_zones = nz;
+        ctx->zstride = zstride;
+    }
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_x = n_x_slots;
     ctx->n_d = n_d_pos;
@@ -638,6 +822,100 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
 int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
                      uint64_t exec_nodes_cap) {
     return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);
+}
+
+int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps, const gf_result* results,
+                              const uint32_t* exec_nodes, uint64_t exec_nodes_len, gf_avg_efficiency* out) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_apps > 0 && (!apps || !results || !out)) return fail(ctx, GF_ERR_INVALID, "apps/results/out must not be NULL");
+    if (n_apps == 0) return GF_OK;
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede");
+    if (!ctx->have_sched) return fail(ctx, GF_ERR_STATE, "efficiencies need the schedulable columns of gf_snapshot_set");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    // validate the lists on the host: every placed node must own a slot (it came out of one of the two orders)
+    uint64_t total_k = 0;
+    GF_HIP(ctx, ctx->h_apps.reserve(n_apps));
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        gf_app& o = ctx->h_apps.ptr[a];
+        o = apps[a];
+        if (o.k < 0 || o.k > GF_MAX_K) return fail(ctx, GF_ERR_INVALID, "apps[%u].k out of range", a);
+        o.exec_off = total_k;
+        if (results[a].has_capacity) {
+            const uint32_t d = results[a].driver_node;
+            if (d >= ctx->n_nodes || ctx->h_node_slot[d] == GF_NO_NODE)
+                return fail(ctx, GF_ERR_INVALID, "results[%u].driver_node is not a candidate node", a);
+            if (total_k + (uint64_t)o.k > exec_nodes_len || (o.k > 0 && !exec_nodes))
+                return fail(ctx, GF_ERR_CAPACITY, "exec_nodes too short");
+            for (int32_t i = 0; i < o.k; ++i) {
+                const uint32_t n = exec_nodes[total_k + i];
+                if (n >= ctx->n_nodes || ctx->h_node_slot[n] == GF_NO_NODE)
+                    return fail(ctx, GF_ERR_INVALID, "exec_nodes[%llu] is not a candidate node",
+                                (unsigned long long)(total_k + i));
+            }
+        }
+        total_k += (uint64_t)o.k;
+    }
+    hipStream_t st = ctx->stream;
+    GF_HIP(ctx, ctx->d_apps.reserve(n_apps));
+    GF_HIP(ctx, ctx->d_results.reserve(n_apps));
+    GF_HIP(ctx, ctx->d_exec.reserve(total_k + 1));
+    GF_HIP(ctx, ctx->d_avg.reserve(4 * (size_t)n_apps));
+    GF_HIP(ctx, ctx->h_avg.reserve(4 * (size_t)n_apps));
+    int rc = ensure_cnt(ctx, n_apps, st);
+    if (rc != GF_OK) return rc;
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_results.ptr, results, (size_t)n_apps * sizeof(gf_result), hipMemcpyHostToDevice, st));
+    if (total_k && exec_nodes)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_exec.ptr, exec_nodes, (size_t)(total_k <= exec_nodes_len ? total_k : exec_nodes_len) * sizeof(uint32_t),
+                                   hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, gangfit::launch_avg_efficiency(reserves_executors(algo), make_table(ctx, ctx->d_snap.ptr),
+                                               slot_eff_tables(ctx, ctx->d_snap.ptr), ctx->d_cnt.ptr, ctx->cnt_rows,
+                                               n_apps, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr,
+                                               ctx->d_avg.ptr, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_avg.ptr, ctx->d_avg.ptr, 4 * (size_t)n_apps * sizeof(double), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    static_assert(sizeof(gf_avg_efficiency) == 4 * sizeof(double), "gf_avg_efficiency layout");
+    std::memcpy(out, ctx->h_avg.ptr, 4 * (size_t)n_apps * sizeof(double));
+    return GF_OK;
+}
+
+int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const gf_result* result,
+                            const uint32_t* exec_nodes, double* eff_out) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!app || !result || !eff_out) return fail(ctx, GF_ERR_INVALID, "app/result/eff_out must not be NULL");
+    if (!ctx->have_snapshot || !ctx->have_sched)
+        return fail(ctx, GF_ERR_STATE, "efficiencies need gf_snapshot_set with the schedulable columns");
+    if (app->k < 0 || app->k > GF_MAX_K || (result->has_capacity && app->k > 0 && !exec_nodes))
+        return fail(ctx, GF_ERR_INVALID, "bad k / exec_nodes");
+    const uint32_t n = ctx->n_nodes;
+    if (n == 0) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    GF_HIP(ctx, ctx->d_apps.reserve(1));
+    GF_HIP(ctx, ctx->d_results.reserve(1));
+    GF_HIP(ctx, ctx->d_exec.reserve((size_t)app->k + 1));
+    GF_HIP(ctx, ctx->d_reserved.reserve(3 * (size_t)n));
+    GF_HIP(ctx, ctx->d_eff.reserve(3 * (size_t)n));
+    GF_HIP(ctx, ctx->h_apps.reserve(1));
+    ctx->h_apps.ptr[0] = *app;
+    ctx->h_apps.ptr[0].exec_off = 0;
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, sizeof(gf_app), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_results.ptr, result, sizeof(gf_result), hipMemcpyHostToDevice, st));
+    if (result->has_capacity && app->k > 0)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_exec.ptr, exec_nodes, (size_t)app->k * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    gangfit::EffTables e;
+    for (int j = 0; j < 3; ++j) {
+        e.avail[j] = ctx->d_node_tab.ptr + (size_t)j * n;
+        e.sched[j] = ctx->d_node_tab.ptr + (size_t)(3 + j) * n;
+    }
+    GF_HIP(ctx, gangfit::launch_node_efficiencies(reserves_executors(algo), e, n, app->k, ctx->d_apps.ptr,
+                                                  ctx->d_results.ptr, ctx->d_exec.ptr, ctx->d_reserved.ptr,
+                                                  ctx->d_eff.ptr, st));
+    GF_HIP(ctx, hipMemcpyAsync(eff_out, ctx->d_eff.ptr, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    return GF_OK;
 }
 
 int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {

@@ -40,6 +40,24 @@ struct NodeTable {
     uint32_t d_identity;        // 1: driver position == slot (merged layout)
 };
 
+// Zone view of the two candidate orders for the single-AZ packers (LIB/binpack/single_az.go:23-72): zone zi of the
+// evaluation list keeps only its own nodes of driverNodePriorityOrder / executorNodePriorityOrder, order preserved —
+// i.e. the same slot table scanned through per-zone candidate bit masks.  The evaluation list is driverZonesInOrder
+// (zones by first appearance in the driver order) restricted to zones that own at least one executor candidate (:36-41).
+struct ZoneTable {
+    const uint64_t* xmask;  // [n_zones][stride] executor-candidate bits of each zone (indexed like NodeTable::xmask)
+    const uint64_t* dmask;  // [n_zones][stride] driver-candidate bits: by slot (merged layout) or by driver position (general)
+    uint32_t n_zones;
+    uint32_t stride;        // 64-bit words per zone row
+};
+
+// Node tables the efficiency kernels read (LIB/binpack/efficiency.go:66-156): AvailableResources and
+// SchedulableResources, SoA int64, indexed by slot (hot path) or by the caller's node index (full per-node map).
+struct EffTables {
+    const int64_t* avail[3];
+    const int64_t* sched[3];
+};
+
 // App record as the FIFO-chain kernel consumes it: gf_app + the per-dimension reciprocals of the executor request
 // (prepare_apps_kernel computes them once per launch).  128 bytes = 8 lanes x 16 bytes.
 struct DevApp {
@@ -111,6 +129,37 @@ hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& 
                            uint32_t n_apps, const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps,
                            int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                            uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream);
+
+// Zone-aware packers on an independent batch: one wave per (app, zone) runs SparkBinPack on the zone's view, one wave
+// per decision averages the packing efficiencies of [driver] ++ executors in slice order (chooseBestResult,
+// single_az.go:75-97), one wave per app keeps the first zone with the strictly highest average and writes the final
+// result.  az_aware: apps without a single-zone fit keep the plain tightly-pack answer already in d_results.
+struct ZoneBuffers {
+    gf_result* zres;      // [n_apps * n_zones]
+    uint32_t* zexec;      // [n_zones][zexec_stride] placements as SLOT ids
+    uint64_t zexec_stride;
+    double* zavg;         // [n_apps * n_zones][4]
+    uint32_t* cnt;        // [n_cnt_waves][n_slots] zero between launches: per-wave executor multiplicity scratch
+    uint32_t n_cnt_waves;
+    double* avg_out;      // [n_apps][4] AvgPackingEfficiency of the chosen result (zeros when infeasible); nullable
+};
+hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, const NodeTable& table,
+                            const ZoneTable& zones, const EffTables& eff, const ZoneBuffers& buf, uint32_t n_apps,
+                            const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                            uint64_t scratch_half, hipStream_t stream);
+
+// ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
+// (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.
+hipError_t launch_avg_efficiency(bool reserve_execs, const NodeTable& table, const EffTables& eff, uint32_t* d_cnt,
+                                 uint32_t n_cnt_waves, uint32_t n_apps, const gf_app* d_apps,
+                                 const gf_result* d_results, const uint32_t* d_exec_nodes, double* d_avg_out,
+                                 hipStream_t stream);
+
+// ComputePackingEfficiencies (efficiency.go:66-103) for ONE result: per-node {cpu, memory, gpu} efficiencies in the
+// caller's node-index space (eff tables indexed by node), d_reserved: n_nodes x 3 int64 scratch (zeroed here).
+hipError_t launch_node_efficiencies(bool reserve_execs, const EffTables& eff_by_node, uint32_t n_nodes, int32_t k,
+                                    const gf_app* d_app, const gf_result* d_result, const uint32_t* d_exec_nodes,
+                                    int64_t* d_reserved, double* d_eff_out, hipStream_t stream);
 
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
 // Writes the number of mismatching lanes/cases to *d_mismatch.

@@ -291,6 +291,8 @@ struct Orders {
     uint32_t n_x;
     uint32_t n_d;
     bool d_identity;  // merged layout: driver position == slot, candidates flagged by the dmask bits
+    bool dpos_mask = false;  // general layout: the view's dmask is indexed by driver POSITION and must be consulted
+                             // (zone views; the plain general layout accepts every position)
     __device__ __forceinline__ uint32_t driver_slot(uint32_t i) const { return d_identity ? i : dslot[i]; }
 };
 
@@ -365,7 +367,7 @@ __device__ __forceinline__ int64_t wave_first_fitting_driver(const View& V, cons
     for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool fit = false;
-        if (i < O.n_d) {
+        if (i < O.n_d && (!O.dpos_mask || V.dcand(i))) {
             int64_t a0, a1, a2;
             V.load(O.driver_slot(i), a0, a1, a2);
             fit = driver_fits(a0, a1, a2, app);
@@ -387,7 +389,7 @@ __device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, cons
     for (uint32_t b = from; b < O.n_d; b += kWave) {
         const uint32_t i = b + lane;
         bool ok = false;
-        if (i < O.n_d && (!O.d_identity || V.dcand(i))) {
+        if (i < O.n_d && ((!O.d_identity && !O.dpos_mask) || V.dcand(i))) {
             const uint32_t s = O.driver_slot(i);
             int64_t a0, a1, a2;
             V.load(s, a0, a1, a2);
@@ -1154,6 +1156,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 
 #include "gangfit_fifo_fused.inc"
 #include "gangfit_fifo_narrow.inc"
+#include "gangfit_zones.inc"
 
 // ------------------------------------------------------------------------------------------------ self-test
 
@@ -1372,6 +1375,90 @@ hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& 
     return launch_fifo_algo<GF_ALGO_DISTRIBUTE_EVENLY>(plan, table, ntable, n_apps, d_apps, d_dev_apps, d_napps,
                                                        d_wide_needed, d_results, d_exec_nodes, d_scratch, scratch_half,
                                                        d_chain_failed_at, d_stats, stream);
+}
+
+hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, const NodeTable& table,
+                            const ZoneTable& zones, const EffTables& eff, const ZoneBuffers& buf, uint32_t n_apps,
+                            const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                            uint64_t scratch_half, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    if (inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
+    const dim3 block(kWave * kWavesPerBlock);
+    const dim3 app_grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipError_t e = hipSuccess;
+    if (az_aware) {  // the plain TightlyPack answer first; the select kernel overwrites it where a zone wins
+        e = launch_fit_independent(GF_ALGO_TIGHTLY_PACK, table, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
+                                   scratch_half, nullptr, stream);
+        if (e != hipSuccess) return e;
+        if (buf.avg_out != nullptr) {
+            e = launch_avg_efficiency(true, table, eff, buf.cnt, buf.n_cnt_waves, n_apps, d_apps, d_results,
+                                      d_exec_nodes, buf.avg_out, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    if (zones.n_zones > 0) {
+        const uint64_t n_dec = (uint64_t)n_apps * zones.n_zones;
+        const dim3 dec_grid((unsigned)((n_dec + kWavesPerBlock - 1) / kWavesPerBlock));
+        hipLaunchKernelGGL(fit_zoned_kernel<GF_ALGO_TIGHTLY_PACK>, dec_grid, block, 0, stream, table, zones, n_apps,
+                           d_apps, buf.zres, buf.zexec, buf.zexec_stride, d_scratch, scratch_half);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        const dim3 eff_grid((buf.n_cnt_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+        if (reserve_execs)
+            hipLaunchKernelGGL((avg_efficiency_kernel<true, true>), eff_grid, block, 0, stream, eff, table.node_slot,
+                               table.n_slots, zones.n_zones, n_apps, d_apps, (const gf_result*)buf.zres,
+                               (const uint32_t*)buf.zexec, buf.zexec_stride, buf.cnt, buf.n_cnt_waves, buf.zavg);
+        else
+            hipLaunchKernelGGL((avg_efficiency_kernel<false, true>), eff_grid, block, 0, stream, eff, table.node_slot,
+                               table.n_slots, zones.n_zones, n_apps, d_apps, (const gf_result*)buf.zres,
+                               (const uint32_t*)buf.zexec, buf.zexec_stride, buf.cnt, buf.n_cnt_waves, buf.zavg);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (az_aware)
+        hipLaunchKernelGGL(zone_select_kernel<true>, app_grid, block, 0, stream, table.slot_node, zones.n_zones, n_apps,
+                           d_apps, (const gf_result*)buf.zres, (const uint32_t*)buf.zexec, buf.zexec_stride,
+                           (const double*)buf.zavg, d_results, d_exec_nodes, buf.avg_out);
+    else
+        hipLaunchKernelGGL(zone_select_kernel<false>, app_grid, block, 0, stream, table.slot_node, zones.n_zones, n_apps,
+                           d_apps, (const gf_result*)buf.zres, (const uint32_t*)buf.zexec, buf.zexec_stride,
+                           (const double*)buf.zavg, d_results, d_exec_nodes, buf.avg_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_avg_efficiency(bool reserve_execs, const NodeTable& table, const EffTables& eff, uint32_t* d_cnt,
+                                 uint32_t n_cnt_waves, uint32_t n_apps, const gf_app* d_apps,
+                                 const gf_result* d_results, const uint32_t* d_exec_nodes, double* d_avg_out,
+                                 hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    const dim3 block(kWave * kWavesPerBlock);
+    const dim3 grid((n_cnt_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (reserve_execs)
+        hipLaunchKernelGGL((avg_efficiency_kernel<true, false>), grid, block, 0, stream, eff, table.node_slot,
+                           table.n_slots, 1u, n_apps, d_apps, d_results, d_exec_nodes, (uint64_t)0, d_cnt, n_cnt_waves,
+                           d_avg_out);
+    else
+        hipLaunchKernelGGL((avg_efficiency_kernel<false, false>), grid, block, 0, stream, eff, table.node_slot,
+                           table.n_slots, 1u, n_apps, d_apps, d_results, d_exec_nodes, (uint64_t)0, d_cnt, n_cnt_waves,
+                           d_avg_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_node_efficiencies(bool reserve_execs, const EffTables& eff_by_node, uint32_t n_nodes, int32_t k,
+                                    const gf_app* d_app, const gf_result* d_result, const uint32_t* d_exec_nodes,
+                                    int64_t* d_reserved, double* d_eff_out, hipStream_t stream) {
+    if (n_nodes == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_reserved, 0, 3 * (size_t)n_nodes * sizeof(int64_t), stream);
+    if (e != hipSuccess) return e;
+    const unsigned k_blocks = (unsigned)(((k > 0 ? k : 1) + 255) / 256);
+    if (reserve_execs)
+        hipLaunchKernelGGL(reserved_scatter_kernel<true>, dim3(k_blocks), dim3(256), 0, stream, d_app, d_result,
+                           d_exec_nodes, n_nodes, reinterpret_cast<unsigned long long*>(d_reserved));
+    else
+        hipLaunchKernelGGL(reserved_scatter_kernel<false>, dim3(1), dim3(64), 0, stream, d_app, d_result, d_exec_nodes,
+                           n_nodes, reinterpret_cast<unsigned long long*>(d_reserved));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(node_efficiency_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, eff_by_node, n_nodes,
+                       (const int64_t*)d_reserved, d_eff_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest(uint64_t seed, uint32_t n_cases, uint32_t* d_mismatch, hipStream_t stream) {

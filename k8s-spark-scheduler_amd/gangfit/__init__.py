@@ -6,7 +6,11 @@ libgangfit_host.so (host/: C++ mirror of the reference's plug-in interface).
 """
 from . import _native, build, workloads  # noqa: F401
 from ._native import (  # noqa: F401
+    GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
     GF_ALGO_DISTRIBUTE_EVENLY,
+    GF_ALGO_MINIMAL_FRAGMENTATION,
+    GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION,
+    GF_ALGO_SINGLE_AZ_TIGHTLY_PACK,
     GF_ALGO_TIGHTLY_PACK,
     GF_APP_SKIPPABLE,
     GF_MODE_FIFO_CHAIN,

@@ -20,6 +20,10 @@ GF_NO_NODE = 0xFFFFFFFF
 GF_MAX_K = 1 << 20
 GF_ALGO_TIGHTLY_PACK = 0
 GF_ALGO_DISTRIBUTE_EVENLY = 1
+GF_ALGO_MINIMAL_FRAGMENTATION = 2
+GF_ALGO_AZ_AWARE_TIGHTLY_PACK = 3
+GF_ALGO_SINGLE_AZ_TIGHTLY_PACK = 4
+GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION = 5
 GF_MODE_INDEPENDENT = 0
 GF_MODE_FIFO_CHAIN = 1
 GF_APP_SKIPPABLE = 1
@@ -36,7 +40,7 @@ assert APP_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
 EXPORTED_SYMBOLS = [
     "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch",
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats",
-    "gf_selftest", "gf_device_info_get",
+    "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
 ]
 
 
@@ -95,6 +99,12 @@ def load() -> C.CDLL:
     L.gf_fit_batch_dev.argtypes = [p, i32, i32, u32, p, p, p, u64, p, p]
     L.gf_spark_binpack.restype = i32
     L.gf_spark_binpack.argtypes = [p, i32, p, p, p, u64]
+    L.gf_zones_set.restype = i32
+    L.gf_zones_set.argtypes = [p, p]
+    L.gf_avg_packing_efficiency.restype = i32
+    L.gf_avg_packing_efficiency.argtypes = [p, i32, u32, p, p, p, u64, p]
+    L.gf_packing_efficiencies.restype = i32
+    L.gf_packing_efficiencies.argtypes = [p, i32, p, p, p, p]
     L.gf_residual_get.restype = i32
     L.gf_residual_get.argtypes = [p, p]
     L.gf_timer_begin.restype = i32

@@ -34,7 +34,8 @@ def _stale(target: str, deps) -> bool:
 def build_native(force: bool = False, extra_flags=()) -> str:
     """hipcc --offload-arch=gfx950 ... -> k8s-spark-scheduler_amd/libgangfit.so"""
     srcs = [os.path.join(CSRC, s) for s in _SOURCES]
-    if force or extra_flags or _stale(LIB_PATH, srcs + _HEADERS):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + _HEADERS  # .inc files are #included by the .hip
+    if force or extra_flags or _stale(LIB_PATH, deps):
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
                *extra_flags, *srcs, "-o", LIB_PATH]
         subprocess.check_call(cmd)

@@ -98,6 +98,12 @@ class Context:
         self._check(self._lib.gf_snapshot_set(self._h, len(avail), *[N.ptr(c) for c in cols], *[N.ptr(c) for c in scols]))
         self.n_nodes = len(avail)
 
+    def set_zones(self, zone_of_node):
+        """Zone id per node (after set_snapshot, before set_orders)."""
+        z = np.ascontiguousarray(zone_of_node, dtype=np.uint32)
+        assert len(z) == self.n_nodes
+        self._check(self._lib.gf_zones_set(self._h, N.ptr(z)))
+
     def set_orders(self, driver_order, exec_order):
         d = np.ascontiguousarray(driver_order, dtype=np.uint32)
         x = np.ascontiguousarray(exec_order, dtype=np.uint32)
@@ -122,6 +128,27 @@ class Context:
         self._check(self._lib.gf_spark_binpack(self._h, algo, N.ptr(app), N.ptr(res), N.ptr(out), k))
         n = int(res[0]["exec_len"])
         return bool(res[0]["has_capacity"]), int(res[0]["driver_node"]), out[:n].copy()
+
+    def avg_packing_efficiency(self, algo: int, apps: np.ndarray, out: BatchOut) -> np.ndarray:
+        """(A, 4) float64 [CPU, Memory, GPU, Max]: ComputeAvgPackingEfficiency over [driver] ++ executors per result."""
+        apps_off, total_k = with_offsets(np.ascontiguousarray(apps, dtype=N.APP_DTYPE))
+        res = np.ascontiguousarray(out.results)
+        ex = np.ascontiguousarray(out.exec_nodes, dtype=np.uint32)
+        avg = np.zeros((len(apps_off), 4), dtype=np.float64)
+        self._check(self._lib.gf_avg_packing_efficiency(self._h, algo, len(apps_off), N.ptr(apps_off), N.ptr(res),
+                                                        N.ptr(ex) if len(ex) else None, len(ex), N.ptr(avg)))
+        return avg
+
+    def packing_efficiencies(self, algo: int, drv, exe, driver_node: int, exec_nodes) -> np.ndarray:
+        """(n_nodes, 3) float64 per-node efficiencies of one result (PackingResult.PackingEfficiencies)."""
+        app = make_apps([drv], [exe], [len(exec_nodes)])
+        res = np.zeros(1, dtype=N.RESULT_DTYPE)
+        res[0] = (1, driver_node, len(exec_nodes), 1)
+        ex = np.ascontiguousarray(exec_nodes, dtype=np.uint32)
+        eff = np.zeros((self.n_nodes, 3), dtype=np.float64)
+        self._check(self._lib.gf_packing_efficiencies(self._h, algo, N.ptr(app), N.ptr(res),
+                                                      N.ptr(ex) if len(ex) else None, N.ptr(eff)))
+        return eff
 
     def residual(self) -> np.ndarray:
         out = np.zeros((self.n_nodes, 3), dtype=np.int64)

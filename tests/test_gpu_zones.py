@@ -1,0 +1,168 @@
+"""GPU parity of the zone-aware packers (single-az-tightly-pack, az-aware-tightly-pack) and of the packing efficiencies
+(float64, BIT-identical: chooseBestResult compares them) against the CPU oracle.  `python -m pytest tests -m gpu`."""
+import numpy as np
+import pytest
+
+import gangfit
+import kats
+from gangfit import workloads as wl
+from oracle import binding as ob
+from test_gpu_parity import _assert_same, _random_problem
+
+pytestmark = pytest.mark.gpu
+
+IND = gangfit.GF_MODE_INDEPENDENT
+TIGHT, EVEN = gangfit.GF_ALGO_TIGHTLY_PACK, gangfit.GF_ALGO_DISTRIBUTE_EVENLY
+SAZ, AZA = gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.GF_ALGO_AZ_AWARE_TIGHTLY_PACK
+O_ALGO = {SAZ: ob.ALGO_SINGLE_AZ_TIGHTLY_PACK, AZA: ob.ALGO_AZ_AWARE_TIGHTLY_PACK, TIGHT: 0, EVEN: 1}
+GIB = kats.GIB
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _setup(ctx, avail, sched, zone, D, X):
+    ctx.set_snapshot(avail, sched)
+    if zone is not None:
+        ctx.set_zones(zone)
+    ctx.set_orders(D, X)
+
+
+@pytest.mark.parametrize("case", kats.REFERENCE_PINNED, ids=[c["name"] for c in kats.REFERENCE_PINNED])
+def test_reference_tests_through_single_az_tightly_pack(gf_ctx, case):
+    """T1/T3/T4 of the reference select `single-az-tightly-pack` (one zone "default")."""
+    avail = np.array(case["avail"], dtype=np.int64)
+    _setup(gf_ctx, avail, avail, None, case["D"], case["X"])
+    ok, d, ex = gf_ctx.spark_binpack(SAZ, case["drv"], case["exe"], case["k"])
+    assert ok == case["feasible"]
+    if ok:
+        assert d == case["driver"] and ex.tolist() == case["execs"]
+    else:
+        assert d == gangfit.GF_NO_NODE and len(ex) == 0
+
+
+def test_zone_choice_and_tie_break(gf_ctx):
+    sched = [[16000, 64 * GIB, 0], [16000, 64 * GIB, 0], [8000, 16 * GIB, 0]]
+    avail = [[16000, 64 * GIB, 0], [16000, 64 * GIB, 0], [4000, 8 * GIB, 0]]
+    _setup(gf_ctx, avail, sched, [0, 0, 1], [0, 1, 2], [0, 1, 2])
+    ok, d, ex = gf_ctx.spark_binpack(SAZ, [1000, GIB, 0], [1000, GIB, 0], 2)
+    assert ok and d == 2 and ex.tolist() == [2, 2]  # zone 1: average Max 7/8 beats zone 0's 3/16
+    sched2 = [[8000, 16 * GIB, 0], [8000, 16 * GIB, 0]]
+    avail2 = [[4000, 8 * GIB, 0], [4000, 8 * GIB, 0]]
+    _setup(gf_ctx, avail2, sched2, [5, 9], [1, 0], [0, 1])
+    ok, d, ex = gf_ctx.spark_binpack(SAZ, [1000, GIB, 0], [1000, GIB, 0], 2)
+    assert ok and d == 1 and ex.tolist() == [1, 1]  # tie: first zone of the DRIVER order
+    # no single zone fits; az-aware falls back to plain tightly-pack
+    sched3 = [[4000, 8 * GIB, 0], [4000, 8 * GIB, 0]]
+    avail3 = [[2000, 8 * GIB, 0], [2000, 8 * GIB, 0]]
+    _setup(gf_ctx, avail3, sched3, [0, 1], [0, 1], [0, 1])
+    assert not gf_ctx.spark_binpack(SAZ, [1000, GIB, 0], [1000, GIB, 0], 2)[0]
+    ok, d, ex = gf_ctx.spark_binpack(AZA, [1000, GIB, 0], [1000, GIB, 0], 2)
+    assert ok and d == 0 and ex.tolist() == [0, 1]
+    # a feasible zone result with average 0.0 is not better than WorstAvgPackingEfficiency -> empty result
+    full = [[4000, 8 * GIB, 0], [4000, 8 * GIB, 0]]
+    _setup(gf_ctx, full, full, [0, 0], [0, 1], [0, 1])
+    assert not gf_ctx.spark_binpack(SAZ, [0, 0, 0], [0, 0, 0], 2)[0]
+    # zones need the schedulable columns
+    gf_ctx.set_snapshot(full)
+    gf_ctx.set_orders([0, 1], [0, 1])
+    with pytest.raises(gangfit.GangfitError):
+        gf_ctx.spark_binpack(SAZ, [1, 1, 0], [1, 1, 0], 1)
+
+
+def _zoned_problem(rng, n, a, tight_cluster, layout, n_zones):
+    avail, D, X, drv, exe, k = _random_problem(rng, n, a, tight_cluster, layout)
+    extra = rng.integers(0, 50 if tight_cluster else 5000, size=(n, 3)).astype(np.int64)
+    sched = np.maximum(avail, 0) + extra  # some nodes with sched == 0 in a dimension, some unused, some overcommitted
+    sched[rng.random(n) < 0.1] = 0
+    sched[:, 0] *= 250  # cpu in quarter cores: Value() rounding away from zero matters
+    avail = avail.copy()
+    avail[:, 0] *= 250
+    drv = drv.copy()
+    exe = exe.copy()
+    drv[:, 0] *= 250
+    exe[:, 0] *= 250
+    zone = rng.integers(0, n_zones, size=n).astype(np.uint32) * 7 + 3  # ids need not be dense
+    return avail, sched, zone, D, X, drv, exe, k
+
+
+@pytest.mark.parametrize("layout", ["general", "merged", "identical"])
+@pytest.mark.parametrize("algo", [SAZ, AZA])
+@pytest.mark.parametrize("n", [1, 2, 64, 65, 200, 1000])
+def test_zoned_independent_batch_random(gf_ctx, algo, n, layout):
+    rng = np.random.default_rng(31 * algo + n + 5 * len(layout))
+    seen_feasible = False
+    for tight_cluster in (True, False):
+        for n_zones in (1, 3):
+            a = 130
+            avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, n, a, tight_cluster, layout, n_zones)
+            _setup(gf_ctx, avail, sched, zone, D, X)
+            apps = gangfit.make_apps(drv, exe, k)
+            gpu = gf_ctx.fit_batch(IND, algo, apps)
+            ref = ob.fit_independent(O_ALGO[algo], avail, ob.make_apps(drv, exe, k), D, X, closed_form=True,
+                                     sched=sched, zone=zone)
+            _assert_same(gpu, ref, apps)
+            # the averages chooseBestResult compared, bit for bit
+            avg = gf_ctx.avg_packing_efficiency(algo, apps, gpu)
+            assert np.array_equal(_bits(avg), _bits(ref.avg_eff))
+            seen_feasible = seen_feasible or bool(ref.results["has_capacity"].any())
+    if n >= 64:
+        assert seen_feasible
+
+
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_avg_efficiency_of_plain_packers_bit_exact(gf_ctx, algo):
+    rng = np.random.default_rng(77 + algo)
+    for layout in ("merged", "general"):
+        avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, 700, 200, False, layout, 1)
+        k = np.minimum(k, 400)
+        _setup(gf_ctx, avail, sched, None, D, X)
+        apps = gangfit.make_apps(drv, exe, k)
+        gpu = gf_ctx.fit_batch(IND, algo, apps)
+        ref = ob.fit_independent(algo, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True, sched=sched)
+        _assert_same(gpu, ref, apps)
+        avg = gf_ctx.avg_packing_efficiency(algo, apps, gpu)
+        assert np.array_equal(_bits(avg), _bits(ref.avg_eff))
+        assert ref.results["has_capacity"].any()
+        # minimal-fragmentation flavour of the same lists: `reserved` holds the driver only
+        a0 = int(np.nonzero(ref.results["has_capacity"])[0][0])
+        _, d, ex = ref.placement(a0)
+        want = ob.avg_packing_efficiency_list(avail, sched, drv[a0], exe[a0], d, ex, reserved_includes_executors=False)
+        got = gf_ctx.avg_packing_efficiency(gangfit.GF_ALGO_MINIMAL_FRAGMENTATION, apps[a0:a0 + 1],
+                                            gangfit.BatchOut(gpu.results[a0:a0 + 1], np.zeros(1, dtype=np.uint64), ex))
+        assert np.array_equal(_bits(got[0]), _bits(want))
+
+
+def test_per_node_efficiency_map_bit_exact(gf_ctx):
+    rng = np.random.default_rng(5)
+    avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, 900, 40, False, "merged", 1)
+    big = np.int64(1) << 61  # huge quantities: int64 -> float64 conversions must round like the reference's
+    sched[:20, 1] += big
+    avail[:20, 1] += big - rng.integers(0, 1 << 40, size=20)
+    _setup(gf_ctx, avail, sched, None, D, X)
+    ref = ob.fit_independent(0, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True)
+    checked = 0
+    for a in np.nonzero(ref.results["has_capacity"])[0][:6]:
+        _, d, ex = ref.placement(int(a))
+        want, _ = ob.packing_efficiency(avail, sched, drv[a], exe[a], d, ex)
+        got = gf_ctx.packing_efficiencies(TIGHT, drv[a], exe[a], d, ex)
+        assert np.array_equal(_bits(got), _bits(want))
+        checked += 1
+    assert checked > 0
+
+
+def test_headline_size_single_az(gf_ctx):
+    """10 000 nodes x 1 000 apps, 3 zones, against the closed-form oracle."""
+    w = wl.headline(10000, 1000)
+    s = w.snapshot
+    zone = (wl.splitmix64(0xA2, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+    _setup(gf_ctx, s.avail, s.sched, zone, s.driver_order, s.exec_order)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k)
+    for algo in (SAZ, AZA):
+        gpu = gf_ctx.fit_batch(IND, algo, apps)
+        ref = ob.fit_independent(O_ALGO[algo], s.avail, ob.make_apps(w.drv, w.exe, w.k), s.driver_order,
+                                 s.exec_order, closed_form=True, sched=s.sched, zone=zone)
+        _assert_same(gpu, ref, apps)
+        assert np.array_equal(_bits(gf_ctx.avg_packing_efficiency(algo, apps, gpu)), _bits(ref.avg_eff))
+        assert ref.results["has_capacity"].mean() > 0.5
