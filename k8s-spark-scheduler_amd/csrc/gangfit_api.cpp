@@ -218,8 +218,8 @@ int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
     return GF_OK;
 }
 
-int launch_zoned(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
-                 uint32_t* d_exec_nodes, uint64_t exec_nodes_len, hipStream_t stream) {
+int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
+                 uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
     if (!ctx->have_sched)
         return fail(ctx, GF_ERR_STATE, "zone-aware packers compare packing efficiencies: gf_snapshot_set needs the schedulable columns");
     if (algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)
@@ -228,14 +228,27 @@ int launch_zoned(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_app
     const uint32_t nz = ctx->n_zones;
     const uint64_t n_dec = (uint64_t)n_apps * (nz ? nz : 1);
     GF_HIP(ctx, ctx->d_zres.reserve(n_dec));
-    GF_HIP(ctx, ctx->d_zexec.reserve((nz ? nz : 1) * half));
+    GF_HIP(ctx, ctx->d_zexec.reserve(((uint64_t)nz + 1) * half));
     GF_HIP(ctx, ctx->d_zavg.reserve(4 * n_dec));
     GF_HIP(ctx, ctx->d_avg.reserve(4 * (size_t)n_apps));
-    int rc = ensure_cnt(ctx, n_dec, stream);
+    int rc = ensure_cnt(ctx, n_dec < 16 ? 16 : n_dec, stream);
     if (rc != GF_OK) return rc;
     gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)nz * ctx->zstride, nz, ctx->zstride};
     gangfit::ZoneBuffers zb{ctx->d_zres.ptr, ctx->d_zexec.ptr, half, ctx->d_zavg.ptr, ctx->d_cnt.ptr, ctx->cnt_rows,
                             ctx->d_avg.ptr};
+    if (mode == GF_MODE_FIFO_CHAIN) {
+        if (nz + 1 > 64) return fail(ctx, GF_ERR_UNSUPPORTED, "more than 63 zones in a FIFO chain");
+        if (ctx->cnt_rows < 16) return fail(ctx, GF_ERR_HIP, "multiplicity scratch too small");
+        // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                   hipMemcpyDeviceToDevice, stream));
+        ctx->work_valid = true;
+        GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_TIGHTLY_PACK, true, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
+                                                     reserves_executors(algo), make_table(ctx, ctx->d_work.ptr), zt,
+                                                     ctx->d_sched.ptr, zb, n_apps, d_apps, d_results, d_exec_nodes,
+                                                     ctx->d_scratch.ptr, half, d_failed, stream));
+        return GF_OK;
+    }
     GF_HIP(ctx, gangfit::launch_fit_zoned(GF_ALGO_TIGHTLY_PACK, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
                                           reserves_executors(algo), make_table(ctx, ctx->d_snap.ptr), zt,
                                           slot_eff_tables(ctx, ctx->d_snap.ptr), zb, n_apps, d_apps, d_results,
@@ -249,9 +262,9 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     const uint64_t half = exec_nodes_len + 1;
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
     if (is_zone_algo(algo)) {
-        if (mode != GF_MODE_INDEPENDENT)
-            return fail(ctx, GF_ERR_UNSUPPORTED, "zone-aware packers are served in GF_MODE_INDEPENDENT only");
-        return launch_zoned(ctx, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, stream);
+        if (mode != GF_MODE_INDEPENDENT && mode != GF_MODE_FIFO_CHAIN)
+            return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
+        return launch_zoned(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_failed, stream);
     }
     if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY)
         return fail(ctx, GF_ERR_UNSUPPORTED, "gf_algo %d is not served by the device path", (int)algo);

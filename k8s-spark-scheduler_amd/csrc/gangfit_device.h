@@ -148,6 +148,15 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
                             const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                             uint64_t scratch_half, hipStream_t stream);
 
+// FIFO chain for any packer (zone-aware ones included): one workgroup, one wavefront per candidate view of the current
+// app (each zone, plus the plain pack for az-aware), working table in global memory.  buf.zexec needs
+// (n_zones + 1) rows, buf.cnt at least 16 rows.  Writes final results / placements as node indices.
+hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bool reserve_execs, const NodeTable& table,
+                                   const ZoneTable& zones, const int64_t* d_sched, const ZoneBuffers& buf,
+                                   uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
+                                   uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
+                                   hipStream_t stream);
+
 // ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
 // (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.
 hipError_t launch_avg_efficiency(bool reserve_execs, const NodeTable& table, const EffTables& eff, uint32_t* d_cnt,

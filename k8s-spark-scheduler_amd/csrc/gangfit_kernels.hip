@@ -1424,6 +1424,39 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
     return hipGetLastError();
 }
 
+hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bool reserve_execs, const NodeTable& table,
+                                   const ZoneTable& zones, const int64_t* d_sched, const ZoneBuffers& buf,
+                                   uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
+                                   uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
+                                   hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    const uint32_t n_cand = zoned ? zones.n_zones + (az_aware ? 1u : 0u) : 1u;
+    if (n_cand > 64) return hipErrorInvalidValue;
+    const uint32_t n_waves = n_cand < 1 ? 1 : (n_cand > 16 ? 16 : n_cand);
+    const dim3 grid(1), block(kWave * n_waves);
+#define GF_GEN(ALGO, ZO, AZ, RE)                                                                                        \
+    hipLaunchKernelGGL((fit_fifo_generic_kernel<ALGO, ZO, AZ, RE>), grid, block, 0, stream, table, zones, d_sched, n_apps, \
+                       d_apps, d_results, d_exec_nodes, buf.zexec, buf.zexec_stride, d_scratch, scratch_half, buf.cnt,  \
+                       d_chain_failed_at)
+    if (!zoned) {
+        if (inner_algo == GF_ALGO_TIGHTLY_PACK)
+            GF_GEN(GF_ALGO_TIGHTLY_PACK, false, false, true);
+        else if (inner_algo == GF_ALGO_DISTRIBUTE_EVENLY)
+            GF_GEN(GF_ALGO_DISTRIBUTE_EVENLY, false, false, true);
+        else
+            return hipErrorInvalidValue;
+    } else {
+        if (inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
+        (void)reserve_execs;
+        if (az_aware)
+            GF_GEN(GF_ALGO_TIGHTLY_PACK, true, true, true);
+        else
+            GF_GEN(GF_ALGO_TIGHTLY_PACK, true, false, true);
+    }
+#undef GF_GEN
+    return hipGetLastError();
+}
+
 hipError_t launch_avg_efficiency(bool reserve_execs, const NodeTable& table, const EffTables& eff, uint32_t* d_cnt,
                                  uint32_t n_cnt_waves, uint32_t n_apps, const gf_app* d_apps,
                                  const gf_result* d_results, const uint32_t* d_exec_nodes, double* d_avg_out,

@@ -166,3 +166,41 @@ def test_headline_size_single_az(gf_ctx):
         _assert_same(gpu, ref, apps)
         assert np.array_equal(_bits(gf_ctx.avg_packing_efficiency(algo, apps, gpu)), _bits(ref.avg_eff))
         assert ref.results["has_capacity"].mean() > 0.5
+
+
+@pytest.mark.parametrize("layout", ["general", "merged", "identical"])
+@pytest.mark.parametrize("algo", [SAZ, AZA])
+@pytest.mark.parametrize("n", [3, 64, 300, 1500])
+def test_zoned_fifo_chain_random(gf_ctx, algo, n, layout):
+    """fitEarlierDrivers with a zone-aware packer: every earlier driver commits the zone chooseBestResult picked."""
+    rng = np.random.default_rng(13 * algo + n + 3 * len(layout))
+    for rep in range(3):
+        a = 90
+        avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, n, a, rep == 2, layout, 1 + rep)
+        exe = np.maximum(exe, 1)
+        k = np.minimum(k, 40).astype(np.int32)
+        flags = (rng.random(a) < (0.9 if rep else 1.0)).astype(np.uint32)
+        _setup(gf_ctx, avail, sched, zone, D, X)
+        apps = gangfit.make_apps(drv, exe, k, flags)
+        gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps)
+        ref = ob.fit_fifo_chain(O_ALGO[algo], avail, ob.make_apps(drv, exe, k, flags), D, X, closed_form=True,
+                                sched=sched, zone=zone)
+        assert gpu.failed_at == ref.failed_at
+        _assert_same(gpu, ref, apps)
+        assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+
+
+def test_zoned_fifo_chain_headline_shape(gf_ctx):
+    """C5-shaped chain (999 earlier drivers + 1) at 10 000 nodes, 3 zones, single-az-tightly-pack."""
+    w = wl.headline(10000, 1000)
+    s = w.snapshot
+    zone = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+    _setup(gf_ctx, s.avail, s.sched, zone, s.driver_order, s.exec_order)
+    flags = np.ones(len(w.k), dtype=np.uint32)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, flags)
+    gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, SAZ, apps)
+    ref = ob.fit_fifo_chain(O_ALGO[SAZ], s.avail, ob.make_apps(w.drv, w.exe, w.k, flags), s.driver_order, s.exec_order,
+                            closed_form=True, sched=s.sched, zone=zone)
+    assert gpu.failed_at == ref.failed_at
+    _assert_same(gpu, ref, apps)
+    assert np.array_equal(gf_ctx.residual(), ref.avail_after)
