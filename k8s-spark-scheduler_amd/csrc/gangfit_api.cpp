@@ -222,8 +222,7 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
                  uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
     if (!ctx->have_sched)
         return fail(ctx, GF_ERR_STATE, "zone-aware packers compare packing efficiencies: gf_snapshot_set needs the schedulable columns");
-    if (algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)
-        return fail(ctx, GF_ERR_UNSUPPORTED, "single-az-minimal-fragmentation is not served by the device path yet");
+    const int inner = algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ? GF_ALGO_MINIMAL_FRAGMENTATION : GF_ALGO_TIGHTLY_PACK;
     const uint64_t half = exec_nodes_len + 1;
     const uint32_t nz = ctx->n_zones;
     const uint64_t n_dec = (uint64_t)n_apps * (nz ? nz : 1);
@@ -243,13 +242,13 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
-        GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_TIGHTLY_PACK, true, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
+        GF_HIP(ctx, gangfit::launch_fit_fifo_generic(inner, true, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
                                                      reserves_executors(algo), make_table(ctx, ctx->d_work.ptr), zt,
                                                      ctx->d_sched.ptr, zb, n_apps, d_apps, d_results, d_exec_nodes,
                                                      ctx->d_scratch.ptr, half, d_failed, stream));
         return GF_OK;
     }
-    GF_HIP(ctx, gangfit::launch_fit_zoned(GF_ALGO_TIGHTLY_PACK, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
+    GF_HIP(ctx, gangfit::launch_fit_zoned(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
                                           reserves_executors(algo), make_table(ctx, ctx->d_snap.ptr), zt,
                                           slot_eff_tables(ctx, ctx->d_snap.ptr), zb, n_apps, d_apps, d_results,
                                           d_exec_nodes, ctx->d_scratch.ptr, half, stream));
@@ -266,8 +265,21 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
             return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
         return launch_zoned(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_failed, stream);
     }
-    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY)
+    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY && algo != GF_ALGO_MINIMAL_FRAGMENTATION)
         return fail(ctx, GF_ERR_UNSUPPORTED, "gf_algo %d is not served by the device path", (int)algo);
+    if (algo == GF_ALGO_MINIMAL_FRAGMENTATION && mode == GF_MODE_FIFO_CHAIN) {
+        // the generic chain kernel (one candidate view, one wavefront) against the working table in global memory
+        GF_HIP(ctx, ctx->d_zexec.reserve(half));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                   hipMemcpyDeviceToDevice, stream));
+        ctx->work_valid = true;
+        gangfit::ZoneTable zt{nullptr, nullptr, 0, 0};
+        gangfit::ZoneBuffers zb{nullptr, ctx->d_zexec.ptr, half, nullptr, nullptr, 0, nullptr};
+        GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_MINIMAL_FRAGMENTATION, false, false, false,
+                                                     make_table(ctx, ctx->d_work.ptr), zt, nullptr, zb, n_apps, d_apps,
+                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, stream));
+        return GF_OK;
+    }
     ScanStats* stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
     if (mode == GF_MODE_INDEPENDENT) {
         GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), n_apps, d_apps, d_results,

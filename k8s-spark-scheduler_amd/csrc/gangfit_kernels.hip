@@ -552,6 +552,8 @@ __device__ __forceinline__ int64_t wave_even_general(const View& V, const Orders
     return S;
 }
 
+#include "gangfit_minfrag.inc"
+
 struct Decision {
     bool feasible;
     uint32_t ds;    // driver slot
@@ -564,6 +566,7 @@ __device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, con
                                              uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
                                              unsigned long long& xvis) {
     if (ALGO == GF_ALGO_TIGHTLY_PACK) return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis);
+    if (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) return wave_minfrag<View, SLOTS>(V, O, app, ds, out, lane, xvis);
     pass1 = wave_even_pass1<View, SLOTS>(V, O, app, ds, out, scratch_a, lane, xvis);
     if (pass1 >= (int64_t)app.k) return pass1;
     return wave_even_general<View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, pass1, lane);
@@ -643,15 +646,17 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
     // out[] was written by other lanes of this wave: make it visible before re-reading it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const int64_t first_region = (ALGO == GF_ALGO_TIGHTLY_PACK) ? K : (dec.pass1 < K ? dec.pass1 : K);
+    // tightly-pack and minimal-fragmentation placements are node-major runs (every node occupies ONE run)
+    constexpr bool kRuns = ALGO != GF_ALGO_DISTRIBUTE_EVENLY;
+    const int64_t first_region = kRuns ? K : (dec.pass1 < K ? dec.pass1 : K);
     for (int64_t b = 0; b < K; b += kWave) {
         const int64_t i = b + lane;
         bool first = false;
         uint32_t s = GF_NO_NODE;
         if (i < K) {
             s = out[i];
-            if (ALGO == GF_ALGO_TIGHTLY_PACK)
-                first = (i == 0) || (out[i - 1] != s);  // placements are node-major runs
+            if (kRuns)
+                first = (i == 0) || (out[i - 1] != s);
             else
                 first = i < first_region;  // pass 1 lists every executor node exactly once
         }
@@ -1232,6 +1237,9 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
     if (algo == GF_ALGO_TIGHTLY_PACK)
         hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_TIGHTLY_PACK>, grid, block, 0, stream, table, n_apps,
                            d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
+    else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, grid, block, 0, stream, table, n_apps,
+                           d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
     else
         hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, grid, block, 0, stream, table, n_apps,
                            d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
@@ -1382,7 +1390,8 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
                             const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                             uint64_t scratch_half, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
-    if (inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
+    if (inner_algo != GF_ALGO_TIGHTLY_PACK && inner_algo != GF_ALGO_MINIMAL_FRAGMENTATION) return hipErrorInvalidValue;
+    if (az_aware && inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 app_grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
     hipError_t e = hipSuccess;
@@ -1399,8 +1408,12 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
     if (zones.n_zones > 0) {
         const uint64_t n_dec = (uint64_t)n_apps * zones.n_zones;
         const dim3 dec_grid((unsigned)((n_dec + kWavesPerBlock - 1) / kWavesPerBlock));
-        hipLaunchKernelGGL(fit_zoned_kernel<GF_ALGO_TIGHTLY_PACK>, dec_grid, block, 0, stream, table, zones, n_apps,
-                           d_apps, buf.zres, buf.zexec, buf.zexec_stride, d_scratch, scratch_half);
+        if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+            hipLaunchKernelGGL(fit_zoned_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, dec_grid, block, 0, stream, table, zones,
+                               n_apps, d_apps, buf.zres, buf.zexec, buf.zexec_stride, d_scratch, scratch_half);
+        else
+            hipLaunchKernelGGL(fit_zoned_kernel<GF_ALGO_TIGHTLY_PACK>, dec_grid, block, 0, stream, table, zones, n_apps,
+                               d_apps, buf.zres, buf.zexec, buf.zexec_stride, d_scratch, scratch_half);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         const dim3 eff_grid((buf.n_cnt_waves + kWavesPerBlock - 1) / kWavesPerBlock);
         if (reserve_execs)
@@ -1443,12 +1456,17 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
             GF_GEN(GF_ALGO_TIGHTLY_PACK, false, false, true);
         else if (inner_algo == GF_ALGO_DISTRIBUTE_EVENLY)
             GF_GEN(GF_ALGO_DISTRIBUTE_EVENLY, false, false, true);
+        else if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+            GF_GEN(GF_ALGO_MINIMAL_FRAGMENTATION, false, false, false);
         else
             return hipErrorInvalidValue;
     } else {
-        if (inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
         (void)reserve_execs;
-        if (az_aware)
+        if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION && !az_aware)
+            GF_GEN(GF_ALGO_MINIMAL_FRAGMENTATION, true, false, false);  // minimalFragmentation reserves the driver only
+        else if (inner_algo != GF_ALGO_TIGHTLY_PACK)
+            return hipErrorInvalidValue;
+        else if (az_aware)
             GF_GEN(GF_ALGO_TIGHTLY_PACK, true, true, true);
         else
             GF_GEN(GF_ALGO_TIGHTLY_PACK, true, false, true);

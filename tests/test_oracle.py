@@ -199,6 +199,21 @@ def test_minimal_fragmentation_doc_examples():
     assert not ok
 
 
+def test_minimal_fragmentation_reference_doc_comment():
+    """The reference's own worked examples (minimal_fragmentation.go:43-58): nodePriorityOrder [a..f], capacities
+    1, 1, 3, 5, 5, 17.  Four of the five hold for the code as written; for executorCount = 19 the comment says
+    [f x 17, a, b] but internalMinimalFragmentation (:101-110) puts the remaining 2 on c (first node of the
+    capacity-sorted list with capacity >= 2).  Parity is with the code."""
+    a, b, c, d, e, f = range(6)
+    avail = [[x, 99, 0] for x in (1, 1, 3, 5, 5, 17)] + [[1, 1, 0]]
+    want = {11: [d] * 5 + [e] * 5 + [a], 6: [d] * 5 + [a], 15: [d] * 5 + [e] * 5 + [c] * 3 + [a, b], 17: [f] * 17,
+            19: [f] * 17 + [c, c]}
+    for k, execs in want.items():
+        ok, drv_node, ex = ob.spark_binpack(ob.ALGO_MINIMAL_FRAGMENTATION, avail, [1, 1, 0], [1, 1, 0], k, [6],
+                                            [a, b, c, d, e, f])
+        assert ok and drv_node == 6 and ex.tolist() == execs, k
+
+
 def test_packing_efficiency_matches_formula():
     # efficiency.go:79-103: (schedulable - available + reserved).Value() / schedulable.Value(); Value() rounds cpu
     # milli away from zero to whole cores.
