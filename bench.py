@@ -198,6 +198,56 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- node-range sharding: ONE pending table evaluated by all ranks, each scanning its range of the
+    #      priority order; three KB-sized exchanges per batch over RCCL/xGMI.  Strong scaling over nodes; reported next
+    #      to the app-sharded headline so that the driver's 1/2/4/8-GPU runs measure both.
+    if not args.no_extras:
+        from gangfit import sharded
+
+        comm = sharded.TorchComm() if dist is not None else sharded.SingleComm()
+
+        def time_sharded(c, wk, steps, warmup):
+            eng = sharded.HipShardEngine(c, rank, world, dev)
+            sb = sharded.ShardedBatch(eng, comm, TIGHT, gangfit.make_apps(wk.drv, wk.exe, wk.k, wk.flags))
+            for _ in range(warmup):
+                sb.step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sb.step()
+            barrier()
+            wall_s = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([wall_s], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall_s = float(t.item())
+            return {"decisions_per_s": sb.n_apps * steps / wall_s, "ms_per_batch": wall_s / steps * 1e3,
+                    "apps": sb.n_apps, "nodes": len(wk.snapshot.avail), "n_shards": world, "steps": steps,
+                    "collectives_per_batch": "2 all-gather (16 B/app) + 1 all-reduce (4 B/executor)"}
+
+        node_sharded = {"headline": time_sharded(ctx, base, max(10, args.steps // 4), 5)}
+        # BASELINE config 4's size: 50 000 nodes x 10 000 apps (gang size = MinExecutorCount)
+        w4 = wl.config(4)
+        ctx4 = gangfit.Context(local_rank)
+        ctx4.set_snapshot(w4.snapshot.avail, w4.snapshot.sched)
+        ctx4.set_orders(w4.snapshot.driver_order, w4.snapshot.exec_order)
+        node_sharded["config4_50k_nodes_x_10k_apps"] = time_sharded(ctx4, w4, 10, 2)
+        if world == 1:  # the unsharded kernel on the same table, for the cost of the four-step path itself
+            a4, k4 = gangfit.with_offsets(gangfit.make_apps(w4.drv, w4.exe, w4.k, w4.flags))
+            d_a4 = torch.from_numpy(a4.view(np.uint8).copy()).to(dev)
+            d_r4 = torch.zeros(len(a4) * 16, dtype=torch.uint8, device=dev)
+            d_e4 = torch.zeros(k4 + 1, dtype=torch.int32, device=dev)
+            for _ in range(3):
+                ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
+            torch.cuda.synchronize()
+            node_sharded["config4_unsharded_one_gpu_decisions_per_s"] = len(a4) * 10 / (time.perf_counter() - t0)
+        ctx4.close()
+        out["node_sharded"] = node_sharded
+
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
         # distribute-evenly on the same batch

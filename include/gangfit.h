@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GF_VERSION 110 /* 0.1.1 */
+#define GF_VERSION 120 /* 0.1.2 */
 
 /* ---- status codes ---- */
 #define GF_OK 0
@@ -169,6 +169,45 @@ int gf_avg_packing_efficiency(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const 
  * dense n_nodes x 3 array {CPU, Memory, GPU} in node-index order (the Go map has one entry per metadata key). */
 int gf_packing_efficiencies(gf_ctx *ctx, gf_algo algo, const gf_app *app, const gf_result *result,
                             const uint32_t *exec_nodes, double *eff_out /* n_nodes * 3 */);
+
+/* ---- node-range sharding of an INDEPENDENT batch across the GPUs of one box ----
+ * One gf_ctx per GPU, each given the same snapshot and orders; gf_shard_set tells it which contiguous range of the
+ * priority order it owns (ranges are cut on 64-slot boundaries of the merged driver/executor order; GF_ERR_UNSUPPORTED
+ * when the two orders cannot be merged into one).  A batch is then evaluated in four device steps, with one small
+ * exchange over RCCL/xGMI between consecutive steps (the caller owns the communicator; k8s-spark-scheduler_amd/gangfit/
+ * sharded.py drives it with torch.distributed):
+ *     gf_shard_partials_dev -> all-gather -> gf_shard_drivers_dev -> all-gather -> gf_shard_emit_dev
+ *     -> all-reduce(SUM, uint32) of d_exec2 -> gf_shard_finish_dev
+ * after which EVERY rank holds the complete results: the same gf_result / ExecutorNodes as gf_fit_batch_dev on one GPU.
+ * Tightly-pack and distribute-evenly only; the FIFO chain does not shard (each commit must be visible to the next
+ * scan): it runs as replicas.  All pointers are device pointers; calls are asynchronous on `stream`. */
+typedef struct gf_shard_partial {
+    int64_t cap_sum;   /* sum over the range of min(capacity, K) with nothing reserved; may stop early once >= 2K */
+    int64_t fit_count; /* nodes of the range with capacity >= 1 (distribute-evenly pass 1); same early stop */
+} gf_shard_partial;    /* 16 bytes */
+typedef struct gf_shard_driver {
+    uint32_t pos;      /* first position of the range that passes the driver-fit check (LIB/binpack/binpack.go:69) and
+                          leaves room for the gang, GF_NO_NODE if none */
+    int32_t d_cap;     /* change of cap_sum / fit_count when the driver is reserved there */
+    int32_t d_fit;
+    uint32_t reserved;
+} gf_shard_driver;     /* 16 bytes */
+
+int gf_shard_set(gf_ctx *ctx, uint32_t shard, uint32_t n_shards); /* after gf_orders_set; a new gf_orders_set keeps it */
+int gf_shard_partials_dev(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *d_apps, gf_shard_partial *d_out,
+                          void *stream);
+int gf_shard_drivers_dev(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *d_apps,
+                         const gf_shard_partial *d_all_partials /* [n_shards][n_apps] */, gf_shard_driver *d_out,
+                         void *stream);
+/* d_exec2: 2 * half uint32 (half >= sum of k); zeroed here; [0, half) receives this shard's slice of the placements as
+ * node index + 1, [half, 2 * half) the capacities distribute-evenly needs for passes >= 2. */
+int gf_shard_emit_dev(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *d_apps,
+                      const gf_shard_partial *d_all_partials, const gf_shard_driver *d_all_drivers /* [n_shards][n_apps] */,
+                      gf_result *d_results, uint32_t *d_exec2, uint64_t half, void *stream);
+/* after the all-reduce: d_exec2[0, half) becomes the concatenated ExecutorNodes of gf_fit_batch_dev */
+int gf_shard_finish_dev(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *d_apps,
+                        const gf_shard_partial *d_all_partials, const gf_shard_driver *d_all_drivers,
+                        const gf_result *d_results, uint32_t *d_exec2, uint64_t half, void *stream);
 
 /* Working copy of the available table after the last GF_MODE_FIFO_CHAIN call (n_nodes x 3, row-major) — lets tests
  * compare the replayed residuals with availableNodesSchedulingMetadata after fitEarlierDrivers. */

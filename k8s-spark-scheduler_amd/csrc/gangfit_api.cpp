@@ -101,6 +101,7 @@ struct gf_ctx {
     bool work_valid = false;
     bool d_identity = false;
     bool merged = false;       // slot space is the merged order (see NodeTable)
+    uint32_t shard = 0, n_shards = 1;  // node-range sharding (gf_shard_set)
     DeviceBuf<uint64_t> d_masks;  // xmask | dmask, n_chunks each
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::DevApp> d_dev_apps;  // FIFO chain: app records with reciprocals (prepare_apps_kernel)
@@ -847,6 +848,89 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
 int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
                      uint64_t exec_nodes_cap) {
     return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);
+}
+
+// ---- node-range sharding (gangfit_shard.inc)
+namespace {
+int shard_ready(gf_ctx* ctx, gf_algo algo, gangfit::ShardRange* r) {
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a sharded fit");
+    if (!ctx->merged)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "node-range sharding needs the merged slot layout (driver and executor "
+                                             "orders must be subsequences of one priority order)");
+    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "node-range sharding serves tightly-pack and distribute-evenly only");
+    const uint64_t xc = ((uint64_t)ctx->n_x + 63) / 64;  // chunks of the merged order (the sentinel slot hosts nothing)
+    r->c_lo = (uint32_t)(xc * ctx->shard / ctx->n_shards);
+    r->c_hi = (uint32_t)(xc * (ctx->shard + 1) / ctx->n_shards);
+    r->shard = ctx->shard;
+    r->n_shards = ctx->n_shards;
+    return GF_OK;
+}
+}  // namespace
+
+int gf_shard_set(gf_ctx* ctx, uint32_t shard, uint32_t n_shards) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_shards == 0 || shard >= n_shards || n_shards > 1024)
+        return fail(ctx, GF_ERR_INVALID, "shard %u of %u", shard, n_shards);
+    ctx->shard = shard;
+    ctx->n_shards = n_shards;
+    return GF_OK;
+}
+
+int gf_shard_partials_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_shard_partial* d_out,
+                          void* stream) {
+    if (!ctx) return GF_ERR_INVALID;
+    if (n_apps > 0 && (!d_apps || !d_out)) return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
+    gangfit::ShardRange r{};
+    const int rc = shard_ready(ctx, algo, &r);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, gangfit::launch_shard_partials(algo, make_table(ctx, ctx->d_snap.ptr), r, n_apps, d_apps, d_out, st));
+    return GF_OK;
+}
+
+int gf_shard_drivers_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
+                         const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, void* stream) {
+    if (!ctx) return GF_ERR_INVALID;
+    if (n_apps > 0 && (!d_apps || !d_all_partials || !d_out))
+        return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
+    gangfit::ShardRange r{};
+    const int rc = shard_ready(ctx, algo, &r);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, gangfit::launch_shard_drivers(make_table(ctx, ctx->d_snap.ptr), r, n_apps, d_apps, d_all_partials, d_out, st));
+    return GF_OK;
+}
+
+int gf_shard_emit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
+                      const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers, gf_result* d_results,
+                      uint32_t* d_exec2, uint64_t half, void* stream) {
+    if (!ctx) return GF_ERR_INVALID;
+    if (n_apps > 0 && (!d_apps || !d_all_partials || !d_all_drivers || !d_results || !d_exec2 || half == 0))
+        return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
+    gangfit::ShardRange r{};
+    const int rc = shard_ready(ctx, algo, &r);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, gangfit::launch_shard_emit(algo, make_table(ctx, ctx->d_snap.ptr), r, n_apps, d_apps, d_all_partials,
+                                           d_all_drivers, d_results, d_exec2, half, st));
+    return GF_OK;
+}
+
+int gf_shard_finish_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
+                        const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
+                        const gf_result* d_results, uint32_t* d_exec2, uint64_t half, void* stream) {
+    if (!ctx) return GF_ERR_INVALID;
+    if (n_apps > 0 && (!d_apps || !d_all_partials || !d_all_drivers || !d_results || !d_exec2 || half == 0))
+        return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
+    gangfit::ShardRange r{};
+    const int rc = shard_ready(ctx, algo, &r);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, gangfit::launch_shard_finish(algo, ctx->n_shards, n_apps, d_apps, d_all_partials, d_all_drivers,
+                                             d_results, d_exec2, half, st));
+    return GF_OK;
 }
 
 int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps, const gf_result* results,

@@ -170,6 +170,24 @@ hipError_t launch_node_efficiencies(bool reserve_execs, const EffTables& eff_by_
                                     const gf_app* d_app, const gf_result* d_result, const uint32_t* d_exec_nodes,
                                     int64_t* d_reserved, double* d_eff_out, hipStream_t stream);
 
+// Node-range sharding of an independent batch (gangfit_shard.inc): this GPU owns the 64-slot
+// chunks [c_lo, c_hi) of the merged slot order.
+struct ShardRange {
+    uint32_t c_lo, c_hi;
+    uint32_t shard, n_shards;
+};
+hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
+                                 const gf_app* d_apps, gf_shard_partial* d_out, hipStream_t stream);
+hipError_t launch_shard_drivers(const NodeTable& table, const ShardRange& range, uint32_t n_apps, const gf_app* d_apps,
+                                const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, hipStream_t stream);
+hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
+                             const gf_app* d_apps, const gf_shard_partial* d_all_partials,
+                             const gf_shard_driver* d_all_drivers, gf_result* d_results, uint32_t* d_exec2, uint64_t half,
+                             hipStream_t stream);
+hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps, const gf_app* d_apps,
+                               const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
+                               const gf_result* d_results, uint32_t* d_exec2, uint64_t half, hipStream_t stream);
+
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
 // Writes the number of mismatching lanes/cases to *d_mismatch.
 hipError_t launch_selftest(uint64_t seed, uint32_t n_cases, uint32_t* d_mismatch, hipStream_t stream);

@@ -1162,6 +1162,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 #include "gangfit_fifo_fused.inc"
 #include "gangfit_fifo_narrow.inc"
 #include "gangfit_zones.inc"
+#include "gangfit_shard.inc"
 
 // ------------------------------------------------------------------------------------------------ self-test
 
@@ -1509,6 +1510,65 @@ hipError_t launch_node_efficiencies(bool reserve_execs, const EffTables& eff_by_
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(node_efficiency_kernel, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, eff_by_node, n_nodes,
                        (const int64_t*)d_reserved, d_eff_out);
+    return hipGetLastError();
+}
+
+// ---- node-range sharding (gangfit_shard.inc)
+namespace {
+inline dim3 app_grid(uint32_t n_apps) { return dim3((n_apps + kWavesPerBlock - 1) / kWavesPerBlock); }
+}  // namespace
+
+hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
+                                 const gf_app* d_apps, gf_shard_partial* d_out, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    const dim3 block(kWave * kWavesPerBlock);
+    if (algo == GF_ALGO_TIGHTLY_PACK)
+        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_TIGHTLY_PACK>, app_grid(n_apps), block, 0, stream, table,
+                           range.c_lo, range.c_hi, n_apps, d_apps, d_out);
+    else
+        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, app_grid(n_apps), block, 0, stream, table,
+                           range.c_lo, range.c_hi, n_apps, d_apps, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_drivers(const NodeTable& table, const ShardRange& range, uint32_t n_apps, const gf_app* d_apps,
+                                const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    hipLaunchKernelGGL(shard_drivers_kernel, app_grid(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table, range.c_lo,
+                       range.c_hi, range.n_shards, n_apps, d_apps, d_all_partials, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
+                             const gf_app* d_apps, const gf_shard_partial* d_all_partials,
+                             const gf_shard_driver* d_all_drivers, gf_result* d_results, uint32_t* d_exec2, uint64_t half,
+                             hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_exec2, 0, 2 * half * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const dim3 block(kWave * kWavesPerBlock);
+    if (algo == GF_ALGO_TIGHTLY_PACK)
+        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_TIGHTLY_PACK>, app_grid(n_apps), block, 0, stream, table, range.c_lo,
+                           range.c_hi, range.shard, range.n_shards, n_apps, d_apps, d_all_partials, d_all_drivers,
+                           d_results, d_exec2, half);
+    else
+        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, app_grid(n_apps), block, 0, stream, table,
+                           range.c_lo, range.c_hi, range.shard, range.n_shards, n_apps, d_apps, d_all_partials,
+                           d_all_drivers, d_results, d_exec2, half);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps, const gf_app* d_apps,
+                               const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
+                               const gf_result* d_results, uint32_t* d_exec2, uint64_t half, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    const dim3 block(kWave * kWavesPerBlock);
+    if (algo == GF_ALGO_TIGHTLY_PACK)
+        hipLaunchKernelGGL(shard_finish_kernel<GF_ALGO_TIGHTLY_PACK>, app_grid(n_apps), block, 0, stream, n_shards, n_apps,
+                           d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
+    else
+        hipLaunchKernelGGL(shard_finish_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, app_grid(n_apps), block, 0, stream, n_shards,
+                           n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
     return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch",
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats",
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
+    "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
 ]
 
 
@@ -105,6 +106,16 @@ def load() -> C.CDLL:
     L.gf_avg_packing_efficiency.argtypes = [p, i32, u32, p, p, p, u64, p]
     L.gf_packing_efficiencies.restype = i32
     L.gf_packing_efficiencies.argtypes = [p, i32, p, p, p, p]
+    L.gf_shard_set.restype = i32
+    L.gf_shard_set.argtypes = [p, u32, u32]
+    L.gf_shard_partials_dev.restype = i32
+    L.gf_shard_partials_dev.argtypes = [p, i32, u32, p, p, p]
+    L.gf_shard_drivers_dev.restype = i32
+    L.gf_shard_drivers_dev.argtypes = [p, i32, u32, p, p, p, p]
+    L.gf_shard_emit_dev.restype = i32
+    L.gf_shard_emit_dev.argtypes = [p, i32, u32, p, p, p, p, p, u64, p]
+    L.gf_shard_finish_dev.restype = i32
+    L.gf_shard_finish_dev.argtypes = [p, i32, u32, p, p, p, p, p, u64, p]
     L.gf_residual_get.restype = i32
     L.gf_residual_get.argtypes = [p, p]
     L.gf_timer_begin.restype = i32
