@@ -1,0 +1,84 @@
+// extender.hpp — the driver Filter decision around the gang-fit kernels (host side, C++ mirror of the Go code).
+//
+//   SparkSchedulerExtender.selectDriverNode          internal/extender/resource.go:272-370
+//   fitEarlierDrivers / shouldSkipDriverFifo         internal/extender/resource.go:224-270
+//   outcome strings                                  internal/extender/resource.go:46-55
+//   newResourceReservation / executorReservationName internal/extender/resourcereservations.go:491-533
+//   UnschedulablePodMarker.DoesPodExceedClusterCapacity  internal/extender/unschedulablepods.go:132-166
+// The reference calls BinpackFunc once per earlier driver and once for the driver being filtered
+// (resource.go:238, :321); here the whole FIFO replay + final pack is ONE GF_MODE_FIFO_CHAIN call (the "L-batch"
+// insertion level of SURVEY.md section 8b).  Everything else — listers, caches, demands, metrics, the API write of the
+// reservation — stays in the Go host and is represented by plain inputs / outputs.
+#pragma once
+
+#include <map>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "binpacker.hpp"
+#include "nodesorting.hpp"
+#include "sparkpods.hpp"
+
+namespace gangfit::host {
+
+namespace outcome {
+constexpr const char* failureUnbound = "failure-unbound";
+constexpr const char* failureInternal = "failure-internal";
+constexpr const char* failureFit = "failure-fit";
+constexpr const char* failureEarlierDriver = "failure-earlier-driver";
+constexpr const char* failureNonSparkPod = "failure-non-spark-pod";
+constexpr const char* success = "success";
+}  // namespace outcome
+
+struct FifoConfig {  // config.FifoConfig
+    int64_t DefaultEnforceAfterPodAgeNanos = 0;
+    std::map<std::string, int64_t> EnforceAfterPodAgeByInstanceGroup;
+};
+
+ResourceReservation newResourceReservation(const std::string& driverNode, const std::vector<std::string>& executorNodes,
+                                           const Pod& driver, const Resources& driverResources,
+                                           const Resources& executorResources);
+std::string executorReservationName(int i);  // "executor-<i+1>"
+
+struct SelectNodeResult {
+    std::string node;     // empty on failure
+    std::string outcome;  // one of outcome::*
+    std::string error;    // the reference's error text (or why the device could not serve the request)
+    bool served = true;   // false: the accelerator could not serve the request -> the Go host must run its own path
+    std::optional<ResourceReservation> created;  // what CreateReservations would persist
+};
+
+class SparkSchedulerExtender {
+public:
+    SparkSchedulerExtender(Binpacker binpacker, NodeSorter sorter, bool isFIFO, FifoConfig fifo)
+        : binpacker_(std::move(binpacker)), sorter_(std::move(sorter)), isFIFO_(isFIFO), fifo_(std::move(fifo)) {}
+
+    // Cluster state the listers / caches of the Go host would provide.
+    std::vector<Node> nodes;                         // nodeLister
+    std::vector<Pod> pods;                           // podLister (drivers)
+    std::vector<ResourceReservation> reservations;   // resourceReservationManager
+    NodeGroupResources softReservationUsage;         // added by GetReservedResources (resourcereservations.go:258-263)
+    NodeGroupResources overhead;                     // overheadComputer.GetOverhead
+    int64_t nowNanos = 0;                            // time.Now()
+
+    // availableNodes = nodes whose labels satisfy the driver's required node affinity; the caller passes the predicate's
+    // result because affinity matching is k8s API bookkeeping (resource.go:292-298).
+    SelectNodeResult selectDriverNode(const std::string& instanceGroup, const Pod& driver,
+                                      const std::vector<std::string>& nodeNames, const std::vector<Node>& availableNodes);
+
+    // unschedulablepods.go:132-166: does the application fit an EMPTY cluster (usage = 0, the given overhead)?
+    // nodes are used in lister order for both candidate lists.
+    bool DoesPodExceedClusterCapacity(const Pod& driver, const std::vector<Node>& availableNodes,
+                                      const NodeGroupResources& nonSchedulableOverhead, bool* served, std::string* err);
+
+    bool shouldSkipDriverFifo(const Pod& pod, const std::string& instanceGroup) const;
+
+private:
+    Binpacker binpacker_;
+    NodeSorter sorter_;
+    bool isFIFO_;
+    FifoConfig fifo_;
+};
+
+}  // namespace gangfit::host

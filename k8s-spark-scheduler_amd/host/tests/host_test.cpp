@@ -1,0 +1,460 @@
+// host_test.cpp — tests of the C++ host mirror, written after the reference's own Go tests so that they read alike:
+//   TestSparkResources, TestIsEarliest                          internal/extender/sparkpods_test.go:40-223
+//   TestResourcesSorting, TestScheduleContextSorting,
+//   TestAZAwareNodeSorting(+IfZoneLabelIsMissing), TestLabelPrioritySorting   internal/sort/nodesorting_test.go:27-250
+//   TestScheduler, TestUnschedulablePodMarker, TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs
+//                                                               internal/extender/resource_test.go:27-71, unschedulablepods_test.go:24-80
+// `host_test cpu` needs no GPU (parsing, sorting, snapshot, reservations); `host_test gpu` drives the device through
+// the C ABI exactly like the Go shim would.  Exit code 0 = all passed.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "extender.hpp"
+
+using namespace gangfit::host;
+
+static int g_failed = 0, g_checked = 0;
+#define CHECK(cond)                                                            \
+    do {                                                                       \
+        ++g_checked;                                                           \
+        if (!(cond)) {                                                         \
+            ++g_failed;                                                        \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);        \
+        }                                                                      \
+    } while (0)
+
+static const int64_t Mi = 1024 * 1024, Gi = 1024 * Mi;
+
+// ------------------------------------------------------------------------------------------------ quantity
+static void TestParseQuantity() {
+    struct C {
+        const char* s;
+        bool ok;
+        int64_t value, milli;
+    };
+    const C cases[] = {
+        {"0", true, 0, 0},          {"1", true, 1, 1000},          {"+1", true, 1, 1000},     {"-1", true, -1, -1000},
+        {"500m", true, 1, 500},     {"1500m", true, 2, 1500},      {"0.5", true, 1, 500},     {"1.5", true, 2, 1500},
+        {"100u", true, 1, 1},       {"1n", true, 1, 1},            {"1k", true, 1000, 1000000}, {"1Ki", true, 1024, 1024000},
+        {"2432Mi", true, 2432 * Mi, 2432 * Mi * 1000}, {"6758Mi", true, 6758 * Mi, 6758 * Mi * 1000},
+        {"8Gi", true, 8 * Gi, 8 * Gi * 1000},          {"1.5Gi", true, 3 * Gi / 2, 3 * Gi / 2 * 1000},
+        {"1e3", true, 1000, 1000000}, {"1E3", true, 1000, 1000000}, {"12e-1", true, 2, 1200},  {"1.", true, 1, 1000},
+        {"007", true, 7, 7000},     {".5", true, 1, 500},          {"1.G", true, 1000000000, 1000000000000},
+        {"", false, 0, 0},          {"abc", false, 0, 0},          {"1x", false, 0, 0},       {"1 ", false, 0, 0},
+        {"Gi", false, 0, 0},        {"1Gii", false, 0, 0},         {"1e", false, 0, 0},       {"--1", false, 0, 0},
+        {"1mi", false, 0, 0},       {"1KI", false, 0, 0},
+    };
+    for (const C& c : cases) {
+        Quantity q;
+        const bool ok = Quantity::Parse(c.s, &q);
+        CHECK(ok == c.ok);
+        if (ok && c.ok) {
+            if (q.Value() != c.value || q.MilliValue() != c.milli) std::printf("   case \"%s\": value %lld milli %lld\n", c.s, (long long)q.Value(), (long long)q.MilliValue());
+            CHECK(q.Value() == c.value);
+            CHECK(q.MilliValue() == c.milli);
+        } else if (ok != c.ok) {
+            std::printf("   case \"%s\"\n", c.s);
+        }
+    }
+    // finer than nano rounds up to one nano (quantity.go:343-350), canonical forms are exact-or-nothing
+    Quantity q;
+    CHECK(Quantity::Parse("0.0000000001", &q) && q.nano() == 1);
+    int64_t v = 0;
+    CHECK(Quantity::Parse("250m", &q) && q.canonical_milli(&v) && v == 250 && !q.canonical_units(&v));
+    CHECK(Quantity::Parse("1500u", &q) && !q.canonical_milli(&v));
+    CHECK(Quantity::Parse("4Gi", &q) && q.canonical_units(&v) && v == 4 * Gi);
+    Quantity a = Quantity::FromInt(3), b = Quantity::FromMilli(2500);
+    CHECK(a.Cmp(b) == 1 && b.Cmp(a) == -1 && a.Cmp(a) == 0);
+    a.Sub(b);
+    CHECK(a.MilliValue() == 500);
+    a.Neg();
+    CHECK(a.MilliValue() == -500 && a.Value() == -1);
+}
+
+// ------------------------------------------------------------------------------------------------ sparkpods_test.go
+static bool SameResources(const Resources& a, const Resources& b) { return a.Eq(b); }
+
+static void TestSparkResources() {
+    using namespace common;
+    {  // "parses static allocation pod annotations into resources"
+        Pod pod;
+        pod.Annotations = {{DriverCPU, "1"},        {DriverMemory, "2432Mi"},   {DriverNvidiaGPUs, "1"}, {ExecutorCPU, "2"},
+                           {ExecutorMemory, "6758Mi"}, {ExecutorNvidiaGPUs, "1"}, {ExecutorCount, "2"}};
+        std::string err;
+        auto r = sparkResources(pod, &err);
+        CHECK(r.has_value());
+        CHECK(SameResources(r->DriverResources, Resources::Create(1, 2432 * Mi, 1)));
+        CHECK(SameResources(r->ExecutorResources, Resources::Create(2, 6758 * Mi, 1)));
+        CHECK(r->MinExecutorCount == 2 && r->MaxExecutorCount == 2);
+    }
+    {  // "parses dynamic allocation pod annotations into resources"
+        Pod pod;
+        pod.Annotations = {{DriverCPU, "1"},          {DriverMemory, "2432Mi"},         {DriverNvidiaGPUs, "1"},
+                           {ExecutorCPU, "2"},        {ExecutorMemory, "6758Mi"},       {ExecutorNvidiaGPUs, "1"},
+                           {DynamicAllocationEnabled, "true"}, {DAMinExecutorCount, "2"}, {DAMaxExecutorCount, "5"}};
+        auto r = sparkResources(pod, nullptr);
+        CHECK(r.has_value());
+        CHECK(SameResources(r->DriverResources, Resources::Create(1, 2432 * Mi, 1)));
+        CHECK(SameResources(r->ExecutorResources, Resources::Create(2, 6758 * Mi, 1)));
+        CHECK(r->MinExecutorCount == 2 && r->MaxExecutorCount == 5);
+    }
+    {  // "... when no gpu annotation is present"
+        Pod pod;
+        pod.Annotations = {{DriverCPU, "1"}, {DriverMemory, "2432Mi"}, {ExecutorCPU, "2"}, {ExecutorMemory, "6758Mi"},
+                           {ExecutorCount, "2"}};
+        auto r = sparkResources(pod, nullptr);
+        CHECK(r.has_value());
+        CHECK(SameResources(r->DriverResources, Resources::Create(1, 2432 * Mi, 0)));
+        CHECK(SameResources(r->ExecutorResources, Resources::Create(2, 6758 * Mi, 0)));
+    }
+    // error branches (sparkpods.go:78-103)
+    auto error_of = [](std::map<std::string, std::string> ann) {
+        Pod pod;
+        pod.Annotations = std::move(ann);
+        std::string err;
+        auto r = sparkResources(pod, &err);
+        return r.has_value() ? std::string("<ok>") : err;
+    };
+    CHECK(error_of({{DriverCPU, "1"}, {DriverMemory, "1"}, {ExecutorCPU, "1"}, {ExecutorMemory, "1"}}) ==
+          "annotation ExecutorCount is required when DynamicAllocationEnabled is false");
+    CHECK(error_of({{DriverCPU, "1"}, {DriverMemory, "1"}, {ExecutorCPU, "1"}, {ExecutorMemory, "1"},
+                    {DynamicAllocationEnabled, "true"}, {DAMinExecutorCount, "1"}}) ==
+          "annotation spark-dynamic-allocation-max-executor-count is required when DynamicAllocationEnabled is true");
+    CHECK(error_of({{DriverMemory, "1"}, {ExecutorCPU, "1"}, {ExecutorMemory, "1"}, {ExecutorCount, "1"}}) ==
+          "annotation spark-driver-cpu is missing from driver");
+    CHECK(error_of({{DriverCPU, "one"}, {DriverMemory, "1"}, {ExecutorCPU, "1"}, {ExecutorMemory, "1"}, {ExecutorCount, "1"}}) ==
+          "annotation spark-driver-cpu does not have a parseable value one");
+    CHECK(error_of({{DynamicAllocationEnabled, "maybe"}}) == "annotation DynamicAllocationEnabled could not be parsed as a boolean");
+}
+
+static Pod createPod(int64_t seconds, const char* uid, const char* instanceGroup) {
+    Pod p;
+    p.UID = uid;
+    p.CreationTimestampNanos = seconds * 1000000000;
+    p.InstanceGroup = instanceGroup;
+    return p;
+}
+
+static void TestIsEarliest() {
+    struct T {
+        Pod pod;
+        std::vector<Pod> pods;
+        std::vector<std::string> result;
+    };
+    const char* g = "instance-group-foobar";
+    std::vector<T> tests = {
+        {createPod(100, "1", g), {createPod(101, "3", g), createPod(150, "2", g), createPod(100, "1", g)}, {}},
+        {createPod(100, "1", g), {createPod(101, "2", g)}, {}},
+        {createPod(100, "1", g), {createPod(101, "3", g), createPod(99, "2", g), createPod(100, "1", g)}, {"2"}},
+        {createPod(100, "1", g), {createPod(99, "3", g), createPod(101, "2", g)}, {"3"}},
+    };
+    for (const T& t : tests) {
+        std::vector<std::string> uids;
+        for (const Pod* p : filterToEarliestAndSort(t.pod, t.pods)) uids.push_back(p->UID);
+        CHECK(uids == t.result);
+    }
+    // other instance groups, assigned pods, other schedulers and pods being deleted are not predecessors; order is creation time
+    Pod me = createPod(100, "me", g);
+    me.SchedulerName = common::SparkSchedulerName;
+    std::vector<Pod> all = {createPod(50, "other-group", "x"), createPod(60, "assigned", g), createPod(70, "b", g),
+                            createPod(65, "a", g), createPod(66, "deleting", g), createPod(67, "default-scheduler", g)};
+    for (Pod& p : all) p.SchedulerName = common::SparkSchedulerName;
+    all[1].NodeName = "node1";
+    all[4].Deleting = true;
+    all[5].SchedulerName = "default-scheduler";
+    std::vector<std::string> uids;
+    for (const Pod* p : filterToEarliestAndSort(me, all)) uids.push_back(p->UID);
+    CHECK((uids == std::vector<std::string>{"a", "b"}));
+}
+
+// ------------------------------------------------------------------------------------------------ nodesorting_test.go
+static Resources CpuMem(int64_t cpu, int64_t mem) { return Resources::Create(cpu, mem, 0); }
+
+static void TestResourcesSorting() {
+    Resources node = CpuMem(1, 1), freeMemory = CpuMem(1, 2), freeCPU = CpuMem(2, 1);
+    CHECK(!resourcesLessThan(freeMemory, node) && resourcesLessThan(node, freeMemory));
+    CHECK(!resourcesLessThan(freeCPU, node) && resourcesLessThan(node, freeCPU));
+}
+
+static void TestScheduleContextSorting() {
+    Resources less = CpuMem(1, 1), more = CpuMem(1, 2);
+    ScheduleContext base1{0, less, "base1"}, base2{0, less, "base2"}, lowerAzPriority{1, less, "lower"},
+        moreNodeResources{0, more, "more"};
+    CHECK(!scheduleContextLessThan(lowerAzPriority, base1) && scheduleContextLessThan(base1, lowerAzPriority));
+    CHECK(!scheduleContextLessThan(moreNodeResources, base1) && scheduleContextLessThan(base1, moreNodeResources));
+    CHECK(!scheduleContextLessThan(base2, base1) && scheduleContextLessThan(base1, base2));
+}
+
+static NodeSchedulingMetadata Meta(int64_t cpu, int64_t mem, const char* zone, bool ready = false) {
+    NodeSchedulingMetadata m;
+    m.AvailableResources = CpuMem(cpu, mem);
+    m.ZoneLabel = zone;
+    m.Ready = ready;
+    return m;
+}
+
+static void TestAZAwareNodeSorting() {
+    NodeGroupSchedulingMetadata md;
+    md["zone1Node1"] = Meta(1, 1, "zone1");
+    md["zone1Node2"] = Meta(1, 2, "zone1");
+    md["zone1Node3"] = Meta(2, 1, "zone1");
+    md["zone2Node1"] = Meta(1, 1, "zone2");
+    CHECK((getNodeNamesInPriorityOrder(md) == std::vector<std::string>{"zone2Node1", "zone1Node1", "zone1Node3", "zone1Node2"}));
+}
+
+static void TestAZAwareNodeSortingWorksIfZoneLabelIsMissing() {
+    NodeGroupSchedulingMetadata md;
+    md["node1"] = Meta(2, 1, "", true);
+    md["node2"] = Meta(2, 2, "", true);
+    md["node3"] = Meta(1, 1, "", true);
+    CHECK((getNodeNamesInPriorityOrder(md) == std::vector<std::string>{"node3", "node1", "node2"}));
+}
+
+static void TestLabelPrioritySorting() {
+    auto labelled = [](std::vector<std::pair<const char*, const char*>> v) {
+        NodeGroupSchedulingMetadata md;
+        for (auto& [node, value] : v) {
+            NodeSchedulingMetadata m;
+            if (value) m.AllLabels["test-label"] = value;
+            md[node] = m;
+        }
+        return md;
+    };
+    struct T {
+        LabelPriorityOrder order;
+        NodeGroupSchedulingMetadata md;
+        std::vector<std::string> nodeNames, expected;
+    };
+    std::vector<T> tests = {
+        {{"test-label", {"best", "good"}}, labelled({{"node1", "worst"}, {"node2", "good"}, {"node3", "best"}}),
+         {"node1", "node3", "node2"}, {"node3", "node2", "node1"}},
+        {{"test-label", {"best", "good"}}, labelled({{"node1", nullptr}, {"node2", "good"}, {"node3", "best"}}),
+         {"node2", "node3", "node1"}, {"node3", "node2", "node1"}},
+        {{"test-label", {"best", "better", "good"}}, labelled({{"node1", "better"}, {"node2", "good"}, {"node3", "best"}}),
+         {"node1", "node2", "node3"}, {"node3", "node1", "node2"}},
+    };
+    for (T& t : tests) {
+        sortNodesByLabelPriority(t.nodeNames, t.md, t.order);
+        CHECK(t.nodeNames == t.expected);
+    }
+}
+
+static void TestPotentialNodes() {
+    // nodesorting.go:41-64: drivers = requested names in priority order; executors = schedulable && ready nodes
+    NodeGroupSchedulingMetadata md;
+    md["a"] = Meta(4, 4, "z", true);
+    md["b"] = Meta(1, 1, "z", true);
+    md["c"] = Meta(2, 2, "z", false);  // not ready: driver candidate only
+    md["d"] = Meta(3, 3, "z", true);
+    md["d"].Unschedulable = true;
+    md["a"].AllLabels["pool"] = "cheap";
+    md["b"].AllLabels["pool"] = "costly";
+    NodeSorter plain;
+    auto [drivers, executors] = plain.PotentialNodes(md, {"a", "c", "d", "not-a-node"});
+    CHECK((drivers == std::vector<std::string>{"c", "d", "a"}));
+    CHECK((executors == std::vector<std::string>{"b", "a"}));
+    NodeSorter labelled(std::nullopt, LabelPriorityOrder{"pool", {"cheap", "costly"}});
+    auto [d2, e2] = labelled.PotentialNodes(md, {"a", "b"});
+    CHECK((d2 == std::vector<std::string>{"b", "a"}));
+    CHECK((e2 == std::vector<std::string>{"a", "b"}));
+}
+
+// ------------------------------------------------------------------------------------------------ snapshot & reservations
+static Node NewNode(const char* name, const char* zone) {  // extendertest.NewNode (extender_test_utils.go:239-271)
+    Node n;
+    n.Name = name;
+    n.labels = {{"resource_channel", "batch-medium-priority"},
+                {"com.palantir.rubix/instance-group", "batch-medium-priority"},
+                {"test", "something"},
+                {"topology.kubernetes.io/zone", zone}};  // NOT the label the bin-pack snapshot reads
+    n.Allocatable = {{kResourceCPU, Quantity::FromInt(8)}, {kResourceMemory, Quantity::FromInt(8 * Gi)},
+                     {kResourceNvidiaGPU, Quantity::FromInt(1)}};
+    n.Ready = true;
+    return n;
+}
+
+static Pod Driver(const char* app, std::map<std::string, std::string> annotations, int64_t created_s = 0) {
+    Pod p;
+    p.Name = std::string(app) + "-spark-driver";
+    p.Namespace = "namespace";
+    p.labels = {{common::SparkRoleLabel, common::Driver}, {common::SparkAppIDLabel, app}};
+    p.Annotations = std::move(annotations);
+    p.SchedulerName = common::SparkSchedulerName;
+    p.InstanceGroup = "batch-medium-priority";
+    p.CreationTimestampNanos = created_s * 1000000000;
+    return p;
+}
+static std::map<std::string, std::string> StaticAnnotations(int numExecutors, const char* driverMem = "1",
+                                                            const char* driverCPU = "1", const char* executorMem = "1",
+                                                            const char* executorCPU = "1", bool executorGpu = false) {
+    std::map<std::string, std::string> a = {{"spark-driver-cpu", driverCPU},     {"spark-driver-mem", driverMem},
+                                            {"spark-driver-nvidia.com/gpu", "1"}, {"spark-executor-cpu", executorCPU},
+                                            {"spark-executor-mem", executorMem},
+                                            {"spark-executor-count", std::to_string(numExecutors)}};
+    if (executorGpu) a["spark-executor-nvidia.com/gpu"] = "1";
+    return a;
+}
+
+static void TestSnapshotAndReservations() {
+    std::vector<Node> nodes = {NewNode("node1", "zone1"), NewNode("node2", "zone1")};
+    nodes[1].labels[kLabelZoneFailureDomain] = "us-east-1a";
+    Pod driver = Driver("app", StaticAnnotations(3));
+    auto res = sparkResources(driver, nullptr);
+    ResourceReservation rr = newResourceReservation("node1", {"node1", "node2", "node1"}, driver, res->DriverResources,
+                                                    res->ExecutorResources);
+    CHECK(rr.Name == "app" && rr.Namespace == "namespace" && rr.Pods.at("driver") == "app-spark-driver");
+    CHECK(rr.Reservations.size() == 4 && rr.Reservations.at("driver").Node == "node1");
+    CHECK(rr.Reservations.at("executor-1").Node == "node1" && rr.Reservations.at("executor-2").Node == "node2" &&
+          rr.Reservations.at("executor-3").Node == "node1");  // names follow ExecutorNodes order (:501-502)
+    CHECK(rr.Reservations.at("driver").Resources.at(kResourceNvidiaGPU).Value() == 1);
+    // UsageForNodes: every reservation counts in full
+    NodeGroupResources usage = UsageForNodes({rr});
+    CHECK(usage.at("node1").CPU.Value() == 3 && usage.at("node2").CPU.Value() == 1 && usage.at("node1").NvidiaGPU.Value() == 1);
+    NodeGroupResources overhead;
+    overhead["node1"] = Resources{Quantity::FromMilli(500), Quantity::FromInt(Gi), Quantity()};
+    NodeGroupSchedulingMetadata md = NodeSchedulingMetadataForNodes(nodes, usage, overhead);
+    CHECK(md.at("node1").AvailableResources.CPU.MilliValue() == 8000 - 3000 - 500);
+    CHECK(md.at("node1").SchedulableResources.CPU.MilliValue() == 7500);
+    CHECK(md.at("node1").AvailableResources.Memory.Value() == 8 * Gi - 3 - Gi);
+    CHECK(md.at("node2").AvailableResources.CPU.MilliValue() == 7000 && md.at("node2").SchedulableResources.Memory.Value() == 8 * Gi);
+    CHECK(md.at("node1").ZoneLabel == "default" && md.at("node2").ZoneLabel == "us-east-1a");
+    CHECK(md.at("node1").Ready && !md.at("node1").Unschedulable);
+    CHECK(usage.at("node1").CPU.MilliValue() == 3500);  // the in-place Add of the reference (quirk 5)
+    // sparkResourceUsage: multiplicity lost, the driver entry overwritten by an executor on the same node
+    NodeGroupResources u = sparkResourceUsage(Resources::Create(2, 2, 0), Resources::Create(3, 3, 0), "n1", {"n1", "n1", "n2"});
+    CHECK(u.size() == 2 && u.at("n1").CPU.Value() == 3 && u.at("n2").CPU.Value() == 3);
+    md.SubtractUsageIfExists({{"node2", Resources::Create(1, 1, 0)}, {"ghost", Resources::Create(1, 1, 0)}});
+    CHECK(md.at("node2").AvailableResources.CPU.MilliValue() == 6000 && md.count("ghost") == 0);
+}
+
+// ------------------------------------------------------------------------------------------------ device-backed tests
+static gf_ctx* g_ctx = nullptr;
+
+static SparkSchedulerExtender NewTestExtender(const char* binpackAlgo, std::vector<Node> nodes, bool fifo = true) {
+    SparkSchedulerExtender e(SelectBinpacker(binpackAlgo, g_ctx), NodeSorter(), fifo, FifoConfig{});
+    e.nodes = std::move(nodes);
+    e.nowNanos = 1000ll * 1000000000;
+    return e;
+}
+
+static void TestScheduler() {  // resource_test.go:27-71 (the driver half; executors bind to the reservation in the Go host)
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    auto ext = NewTestExtender("single-az-tightly-pack", {node1, node2});
+    Pod driver = Driver("2-executor-app", StaticAnnotations(2));
+    SelectNodeResult r = ext.selectDriverNode("batch-medium-priority", driver, {"node1", "node2"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::success) && r.node == "node1");
+    CHECK(r.created.has_value());
+    if (r.created) {
+        CHECK(r.created->Reservations.at("driver").Node == "node1");
+        CHECK(r.created->Reservations.at("executor-1").Node == "node1" && r.created->Reservations.at("executor-2").Node == "node1");
+        CHECK(r.created->Reservations.size() == 3);
+        ext.reservations.push_back(*r.created);
+    }
+    // a second Filter for the same driver returns the reserved node (resource.go:278-291)
+    r = ext.selectDriverNode("batch-medium-priority", driver, {"node2"}, ext.nodes);
+    CHECK(r.outcome == std::string(outcome::success) && r.node == "node1" && !r.created.has_value());
+    // with the first app's reservations in place a 13-executor app does not fit (16 cpu - 3 = 13 < 14)
+    Pod big = Driver("big-app", StaticAnnotations(13), 10);
+    r = ext.selectDriverNode("batch-medium-priority", big, {"node1", "node2"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::failureFit) && r.node.empty());
+}
+
+static void TestUnschedulablePodMarker() {  // unschedulablepods_test.go:24-53
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    auto ext = NewTestExtender("single-az-tightly-pack", {node1, node2});
+    bool served = false;
+    std::string err;
+    CHECK(!ext.DoesPodExceedClusterCapacity(Driver("2-executor-app", StaticAnnotations(2)), ext.nodes, {}, &served, &err) && served);
+    CHECK(ext.DoesPodExceedClusterCapacity(Driver("100-executor-app", StaticAnnotations(100)), ext.nodes, {}, &served, &err) && served);
+}
+
+static void TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs() {  // unschedulablepods_test.go:55-80
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    auto ext = NewTestExtender("single-az-tightly-pack", {node1, node2});
+    bool served = false;
+    CHECK(ext.DoesPodExceedClusterCapacity(Driver("gpu-app", StaticAnnotations(2, "1", "1", "1", "1", true)), ext.nodes, {}, &served, nullptr) && served);
+    SelectNodeResult r = ext.selectDriverNode("batch-medium-priority", Driver("gpu-app", StaticAnnotations(2, "1", "1", "1", "1", true)),
+                                              {"node1", "node2"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::failureFit));
+}
+
+static void TestFifoAndBinpackers() {
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    // an earlier driver that can never fit blocks the queue (resource.go:244-253) ...
+    auto ext = NewTestExtender("tightly-pack", {node1, node2});
+    Pod hog = Driver("hog", StaticAnnotations(100), 1), small = Driver("small", StaticAnnotations(1), 5);
+    ext.pods = {hog, small};
+    SelectNodeResult r = ext.selectDriverNode("batch-medium-priority", small, {"node1", "node2"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::failureEarlierDriver));
+    // ... unless it is still younger than the enforce-after age (shouldSkipDriverFifo, :264-270)
+    FifoConfig cfg;
+    cfg.EnforceAfterPodAgeByInstanceGroup["batch-medium-priority"] = 3600ll * 1000000000;
+    SparkSchedulerExtender young(SelectBinpacker("tightly-pack", g_ctx), NodeSorter(), true, cfg);
+    young.nodes = ext.nodes;
+    young.pods = ext.pods;
+    young.nowNanos = 1000ll * 1000000000;
+    r = young.selectDriverNode("batch-medium-priority", small, {"node1", "node2"}, young.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::success));
+    // an earlier driver that fits takes its share first: 2 x (8 cpu): earlier app 1 + 6, then 1 + 8 no longer fits
+    auto ext2 = NewTestExtender("tightly-pack", {node1, node2});
+    Pod first = Driver("first", StaticAnnotations(6), 1), second = Driver("second", StaticAnnotations(8), 2);
+    ext2.pods = {first, second};
+    r = ext2.selectDriverNode("batch-medium-priority", second, {"node1", "node2"}, ext2.nodes);
+    // quirk 1: the replay subtracts ONE executor per distinct node (and no driver: it shares node1 with executors), so
+    // node1 8-1=7 and node2 8 remain -> 1 + 8 fits where a full accounting would not
+    CHECK(r.served && r.outcome == std::string(outcome::success));
+    // registry names (internal/binpacker/binpack.go:43-58); unknown names select distribute-evenly
+    CHECK(SelectBinpacker("nope", g_ctx).Name == "distribute-evenly" && !SelectBinpacker("nope", g_ctx).IsSingleAz);
+    CHECK(SelectBinpacker("single-az-minimal-fragmentation", g_ctx).IsSingleAz);
+    // the SparkBinPackFunction shape with string names: distribute-evenly round-robins
+    NodeGroupResources none;
+    NodeGroupSchedulingMetadata md = NodeSchedulingMetadataForNodes({node1, node2}, none, {});
+    Binpacker even = SelectBinpacker("distribute-evenly", g_ctx);
+    PackingResult p = even.BinpackFunc(Resources::Create(1, 1, 1), Resources::Create(1, 1, 0), 3, {"node1", "node2"},
+                                       {"node1", "node2", "ghost"}, md);
+    CHECK(p.served && p.HasCapacity && p.DriverNode == "node1");
+    CHECK((p.ExecutorNodes == std::vector<std::string>{"node1", "node2", "node1"}));
+    CHECK(p.PackingEfficiencies.size() == 2 && p.PackingEfficiencies.at("node1").CPU == 3.0 / 8.0 &&
+          p.PackingEfficiencies.at("node2").CPU == 1.0 / 8.0 && p.PackingEfficiencies.at("node1").GPU == 1.0);
+    // a quantity that is not exactly representable is refused, never rounded
+    Resources odd = Resources::Create(1, 1, 0);
+    Quantity::Parse("1500u", &odd.CPU);
+    p = even.BinpackFunc(odd, Resources::Create(1, 1, 0), 1, {"node1"}, {"node1"}, md);
+    CHECK(!p.served && !p.HasCapacity);
+    for (const char* name : {"tightly-pack", "az-aware-tightly-pack", "single-az-tightly-pack", "single-az-minimal-fragmentation"}) {
+        p = SelectBinpacker(name, g_ctx).BinpackFunc(Resources::Create(1, 1, 1), Resources::Create(1, 1, 0), 2,
+                                                     {"node1", "node2"}, {"node1", "node2"}, md);
+        CHECK(p.served && p.HasCapacity && p.DriverNode == "node1" && (p.ExecutorNodes == std::vector<std::string>{"node1", "node1"}));
+    }
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    if (mode == "cpu" || mode == "all") {
+        TestParseQuantity();
+        TestSparkResources();
+        TestIsEarliest();
+        TestResourcesSorting();
+        TestScheduleContextSorting();
+        TestAZAwareNodeSorting();
+        TestAZAwareNodeSortingWorksIfZoneLabelIsMissing();
+        TestLabelPrioritySorting();
+        TestPotentialNodes();
+        TestSnapshotAndReservations();
+    }
+    if (mode == "gpu" || mode == "all") {
+        if (gf_init(nullptr, 0, &g_ctx) != GF_OK) {
+            std::printf("FAIL gf_init: no gfx950 device (there is no CPU fallback)\n");
+            return 2;
+        }
+        TestScheduler();
+        TestUnschedulablePodMarker();
+        TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs();
+        TestFifoAndBinpackers();
+        gf_destroy(g_ctx);
+    }
+    std::printf("%s: %d checks, %d failed\n", mode.c_str(), g_checked, g_failed);
+    return g_failed == 0 ? 0 : 1;
+}
