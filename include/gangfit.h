@@ -170,6 +170,21 @@ int gf_avg_packing_efficiency(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const 
 int gf_packing_efficiencies(gf_ctx *ctx, gf_algo algo, const gf_app *app, const gf_result *result,
                             const uint32_t *exec_nodes, double *eff_out /* n_nodes * 3 */);
 
+/* Placing single executors: the reschedule / extra-executor path of the executor Filter
+ * (internal/extender/resource.go:594-703), n_req independent requests against the current snapshot and the executor
+ * order of gf_orders_set.
+ *   exe        n_req x 3 executor requests (canonical units, >= 0)
+ *   reserved   nullable, n_nodes x 3 (row-major, >= 0): subtracted from the snapshot's available resources first — the
+ *              overhead the reference counts twice for nodes that already carry reservations (`usage.Add(overhead)`
+ *              after NodeSchedulingMetadataForNodes already did, resource.go:640-643) for the first-fit
+ *              loop; the overhead map GetNodeCapacities receives as reservedResources (:682) for the other variant
+ *   minimal_fragmentation == 0: the first node of the order the executor fits (:658-662)
+ *   minimal_fragmentation != 0: rescheduleExecutorWithMinimalFragmentation (:675-703); hosts_app (nullable) holds, per
+ *              request, ceil(n_nodes / 32) words with bit n set when node n already hosts executors of the application
+ *   node_out   n_req node indices, GF_NO_NODE = "not enough capacity to reschedule the executor" (failure-fit) */
+int gf_executor_fit(gf_ctx *ctx, int minimal_fragmentation, uint32_t n_req, const int64_t *exe, const int64_t *reserved,
+                    const uint32_t *hosts_app, uint32_t *node_out);
+
 /* ---- node-range sharding of an INDEPENDENT batch across the GPUs of one box ----
  * One gf_ctx per GPU, each given the same snapshot and orders; gf_shard_set tells it which contiguous range of the
  * priority order it owns (ranges are cut on 64-slot boundaries of the merged driver/executor order; GF_ERR_UNSUPPORTED

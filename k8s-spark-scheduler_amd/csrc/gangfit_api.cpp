@@ -134,6 +134,10 @@ struct gf_ctx {
     DeviceBuf<double> d_eff;
     PinnedBuf<double> h_avg;
 
+    // single-executor requests (gf_executor_fit)
+    DeviceBuf<int64_t> d_xexe, d_xreserved;
+    DeviceBuf<uint32_t> d_xhosts, d_xout;
+
     // batch buffers
     DeviceBuf<gf_app> d_apps;
     DeviceBuf<gf_result> d_results;
@@ -418,6 +422,10 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_reserved.release();
     ctx->d_eff.release();
     ctx->h_avg.release();
+    ctx->d_xexe.release();
+    ctx->d_xreserved.release();
+    ctx->d_xhosts.release();
+    ctx->d_xout.release();
     ctx->d_apps.release();
     ctx->d_results.release();
     ctx->d_exec.release();
@@ -848,6 +856,43 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
 int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
                      uint64_t exec_nodes_cap) {
     return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);
+}
+
+int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, const int64_t* exe, const int64_t* reserved,
+                    const uint32_t* hosts_app, uint32_t* node_out) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_req == 0) return GF_OK;
+    if (!exe || !node_out) return fail(ctx, GF_ERR_INVALID, "exe/node_out must not be NULL");
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede gf_executor_fit");
+    for (size_t i = 0; i < 3 * (size_t)n_req; ++i)
+        if (exe[i] < 0 || exe[i] >= GF_MAX_ABS_QUANTITY) return fail(ctx, GF_ERR_INVALID, "executor request outside [0, 2^62)");
+    const uint32_t n = ctx->n_nodes;
+    if (reserved)
+        for (size_t i = 0; i < 3 * (size_t)n; ++i)
+            if (reserved[i] < 0 || reserved[i] >= GF_MAX_ABS_QUANTITY)
+                return fail(ctx, GF_ERR_INVALID, "reserved[%zu] outside [0, 2^62)", i);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t words = (n + 31) / 32;
+    GF_HIP(ctx, ctx->d_xexe.reserve(3 * (size_t)n_req));
+    GF_HIP(ctx, ctx->d_xout.reserve(n_req));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_xexe.ptr, exe, 3 * (size_t)n_req * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if (reserved) {
+        GF_HIP(ctx, ctx->d_xreserved.reserve(3 * (size_t)n + 1));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_xreserved.ptr, reserved, 3 * (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
+    const bool with_hosts = minimal_fragmentation && hosts_app && words > 0;
+    if (with_hosts) {
+        GF_HIP(ctx, ctx->d_xhosts.reserve((size_t)n_req * words));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_xhosts.ptr, hosts_app, (size_t)n_req * words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    GF_HIP(ctx, gangfit::launch_executor_fit(minimal_fragmentation != 0, make_table(ctx, ctx->d_snap.ptr),
+                                             reserved ? ctx->d_xreserved.ptr : nullptr, n_req, ctx->d_xexe.ptr,
+                                             with_hosts ? ctx->d_xhosts.ptr : nullptr, words, ctx->d_xout.ptr, st));
+    GF_HIP(ctx, hipMemcpyAsync(node_out, ctx->d_xout.ptr, (size_t)n_req * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    return GF_OK;
 }
 
 // ---- node-range sharding (gangfit_shard.inc)

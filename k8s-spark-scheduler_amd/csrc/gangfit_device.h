@@ -188,6 +188,12 @@ hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps,
                                const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
                                const gf_result* d_results, uint32_t* d_exec2, uint64_t half, hipStream_t stream);
 
+// Placing one executor per request (gangfit_executor.inc): first fit or the minimal-fragmentation choice.
+// d_reserved: 3 x n_nodes int64 by node index (row-major, nullable); d_hosts: per request a bit set over node indices.
+hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& table, const int64_t* d_reserved, uint32_t n_req,
+                               const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
+                               hipStream_t stream);
+
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
 // Writes the number of mismatching lanes/cases to *d_mismatch.
 hipError_t launch_selftest(uint64_t seed, uint32_t n_cases, uint32_t* d_mismatch, hipStream_t stream);

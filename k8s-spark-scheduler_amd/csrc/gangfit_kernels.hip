@@ -1163,6 +1163,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 #include "gangfit_fifo_narrow.inc"
 #include "gangfit_zones.inc"
 #include "gangfit_shard.inc"
+#include "gangfit_executor.inc"
 
 // ------------------------------------------------------------------------------------------------ self-test
 
@@ -1569,6 +1570,20 @@ hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps,
     else
         hipLaunchKernelGGL(shard_finish_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, app_grid(n_apps), block, 0, stream, n_shards,
                            n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
+    return hipGetLastError();
+}
+
+hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& table, const int64_t* d_reserved, uint32_t n_req,
+                               const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
+                               hipStream_t stream) {
+    if (n_req == 0) return hipSuccess;
+    const dim3 block(kWave * kWavesPerBlock);
+    if (minimal_fragmentation)
+        hipLaunchKernelGGL(executor_fit_kernel<true>, app_grid(n_req), block, 0, stream, table, d_reserved, n_req, d_exe,
+                           d_hosts, hosts_stride, d_node_out);
+    else
+        hipLaunchKernelGGL(executor_fit_kernel<false>, app_grid(n_req), block, 0, stream, table, d_reserved, n_req, d_exe,
+                           d_hosts, hosts_stride, d_node_out);
     return hipGetLastError();
 }
 

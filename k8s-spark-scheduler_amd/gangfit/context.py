@@ -150,6 +150,24 @@ class Context:
                                                       N.ptr(ex) if len(ex) else None, N.ptr(eff)))
         return eff
 
+    def executor_fit(self, exe, reserved=None, minimal_fragmentation: bool = False, hosts=None) -> np.ndarray:
+        """One node index (GF_NO_NODE = no capacity) per executor request: rescheduleExecutor's first-fit loop, or
+        rescheduleExecutorWithMinimalFragmentation.  hosts: (n_req, n_nodes) booleans."""
+        exe = np.ascontiguousarray(exe, dtype=np.int64).reshape(-1, 3)
+        r = None if reserved is None else np.ascontiguousarray(reserved, dtype=np.int64).reshape(-1, 3)
+        bits = None
+        if hosts is not None:
+            h = np.asarray(hosts, dtype=bool).reshape(len(exe), self.n_nodes)
+            words = (self.n_nodes + 31) // 32
+            pad = np.zeros((len(exe), words * 32), dtype=bool)
+            pad[:, : self.n_nodes] = h
+            bits = np.packbits(pad.reshape(len(exe), words, 32), axis=2, bitorder="little").view("<u4").reshape(len(exe), words)
+            bits = np.ascontiguousarray(bits)
+        out = np.zeros(len(exe), dtype=np.uint32)
+        self._check(self._lib.gf_executor_fit(self._h, int(minimal_fragmentation), len(exe), N.ptr(exe), N.ptr(r),
+                                              N.ptr(bits), N.ptr(out)))
+        return out
+
     def residual(self) -> np.ndarray:
         out = np.zeros((self.n_nodes, 3), dtype=np.int64)
         self._check(self._lib.gf_residual_get(self._h, N.ptr(out)))

@@ -120,6 +120,76 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNode(const std::string& ins
     return out;
 }
 
+SelectNodeResult SparkSchedulerExtender::rescheduleExecutor(const Pod& driver, const std::vector<std::string>& nodeNames,
+                                                            const std::vector<Node>& availableNodes,
+                                                            const std::set<std::string>& nodesHostingApp,
+                                                            bool isExtraExecutor) {
+    SelectNodeResult out;
+    std::string err;
+    auto resources = sparkResources(driver, &err);
+    if (!resources) {
+        out.outcome = outcome::failureInternal;
+        out.error = err;
+        return out;
+    }
+    int64_t exe[3];
+    if (!resources->ExecutorResources.canonical(exe) || exe[0] < 0 || exe[1] < 0 || exe[2] < 0) {
+        out.served = false;
+        out.error = "executor resources are not exactly representable";
+        return out;
+    }
+    NodeGroupResources usage = UsageForNodes(reservations);  // GetReservedResources
+    for (const auto& [n, r] : softReservationUsage) usage[n].Add(r);
+    std::set<std::string> had_usage;
+    for (const auto& kv : usage) had_usage.insert(kv.first);
+    NodeGroupSchedulingMetadata metadata = NodeSchedulingMetadataForNodes(availableNodes, usage, overhead);
+    auto [driverOrder, executorNodeNames] = sorter_.PotentialNodes(metadata, nodeNames);
+    (void)driverOrder;
+    FlatSnapshot snap;
+    if (!flatten(metadata, {}, executorNodeNames, &snap, &err) || !upload(binpacker_.ctx, snap, &err)) {
+        out.served = false;
+        out.error = err;
+        return out;
+    }
+    const bool minfrag = binpacker_.Name == "single-az-minimal-fragmentation";
+    // what this path subtracts on top of the snapshot: `usage.Add(overhead)` (:642) counts the overhead a second time
+    // for nodes NodeSchedulingMetadataForNodes already updated in place; GetNodeCapacities (:682) is handed the
+    // overhead map as reservedResources
+    std::vector<int64_t> reserved(3 * snap.names.size(), 0);
+    bool any_reserved = false;
+    for (size_t i = 0; i < snap.names.size(); ++i) {
+        auto o = overhead.find(snap.names[i]);
+        if (o == overhead.end()) continue;
+        if (!minfrag && !had_usage.count(snap.names[i])) continue;
+        int64_t v[3];
+        if (!o->second.canonical(v) || v[0] < 0 || v[1] < 0 || v[2] < 0) {
+            out.served = false;
+            out.error = "overhead of node " + snap.names[i] + " is not exactly representable";
+            return out;
+        }
+        for (int j = 0; j < 3; ++j) reserved[3 * i + j] = v[j];
+        any_reserved = true;
+    }
+    std::vector<uint32_t> hosts((snap.names.size() + 31) / 32, 0u);
+    for (const std::string& n : nodesHostingApp)
+        if (auto it = snap.index.find(n); it != snap.index.end()) hosts[it->second >> 5] |= 1u << (it->second & 31);
+    uint32_t node = GF_NO_NODE;
+    if (gf_executor_fit(binpacker_.ctx, minfrag ? 1 : 0, 1, exe, any_reserved ? reserved.data() : nullptr,
+                        minfrag ? hosts.data() : nullptr, &node) != GF_OK) {
+        out.served = false;
+        out.error = std::string("gf_executor_fit: ") + gf_last_error(binpacker_.ctx);
+        return out;
+    }
+    if (node == GF_NO_NODE) {
+        out.outcome = outcome::failureFit;
+        out.error = "not enough capacity to reschedule the executor";
+        return out;
+    }
+    out.node = snap.names[node];
+    out.outcome = isExtraExecutor ? outcome::successScheduledExtraExecutor : outcome::successRescheduled;
+    return out;
+}
+
 bool SparkSchedulerExtender::DoesPodExceedClusterCapacity(const Pod& driver, const std::vector<Node>& availableNodes,
                                                           const NodeGroupResources& nonSchedulableOverhead, bool* served,
                                                           std::string* err) {

@@ -13,6 +13,7 @@
 
 #include <map>
 #include <optional>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,8 @@ constexpr const char* failureFit = "failure-fit";
 constexpr const char* failureEarlierDriver = "failure-earlier-driver";
 constexpr const char* failureNonSparkPod = "failure-non-spark-pod";
 constexpr const char* success = "success";
+constexpr const char* successRescheduled = "success-rescheduled";
+constexpr const char* successScheduledExtraExecutor = "success-scheduled-extra-executor";
 }  // namespace outcome
 
 struct FifoConfig {  // config.FifoConfig
@@ -71,6 +74,13 @@ public:
     // nodes are used in lister order for both candidate lists.
     bool DoesPodExceedClusterCapacity(const Pod& driver, const std::vector<Node>& availableNodes,
                                       const NodeGroupResources& nonSchedulableOverhead, bool* served, std::string* err);
+
+    // rescheduleExecutor (resource.go:594-673) for an executor whose driver is `driver`: availableNodes = getNodes(nodeNames)
+    // (already narrowed to one zone by the caller when single-AZ dynamic allocation applies, :606-633);
+    // nodesHostingApp = getNodesWithExecutorsBelongingToSameApp (only read by single-az-minimal-fragmentation).
+    SelectNodeResult rescheduleExecutor(const Pod& driver, const std::vector<std::string>& nodeNames,
+                                        const std::vector<Node>& availableNodes,
+                                        const std::set<std::string>& nodesHostingApp, bool isExtraExecutor);
 
     bool shouldSkipDriverFifo(const Pod& pod, const std::string& instanceGroup) const;
 

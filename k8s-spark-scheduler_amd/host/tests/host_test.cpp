@@ -430,6 +430,52 @@ static void TestFifoAndBinpackers() {
     }
 }
 
+static std::map<std::string, std::string> DynamicAnnotations(int minExecutors, int maxExecutors, const char* driverMem,
+                                                             const char* driverCPU, const char* executorMem,
+                                                             const char* executorCPU) {
+    return {{"spark-driver-cpu", driverCPU},
+            {"spark-driver-mem", driverMem},
+            {"spark-driver-nvidia.com/gpu", "1"},
+            {"spark-executor-cpu", executorCPU},
+            {"spark-executor-mem", executorMem},
+            {"spark-dynamic-allocation-enabled", "true"},
+            {"spark-dynamic-allocation-min-executor-count", std::to_string(minExecutors)},
+            {"spark-dynamic-allocation-max-executor-count", std::to_string(maxExecutors)}};
+}
+
+static void TestMinimalFragmentationEdgeCase() {  // resource_test.go:127-170
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    auto ext = NewTestExtender("single-az-minimal-fragmentation", {node1, node2});
+    Pod staticDriver = Driver("static-app", StaticAnnotations(0, "4", "1", "1", "1"));
+    Pod dynDriver = Driver("dyn-app", DynamicAnnotations(0, 1, "1", "4", "1", "3"), 1);
+    // "schedule a driver on each node"
+    SelectNodeResult r = ext.selectDriverNode("batch-medium-priority", staticDriver, {"node1"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::success) && r.node == "node1");
+    if (r.created) ext.reservations.push_back(*r.created);
+    r = ext.selectDriverNode("batch-medium-priority", dynDriver, {"node2"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::success) && r.node == "node2");
+    if (r.created) ext.reservations.push_back(*r.created);
+    // "This pod should be scheduled on node2 has it has the smallest capacity"
+    r = ext.rescheduleExecutor(dynDriver, {"node1", "node2"}, ext.nodes, {}, true);
+    CHECK(r.served && r.outcome == std::string(outcome::successScheduledExtraExecutor) && r.node == "node2");
+    // the first-fit packers take the first node of the order instead (node1: less free memory)
+    auto tight = NewTestExtender("single-az-tightly-pack", {node1, node2});
+    tight.reservations = ext.reservations;
+    r = tight.rescheduleExecutor(dynDriver, {"node1", "node2"}, tight.nodes, {}, false);
+    CHECK(r.served && r.outcome == std::string(outcome::successRescheduled) && r.node == "node1");
+    // an executor already running on node1 attracts the next one (resource_test.go:73-125)
+    r = ext.rescheduleExecutor(dynDriver, {"node1", "node2"}, ext.nodes, {"node1"}, true);
+    CHECK(r.served && r.node == "node1");
+    // quirk 5: with overhead on a node that also carries reservations the first-fit loop sees the overhead twice
+    tight.overhead["node1"] = Resources{Quantity::FromInt(2), Quantity(), Quantity()};
+    // node1: 8 - 1 (static driver) - 2 - 2 = 3 cpu < 3? no: exactly 3 -> still fits; one more milli-core of overhead does not
+    r = tight.rescheduleExecutor(dynDriver, {"node1", "node2"}, tight.nodes, {}, false);
+    CHECK(r.served && r.node == "node1");
+    tight.overhead["node1"] = Resources{Quantity::FromMilli(2001), Quantity(), Quantity()};
+    r = tight.rescheduleExecutor(dynDriver, {"node1", "node2"}, tight.nodes, {}, false);
+    CHECK(r.served && r.node == "node2");  // 8 - 1 - 2*2.001 < 3 although allocatable - usage - overhead = 4.999 >= 3
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu" || mode == "all") {
@@ -453,6 +499,7 @@ int main(int argc, char** argv) {
         TestUnschedulablePodMarker();
         TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs();
         TestFifoAndBinpackers();
+        TestMinimalFragmentationEdgeCase();
         gf_destroy(g_ctx);
     }
     std::printf("%s: %d checks, %d failed\n", mode.c_str(), g_checked, g_failed);

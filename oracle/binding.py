@@ -79,6 +79,10 @@ def lib() -> C.CDLL:
         L.go_packing_efficiency.argtypes = [p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, p]
         L.go_executor_first_fit.restype = C.c_uint32
         L.go_executor_first_fit.argtypes = [p, C.c_uint32, p, p, C.c_uint32]
+        L.go_executor_first_fit_reserved.restype = C.c_uint32
+        L.go_executor_first_fit_reserved.argtypes = [p, C.c_uint32, p, p, p, C.c_uint32]
+        L.go_executor_min_frag.restype = C.c_uint32
+        L.go_executor_min_frag.argtypes = [p, C.c_uint32, p, p, p, C.c_uint32, p]
         _lib = L
     return _lib
 
@@ -215,3 +219,15 @@ def executor_first_fit(avail, exe, exec_order) -> int:
     e = np.asarray(exe, dtype=np.int64)
     x = np.ascontiguousarray(exec_order, dtype=np.uint32)
     return int(lib().go_executor_first_fit(_ptr(avail), len(avail), _ptr(e), _ptr(x), len(x)))
+
+
+def executor_fit(avail, exe, exec_order, reserved=None, minimal_fragmentation=False, hosts=None) -> int:
+    """One executor through rescheduleExecutor's first-fit loop or rescheduleExecutorWithMinimalFragmentation."""
+    avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3)
+    e = np.asarray(exe, dtype=np.int64)
+    x = np.ascontiguousarray(exec_order, dtype=np.uint32)
+    r = None if reserved is None else np.ascontiguousarray(reserved, dtype=np.int64).reshape(-1, 3)
+    if minimal_fragmentation:
+        h = None if hosts is None else np.ascontiguousarray(hosts, dtype=np.uint8)
+        return int(lib().go_executor_min_frag(_ptr(avail), len(avail), _ptr(r), _ptr(e), _ptr(x), len(x), _ptr(h)))
+    return int(lib().go_executor_first_fit_reserved(_ptr(avail), len(avail), _ptr(r), _ptr(e), _ptr(x), len(x)))

@@ -781,3 +781,40 @@ uint32_t go_executor_first_fit(const int64_t *avail, uint32_t n_nodes, const int
     }
     return GO_NO_NODE;
 }
+
+/* rescheduleExecutorWithMinimalFragmentation, internal/extender/resource.go:675-703: capacities through
+ * capacity.GetNodeCapacities(executorNodeNames, metadata, overhead, executorResources) (capacity.go:78-102), then the
+ * `best` switch (:686-699).  reserved: n_nodes x 3 or NULL; hosts: one byte per node (non-zero = the node already hosts
+ * executors of this application) or NULL. */
+uint32_t go_executor_min_frag(const int64_t *avail, uint32_t n_nodes, const int64_t *reserved, const int64_t exe[3],
+                              const uint32_t *exec_order, uint32_t n_x, const uint8_t *hosts) {
+    static const int64_t zero[3] = {0, 0, 0};
+    uint32_t best = GO_NO_NODE;
+    int64_t best_cap = 0;
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t n = exec_order[i];
+        if (n >= n_nodes) continue;                                                  /* capacity.go:87 */
+        int64_t cap = go_node_capacity(&avail[3 * n], reserved ? &reserved[3 * n] : zero, exe);
+        if (cap < 1) continue;                                                       /* :685 */
+        int h = hosts && hosts[n], bh = best != GO_NO_NODE && hosts && hosts[best];
+        if (best == GO_NO_NODE || (h && !bh) || (h == bh && cap < best_cap)) {        /* :687-698 */
+            best = n;
+            best_cap = cap;
+        }
+    }
+    return best;
+}
+
+/* The first-fit loop of rescheduleExecutor (resource.go:658-662) against availableResources = the snapshot minus
+ * `reserved` (the overhead counted a second time by `usage.Add(overhead)`, :640-643). */
+uint32_t go_executor_first_fit_reserved(const int64_t *avail, uint32_t n_nodes, const int64_t *reserved,
+                                        const int64_t exe[3], const uint32_t *exec_order, uint32_t n_x) {
+    for (uint32_t i = 0; i < n_x; ++i) {
+        uint32_t n = exec_order[i];
+        if (n >= n_nodes) continue;
+        int64_t a[3];
+        for (int j = 0; j < 3; ++j) a[j] = avail[3 * n + j] - (reserved ? reserved[3 * n + j] : 0);
+        if (!res_greater_than(exe, a)) return n;
+    }
+    return GO_NO_NODE;
+}

@@ -118,6 +118,15 @@ void go_packing_efficiency(const int64_t *avail, const int64_t *sched, uint32_t 
 uint32_t go_executor_first_fit(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3],
                                const uint32_t *exec_order, uint32_t n_x);
 
+/* The same loop against the snapshot minus `reserved` (n_nodes x 3 or NULL): the overhead that the reference counts a
+ * second time on this path (resource.go:640-643). */
+uint32_t go_executor_first_fit_reserved(const int64_t *avail, uint32_t n_nodes, const int64_t *reserved,
+                                        const int64_t exe[3], const uint32_t *exec_order, uint32_t n_x);
+
+/* rescheduleExecutorWithMinimalFragmentation (internal/extender/resource.go:675-703). */
+uint32_t go_executor_min_frag(const int64_t *avail, uint32_t n_nodes, const int64_t *reserved, const int64_t exe[3],
+                              const uint32_t *exec_order, uint32_t n_x, const uint8_t *hosts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+"""Placing single executors (rescheduleExecutor, internal/extender/resource.go:594-703): oracle pinned by the reference's
+TestMinimalFragmentation / TestMinimalFragmentationEdgeCase (resource_test.go:73-170), GPU parity through
+gf_executor_fit."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from test_gpu_parity import _random_problem
+
+GIB = 1 << 30
+NO = 0xFFFFFFFF
+
+
+def test_reference_minimal_fragmentation_edge_case():
+    """resource_test.go:127-170: a 4-byte-memory driver on node1 (1 cpu) and a 4-cpu driver on node2 (1 byte); the extra
+    executor (3 cpu, 1 byte) must go to node2 — it sorts second (more free memory) but has the smaller capacity."""
+    avail = [[8000 - 1000, 8 * GIB - 4, 0], [8000 - 4000, 8 * GIB - 1, 0]]
+    order = [0, 1]  # free memory ascending: node1 first
+    exe = [3000, 1, 0]
+    assert ob.node_capacity(avail[0], [0, 0, 0], exe) == 2 and ob.node_capacity(avail[1], [0, 0, 0], exe) == 1
+    assert ob.executor_fit(avail, exe, order, minimal_fragmentation=True) == 1
+    assert ob.executor_fit(avail, exe, order) == 0  # the plain first-fit loop would have said node1
+
+
+def test_reference_minimal_fragmentation_attracts_to_hosting_node():
+    """resource_test.go:73-125: node1 carries the 3 static pods, node2 the dynamic driver and exec-1; exec-2 must follow
+    exec-1 to node2 although node1 comes first in the order."""
+    avail = [[8000 - 3000, 8 * GIB - 3, 0], [8000 - 2000, 8 * GIB - 2, 0]]
+    assert ob.executor_fit(avail, [1000, 1, 0], [0, 1], minimal_fragmentation=True, hosts=[0, 1]) == 1
+    # without the hint the smaller capacity wins (node1: 5 < node2: 6)
+    assert ob.executor_fit(avail, [1000, 1, 0], [0, 1], minimal_fragmentation=True) == 0
+
+
+def test_oracle_edge_cases():
+    avail = [[1, 1, 0], [5, 5, 0], [9, 9, 1]]
+    assert ob.executor_fit(avail, [2, 2, 0], [0, 1, 2]) == 1
+    assert ob.executor_fit(avail, [2, 2, 0], [0, 1, 2], reserved=[[0, 0, 0], [4, 0, 0], [0, 0, 0]]) == 2  # quirk 5
+    assert ob.executor_fit(avail, [20, 2, 0], [0, 1, 2]) == NO
+    assert ob.executor_fit(avail, [2, 2, 0], [0, 1, 2], minimal_fragmentation=True) == 1  # caps 0, 2, 4
+    assert ob.executor_fit(avail, [2, 2, 0], [2, 1, 0], minimal_fragmentation=True, hosts=[1, 0, 1]) == 2
+    assert ob.executor_fit(avail, [0, 0, 0], [0, 1, 2], minimal_fragmentation=True) == 0  # all math.MaxInt: first stays
+    assert ob.executor_fit(avail, [2, 2, 2], [0, 1, 2], minimal_fragmentation=True) == NO
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["general", "merged", "identical"])
+@pytest.mark.parametrize("n", [1, 64, 65, 700, 3000])
+def test_gpu_matches_oracle(gf_ctx, n, layout):
+    rng = np.random.default_rng(8 + n + 3 * len(layout))
+    for tight in (True, False):
+        avail, D, X, drv, exe, k = _random_problem(rng, n, 120, tight, layout)
+        gf_ctx.set_snapshot(avail)
+        gf_ctx.set_orders(D, X)
+        reserved = rng.integers(0, 4, size=(n, 3)).astype(np.int64) * (rng.random((n, 1)) < 0.3)
+        hosts = rng.random((len(exe), n)) < 0.05
+        for res in (None, reserved):
+            got = gf_ctx.executor_fit(exe, reserved=res)
+            want = [ob.executor_fit(avail, e, X, reserved=res) for e in exe]
+            assert got.tolist() == want
+            for h in (None, hosts):
+                got = gf_ctx.executor_fit(exe, reserved=res, minimal_fragmentation=True, hosts=h)
+                want = [ob.executor_fit(avail, e, X, reserved=res, minimal_fragmentation=True,
+                                        hosts=None if h is None else h[i]) for i, e in enumerate(exe)]
+                assert got.tolist() == want
+
+
+@pytest.mark.gpu
+def test_gpu_reference_pinned_cases(gf_ctx):
+    gf_ctx.set_snapshot([[7000, 8 * GIB - 4, 0], [4000, 8 * GIB - 1, 0]])
+    gf_ctx.set_orders([0, 1], [0, 1])
+    assert gf_ctx.executor_fit([[3000, 1, 0]], minimal_fragmentation=True).tolist() == [1]
+    assert gf_ctx.executor_fit([[3000, 1, 0]]).tolist() == [0]
+    gf_ctx.set_snapshot([[5000, 8 * GIB - 3, 0], [6000, 8 * GIB - 2, 0]])
+    gf_ctx.set_orders([0, 1], [0, 1])
+    assert gf_ctx.executor_fit([[1000, 1, 0]], minimal_fragmentation=True, hosts=[[False, True]]).tolist() == [1]
+    assert gf_ctx.executor_fit([[9000, 1, 0]], minimal_fragmentation=True).tolist() == [NO]
