@@ -117,6 +117,34 @@ int gf_snapshot_set(gf_ctx *ctx, uint32_t n_nodes, const int64_t *avail_cpu_mill
                     const int64_t *avail_gpu, const int64_t *sched_cpu_milli, const int64_t *sched_mem_bytes,
                     const int64_t *sched_gpu);
 
+/* ---- the step BEFORE the decisions, on the device ----
+ * Builds the snapshot from the flat cluster state and installs it (the equivalent of gf_snapshot_set + gf_zones_set +
+ * gf_orders_set on the result):
+ *   UsageForNodes — the ResourceReservation replay (LIB/resources/resources.go:31-43): res_* hold one entry per
+ *     reservation of every ResourceReservation (and per soft reservation, resourcereservations.go:258-263) as
+ *     (node index, cpu milli, memory bytes, gpus); entries whose node index is >= n_nodes are ignored;
+ *   NodeSchedulingMetadataForNodes (resources.go:61-100): available = allocatable - (usage + overhead),
+ *     schedulable = allocatable - overhead;
+ *   NodeSorter.PotentialNodes (internal/sort/nodesorting.go:41-122): zones by free (memory, cpu) ascending — ties keep
+ *     zone-id order, so assign ids in label order —, nodes by (zone rank, free memory, free cpu, name) with
+ *     name_rank[n] = rank of node n's name in lexicographic order (a permutation of 0..n_nodes-1); driver candidates =
+ *     nodes flagged GF_NODE_DRIVER_CANDIDATE (the Filter request's NodeNames), executor candidates = ready and not
+ *     unschedulable; *_label_rank (nullable): rank of the node's value of the configured priority label, UINT32_MAX for
+ *     "not ranked" — a stable re-sort of the respective list (:161-199).
+ * driver_order_out / exec_order_out (nullable, room for n_nodes entries each) receive the two orders. */
+#define GF_NODE_UNSCHEDULABLE 1u
+#define GF_NODE_READY 2u
+#define GF_NODE_DRIVER_CANDIDATE 4u
+int gf_snapshot_build(gf_ctx *ctx, uint32_t n_nodes, const int64_t *alloc_cpu_milli, const int64_t *alloc_mem_bytes,
+                      const int64_t *alloc_gpu, const int64_t *over_cpu_milli, const int64_t *over_mem_bytes,
+                      const int64_t *over_gpu, uint32_t n_res, const uint32_t *res_node, const int64_t *res_cpu_milli,
+                      const int64_t *res_mem_bytes, const int64_t *res_gpu, const uint32_t *node_flags,
+                      const uint32_t *zone_of_node, uint32_t n_zones, const uint32_t *name_rank,
+                      const uint32_t *driver_label_rank, const uint32_t *exec_label_rank, uint32_t *driver_order_out,
+                      uint32_t *n_d_out, uint32_t *exec_order_out, uint32_t *n_x_out);
+/* The installed snapshot, n_nodes x 3 row-major each (either may be NULL). */
+int gf_snapshot_get(gf_ctx *ctx, int64_t *avail_out, int64_t *sched_out);
+
 /* Zone label of every node (NodeSchedulingMetadata.ZoneLabel, LIB/resources/resources.go:78-81, 158-166) as a dense id
  * the caller assigns per distinct label string.  Optional: without it every node is in one zone (the reference's
  * "default" label).  Call after gf_snapshot_set and before gf_orders_set (a new snapshot drops the zones). */

@@ -5,6 +5,7 @@
 // device path cannot serve a call the function returns < 0 and the caller (the Go shim) decides what to do.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -73,7 +74,7 @@ struct PinnedBuf {
 }  // namespace
 
 struct gf_ctx {
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: gf_snapshot_build installs its result through the public setters
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -133,6 +134,13 @@ struct gf_ctx {
     DeviceBuf<int64_t> d_reserved;
     DeviceBuf<double> d_eff;
     PinnedBuf<double> h_avg;
+
+    // gf_snapshot_build
+    DeviceBuf<int64_t> d_bi64;   // alloc | overhead | usage | avail | sched (3n each) | keys_a | keys_b (n each) | res_req (3r) | zone_sum
+    DeviceBuf<uint32_t> d_bu32;  // zone | name_rank | perm_a | perm_b (n each) | res_node (r) | zone_order | zone_rank
+    DeviceBuf<unsigned char> d_btemp;
+    PinnedBuf<int64_t> h_bcols;  // avail | sched (3n each)
+    PinnedBuf<uint32_t> h_border;
 
     // single-executor requests (gf_executor_fit)
     DeviceBuf<int64_t> d_xexe, d_xreserved;
@@ -422,6 +430,11 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_reserved.release();
     ctx->d_eff.release();
     ctx->h_avg.release();
+    ctx->d_bi64.release();
+    ctx->d_bu32.release();
+    ctx->d_btemp.release();
+    ctx->h_bcols.release();
+    ctx->h_border.release();
     ctx->d_xexe.release();
     ctx->d_xreserved.release();
     ctx->d_xhosts.release();
@@ -456,7 +469,7 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
                     const int64_t* avail_gpu, const int64_t* sched_cpu_milli, const int64_t* sched_mem_bytes,
                     const int64_t* sched_gpu) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_nodes > 0 && (!avail_cpu_milli || !avail_mem_bytes || !avail_gpu))
         return fail(ctx, GF_ERR_INVALID, "available arrays must not be NULL");
     if (n_nodes >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "too many nodes");
@@ -500,7 +513,7 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
 
 int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_zones_set");
     if (ctx->n_nodes > 0 && !zone_of_node) return fail(ctx, GF_ERR_INVALID, "zone array must not be NULL");
     ctx->zone.assign(zone_of_node, zone_of_node + ctx->n_nodes);
@@ -510,7 +523,7 @@ int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
 
 int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const uint32_t* exec_order, uint32_t n_x) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_orders_set");
     if ((n_d > 0 && !driver_order) || (n_x > 0 && !exec_order))
         return fail(ctx, GF_ERR_INVALID, "order arrays must not be NULL");
@@ -800,7 +813,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
 int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results,
                  uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_apps > 0 && (!apps || !results)) return fail(ctx, GF_ERR_INVALID, "apps/results must not be NULL");
     if (chain_failed_at) *chain_failed_at = -1;
     if (n_apps == 0) return GF_OK;
@@ -858,10 +871,165 @@ int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* re
     return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);
 }
 
+int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli, const int64_t* alloc_mem_bytes,
+                      const int64_t* alloc_gpu, const int64_t* over_cpu_milli, const int64_t* over_mem_bytes,
+                      const int64_t* over_gpu, uint32_t n_res, const uint32_t* res_node, const int64_t* res_cpu_milli,
+                      const int64_t* res_mem_bytes, const int64_t* res_gpu, const uint32_t* node_flags,
+                      const uint32_t* zone_of_node, uint32_t n_zones, const uint32_t* name_rank,
+                      const uint32_t* driver_label_rank, const uint32_t* exec_label_rank, uint32_t* driver_order_out,
+                      uint32_t* n_d_out, uint32_t* exec_order_out, uint32_t* n_x_out) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const uint32_t n = n_nodes;
+    if (n >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "too many nodes");
+    if (n > 0 && (!alloc_cpu_milli || !alloc_mem_bytes || !alloc_gpu || !node_flags || !name_rank))
+        return fail(ctx, GF_ERR_INVALID, "allocatable / node_flags / name_rank must not be NULL");
+    const bool with_over = over_cpu_milli || over_mem_bytes || over_gpu;
+    if (with_over && !(over_cpu_milli && over_mem_bytes && over_gpu))
+        return fail(ctx, GF_ERR_INVALID, "overhead columns must be all NULL or all set");
+    if (n_res > 0 && (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu))
+        return fail(ctx, GF_ERR_INVALID, "reservation columns must not be NULL");
+    if (zone_of_node == nullptr) n_zones = 1;
+    if (n_zones == 0 || n_zones > 4096) return fail(ctx, GF_ERR_INVALID, "n_zones = %u outside [1, 4096]", n_zones);
+    {  // name_rank must be a permutation: it seeds the stable sort with the name order (nodesorting.go:92)
+        std::vector<uint8_t> seen(n, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (name_rank[i] >= n || seen[name_rank[i]]) return fail(ctx, GF_ERR_INVALID, "name_rank is not a permutation");
+            seen[name_rank[i]] = 1;
+        }
+        if (zone_of_node)
+            for (uint32_t i = 0; i < n; ++i)
+                if (zone_of_node[i] >= n_zones) return fail(ctx, GF_ERR_INVALID, "zone_of_node[%u] >= n_zones", i);
+    }
+    const int64_t* cols[3] = {alloc_cpu_milli, alloc_mem_bytes, alloc_gpu};
+    const int64_t* ocols[3] = {over_cpu_milli, over_mem_bytes, over_gpu};
+    const int64_t* rcols[3] = {res_cpu_milli, res_mem_bytes, res_gpu};
+    const int64_t lim = GF_MAX_ABS_QUANTITY >> 12;  // headroom for the sums: 4096 full-size terms still fit
+    for (int j = 0; j < 3; ++j) {
+        for (uint32_t i = 0; i < n; ++i)
+            if (cols[j][i] < 0 || cols[j][i] >= GF_MAX_ABS_QUANTITY || (with_over && (ocols[j][i] < 0 || ocols[j][i] >= lim)))
+                return fail(ctx, GF_ERR_INVALID, "allocatable / overhead value out of range at node %u", i);
+        for (uint32_t i = 0; i < n_res; ++i)
+            if (rcols[j][i] < 0 || rcols[j][i] >= lim) return fail(ctx, GF_ERR_INVALID, "reservation %u out of range", i);
+    }
+    if ((uint64_t)n_res >= (1ull << 32) - 1) return fail(ctx, GF_ERR_INVALID, "too many reservations");
+    if (n == 0) {
+        int rc = gf_snapshot_set(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc != GF_OK) return rc;
+        if (n_d_out) *n_d_out = 0;
+        if (n_x_out) *n_x_out = 0;
+        return gf_orders_set(ctx, nullptr, 0, nullptr, 0);
+    }
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // ---- device buffers
+    const size_t N = n, R = n_res, Z = n_zones;
+    GF_HIP(ctx, ctx->d_bi64.reserve(15 * N + 2 * N + 3 * R + 3 * Z + 8));
+    GF_HIP(ctx, ctx->d_bu32.reserve(4 * N + R + 2 * Z + 8));
+    const size_t temp = gangfit::snapshot_sort_temp_bytes(n);
+    GF_HIP(ctx, ctx->d_btemp.reserve(temp + 16));
+    int64_t* d_alloc = ctx->d_bi64.ptr;
+    int64_t* d_over = d_alloc + 3 * N;
+    int64_t* d_usage = d_over + 3 * N;
+    int64_t* d_avail = d_usage + 3 * N;
+    int64_t* d_sched = d_avail + 3 * N;
+    int64_t* d_keys_a = d_sched + 3 * N;
+    int64_t* d_keys_b = d_keys_a + N;
+    int64_t* d_res_req = d_keys_b + N;
+    int64_t* d_zone_sum = d_res_req + 3 * R;
+    uint32_t* d_zone = ctx->d_bu32.ptr;
+    uint32_t* d_name_rank = d_zone + N;
+    uint32_t* d_perm_a = d_name_rank + N;
+    uint32_t* d_perm_b = d_perm_a + N;
+    uint32_t* d_res_node = d_perm_b + N;
+    uint32_t* d_zone_order = d_res_node + R;
+    uint32_t* d_zone_rank = d_zone_order + Z;
+    for (int j = 0; j < 3; ++j) {
+        GF_HIP(ctx, hipMemcpyAsync(d_alloc + j * N, cols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (with_over) GF_HIP(ctx, hipMemcpyAsync(d_over + j * N, ocols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (R) GF_HIP(ctx, hipMemcpyAsync(d_res_req + j * R, rcols[j], R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
+    if (R) GF_HIP(ctx, hipMemcpyAsync(d_res_node, res_node, R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (zone_of_node)
+        GF_HIP(ctx, hipMemcpyAsync(d_zone, zone_of_node, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    else
+        GF_HIP(ctx, hipMemsetAsync(d_zone, 0, N * sizeof(uint32_t), st));
+    GF_HIP(ctx, hipMemcpyAsync(d_name_rank, name_rank, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    gangfit::SnapshotBuild b{};
+    b.n_nodes = n;
+    b.n_res = n_res;
+    b.n_zones = n_zones;
+    b.d_alloc = d_alloc;
+    b.d_overhead = with_over ? d_over : nullptr;
+    b.d_res_node = d_res_node;
+    b.d_res_req = d_res_req;
+    b.d_zone = d_zone;
+    b.d_name_rank = d_name_rank;
+    b.d_usage = d_usage;
+    b.d_avail = d_avail;
+    b.d_sched = d_sched;
+    b.d_zone_sum = d_zone_sum;
+    b.d_zone_order = d_zone_order;
+    b.d_zone_rank = d_zone_rank;
+    b.d_perm_a = d_perm_a;
+    b.d_perm_b = d_perm_b;
+    b.d_keys_a = d_keys_a;
+    b.d_keys_b = d_keys_b;
+    b.d_temp = ctx->d_btemp.ptr;
+    b.temp_bytes = temp;
+    GF_HIP(ctx, gangfit::launch_snapshot_build(b, st));
+    GF_HIP(ctx, ctx->h_bcols.reserve(6 * N));
+    GF_HIP(ctx, ctx->h_border.reserve(N));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_bcols.ptr, d_avail, 6 * N * sizeof(int64_t), hipMemcpyDeviceToHost, st));  // avail | sched
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    // ---- the two candidate lists (nodesorting.go:47-63) and the optional stable label re-sorts (:161-199)
+    const int64_t* h_avail = ctx->h_bcols.ptr;
+    const int64_t* h_sched = ctx->h_bcols.ptr + 3 * N;
+    bool sched_ok = true;
+    for (size_t i = 0; i < 3 * N && sched_ok; ++i) sched_ok = h_sched[i] >= 0;
+    std::vector<uint32_t> D, X;
+    D.reserve(N);
+    X.reserve(N);
+    for (size_t i = 0; i < N; ++i) {
+        const uint32_t node = ctx->h_border.ptr[i];
+        const uint32_t f = node_flags[node];
+        if (f & GF_NODE_DRIVER_CANDIDATE) D.push_back(node);
+        if (!(f & GF_NODE_UNSCHEDULABLE) && (f & GF_NODE_READY)) X.push_back(node);
+    }
+    auto by_rank = [](std::vector<uint32_t>& v, const uint32_t* rank) {
+        std::stable_sort(v.begin(), v.end(), [rank](uint32_t a, uint32_t b) { return rank[a] < rank[b]; });
+    };
+    if (driver_label_rank) by_rank(D, driver_label_rank);
+    if (exec_label_rank) by_rank(X, exec_label_rank);
+    int rc = gf_snapshot_set(ctx, n, h_avail, h_avail + N, h_avail + 2 * N, sched_ok ? h_sched : nullptr,
+                             sched_ok ? h_sched + N : nullptr, sched_ok ? h_sched + 2 * N : nullptr);
+    if (rc != GF_OK) return rc;
+    if (zone_of_node && (rc = gf_zones_set(ctx, zone_of_node)) != GF_OK) return rc;
+    if ((rc = gf_orders_set(ctx, D.data(), (uint32_t)D.size(), X.data(), (uint32_t)X.size())) != GF_OK) return rc;
+    if (n_d_out) *n_d_out = (uint32_t)D.size();
+    if (n_x_out) *n_x_out = (uint32_t)X.size();
+    if (driver_order_out) std::memcpy(driver_order_out, D.data(), D.size() * sizeof(uint32_t));
+    if (exec_order_out) std::memcpy(exec_order_out, X.data(), X.size() * sizeof(uint32_t));
+    return GF_OK;
+}
+
+int gf_snapshot_get(gf_ctx* ctx, int64_t* avail_out, int64_t* sched_out) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "no snapshot");
+    for (uint32_t i = 0; i < ctx->n_nodes; ++i)
+        for (int j = 0; j < 3; ++j) {
+            if (avail_out) avail_out[3 * (size_t)i + j] = ctx->avail[j][i];
+            if (sched_out) sched_out[3 * (size_t)i + j] = ctx->have_sched ? ctx->sched[j][i] : 0;
+        }
+    return GF_OK;
+}
+
 int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, const int64_t* exe, const int64_t* reserved,
                     const uint32_t* hosts_app, uint32_t* node_out) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_req == 0) return GF_OK;
     if (!exe || !node_out) return fail(ctx, GF_ERR_INVALID, "exe/node_out must not be NULL");
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede gf_executor_fit");
@@ -915,7 +1083,7 @@ int shard_ready(gf_ctx* ctx, gf_algo algo, gangfit::ShardRange* r) {
 
 int gf_shard_set(gf_ctx* ctx, uint32_t shard, uint32_t n_shards) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_shards == 0 || shard >= n_shards || n_shards > 1024)
         return fail(ctx, GF_ERR_INVALID, "shard %u of %u", shard, n_shards);
     ctx->shard = shard;
@@ -981,7 +1149,7 @@ int gf_shard_finish_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app
 int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps, const gf_result* results,
                               const uint32_t* exec_nodes, uint64_t exec_nodes_len, gf_avg_efficiency* out) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_apps > 0 && (!apps || !results || !out)) return fail(ctx, GF_ERR_INVALID, "apps/results/out must not be NULL");
     if (n_apps == 0) return GF_OK;
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede");
@@ -1037,7 +1205,7 @@ int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const 
 int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const gf_result* result,
                             const uint32_t* exec_nodes, double* eff_out) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!app || !result || !eff_out) return fail(ctx, GF_ERR_INVALID, "app/result/eff_out must not be NULL");
     if (!ctx->have_snapshot || !ctx->have_sched)
         return fail(ctx, GF_ERR_STATE, "efficiencies need gf_snapshot_set with the schedulable columns");
@@ -1074,7 +1242,7 @@ int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const 
 
 int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
     if (!ctx || !avail_out) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_orders || !ctx->work_valid) return fail(ctx, GF_ERR_STATE, "no FIFO chain has run on the current orders");
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, ctx->h_table.reserve(3 * (size_t)ctx->n_slots));
@@ -1107,7 +1275,7 @@ int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
 
 int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (out) {
@@ -1129,7 +1297,7 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
 
 int gf_selftest(gf_ctx* ctx, uint64_t seed, uint32_t n_cases, uint32_t* mismatches) {
     if (!ctx || !mismatches) return GF_ERR_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
     DeviceBuf<uint32_t> d;
     GF_HIP(ctx, d.reserve(1));

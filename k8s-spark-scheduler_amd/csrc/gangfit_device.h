@@ -194,6 +194,34 @@ hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& tabl
                                const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
                                hipStream_t stream);
 
+// Snapshot construction on the device (gangfit_snapshot.hip): reservation replay, available / schedulable columns,
+// zone order, node priority order.  All pointers are device buffers owned by the host layer; columns are SoA
+// (cpu | memory | gpu, n_nodes each).  On return (stream order) d_avail / d_sched hold the columns and d_perm_b the
+// node indices in priority order.
+struct SnapshotBuild {
+    uint32_t n_nodes, n_res, n_zones;
+    const int64_t* d_alloc;      // 3 * n_nodes
+    const int64_t* d_overhead;   // 3 * n_nodes or nullptr
+    const uint32_t* d_res_node;  // n_res
+    const int64_t* d_res_req;    // 3 * n_res (cpu | memory | gpu)
+    const uint32_t* d_zone;      // n_nodes
+    const uint32_t* d_name_rank; // n_nodes, a permutation
+    int64_t* d_usage;            // 3 * n_nodes
+    int64_t* d_avail;            // 3 * n_nodes
+    int64_t* d_sched;            // 3 * n_nodes
+    int64_t* d_zone_sum;         // 3 * n_zones (memory, cpu interleaved | population)
+    uint32_t* d_zone_order;      // n_zones
+    uint32_t* d_zone_rank;       // n_zones
+    uint32_t* d_perm_a;          // n_nodes
+    uint32_t* d_perm_b;          // n_nodes
+    int64_t* d_keys_a;           // n_nodes
+    int64_t* d_keys_b;           // n_nodes
+    void* d_temp;                // radix-sort scratch
+    size_t temp_bytes;
+};
+size_t snapshot_sort_temp_bytes(uint32_t n_nodes);
+hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream);
+
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.
 // Writes the number of mismatching lanes/cases to *d_mismatch.
 hipError_t launch_selftest(uint64_t seed, uint32_t n_cases, uint32_t* d_mismatch, hipStream_t stream);

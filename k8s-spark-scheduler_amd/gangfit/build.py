@@ -14,7 +14,7 @@ HOST_LIB_PATH = os.path.join(_PKG_ROOT, "libgangfit_host.so")
 HOST_TEST_PATH = os.path.join(_PKG_ROOT, "host_test")  # C++ tests of the host mirror (host/tests/host_test.cpp)
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 
-_SOURCES = ["gangfit_kernels.hip", "gangfit_api.cpp"]
+_SOURCES = ["gangfit_kernels.hip", "gangfit_snapshot.hip", "gangfit_api.cpp"]
 _HEADERS = [os.path.join(CSRC, "gangfit_device.h"), os.path.join(INCLUDE, "gangfit.h")]
 
 

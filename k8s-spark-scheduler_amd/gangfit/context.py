@@ -98,6 +98,41 @@ class Context:
         self._check(self._lib.gf_snapshot_set(self._h, len(avail), *[N.ptr(c) for c in cols], *[N.ptr(c) for c in scols]))
         self.n_nodes = len(avail)
 
+    def build_snapshot(self, alloc, node_flags, name_rank, overhead=None, res_node=None, res_req=None, zone=None,
+                       n_zones: int = 1, driver_label_rank=None, exec_label_rank=None):
+        """gf_snapshot_build: reservation replay + available/schedulable + priority orders on the device, installed as
+        the current snapshot.  Returns (driver_order, exec_order)."""
+        alloc = np.ascontiguousarray(alloc, dtype=np.int64).reshape(-1, 3)
+        n = len(alloc)
+        cols = [np.ascontiguousarray(alloc[:, j]) for j in range(3)]
+        ocols = [None] * 3
+        if overhead is not None:
+            overhead = np.ascontiguousarray(overhead, dtype=np.int64).reshape(-1, 3)
+            ocols = [np.ascontiguousarray(overhead[:, j]) for j in range(3)]
+        rn = np.zeros(0, dtype=np.uint32) if res_node is None else np.ascontiguousarray(res_node, dtype=np.uint32)
+        rr = np.zeros((0, 3), dtype=np.int64) if res_req is None else np.ascontiguousarray(res_req, dtype=np.int64).reshape(-1, 3)
+        rcols = [np.ascontiguousarray(rr[:, j]) for j in range(3)]
+        flags = np.ascontiguousarray(node_flags, dtype=np.uint32)
+        ranks = np.ascontiguousarray(name_rank, dtype=np.uint32)
+        z = None if zone is None else np.ascontiguousarray(zone, dtype=np.uint32)
+        dl = None if driver_label_rank is None else np.ascontiguousarray(driver_label_rank, dtype=np.uint32)
+        el = None if exec_label_rank is None else np.ascontiguousarray(exec_label_rank, dtype=np.uint32)
+        d_out, x_out = np.zeros(n + 1, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint32)
+        nd, nx = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.gf_snapshot_build(self._h, n, *[N.ptr(c) for c in cols], *[N.ptr(c) for c in ocols], len(rn),
+                                                N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(flags), N.ptr(z), n_zones,
+                                                N.ptr(ranks), N.ptr(dl), N.ptr(el), N.ptr(d_out), C.byref(nd), N.ptr(x_out),
+                                                C.byref(nx)))
+        self.n_nodes = n
+        return d_out[: nd.value].copy(), x_out[: nx.value].copy()
+
+    def snapshot(self):
+        """(avail, sched) of the installed snapshot, (n_nodes, 3) int64 each."""
+        a = np.zeros((self.n_nodes, 3), dtype=np.int64)
+        s = np.zeros((self.n_nodes, 3), dtype=np.int64)
+        self._check(self._lib.gf_snapshot_get(self._h, N.ptr(a), N.ptr(s)))
+        return a, s
+
     def set_zones(self, zone_of_node):
         """Zone id per node (after set_snapshot, before set_orders)."""
         z = np.ascontiguousarray(zone_of_node, dtype=np.uint32)

@@ -7,7 +7,9 @@
 // `host_test cpu` needs no GPU (parsing, sorting, snapshot, reservations); `host_test gpu` drives the device through
 // the C ABI exactly like the Go shim would.  Exit code 0 = all passed.
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -476,6 +478,139 @@ static void TestMinimalFragmentationEdgeCase() {  // resource_test.go:127-170
     CHECK(r.served && r.node == "node2");  // 8 - 1 - 2*2.001 < 3 although allocatable - usage - overhead = 4.999 >= 3
 }
 
+// gf_snapshot_build (reservation replay + metadata + priority orders on the device) against the string-keyed host mirror
+// of the same reference functions (UsageForNodes, NodeSchedulingMetadataForNodes, NodeSorter.PotentialNodes), which the
+// reference's sort tests pin.
+static void TestDeviceSnapshotBuildAgainstHostMirror() {
+    const int n = 300;
+    uint64_t rng = 0x5EED;
+    auto next = [&]() {
+        rng += 0x9E3779B97F4A7C15ull;
+        uint64_t z = rng;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    const char* zones[] = {"az-a", "az-b", "az-c"};  // ids in label order
+    std::vector<Node> nodes;
+    std::vector<std::string> requested;
+    LabelPriorityOrder pool{"pool", {"spot", "on-demand"}};
+    for (int i = 0; i < n; ++i) {
+        Node nd;
+        nd.Name = "node-" + std::to_string(next() % 100000) + "-" + std::to_string(i);
+        nd.labels[kLabelZoneFailureDomain] = zones[next() % 3];
+        const uint64_t p = next() % 3;
+        if (p < 2) nd.labels["pool"] = p == 0 ? "spot" : "on-demand";
+        nd.Allocatable = {{kResourceCPU, Quantity::FromInt(8 + 8 * (int64_t)(next() % 3))},
+                          {kResourceMemory, Quantity::FromInt((int64_t)(16 + 16 * (next() % 4)) * Gi)},
+                          {kResourceNvidiaGPU, Quantity::FromInt(next() % 10 == 0 ? 4 : 0)}};
+        nd.Unschedulable = next() % 20 == 0;
+        nd.Ready = next() % 20 != 0;
+        if (next() % 5 != 0) requested.push_back(nd.Name);
+        nodes.push_back(nd);
+    }
+    std::vector<ResourceReservation> rrs;
+    for (int r = 0; r < 120; ++r) {
+        ResourceReservation rr;
+        rr.Name = "app-" + std::to_string(r);
+        const int k = 1 + (int)(next() % 9);
+        for (int e = 0; e <= k; ++e) {
+            Reservation res;
+            res.Node = nodes[next() % n].Name;
+            res.Resources = {{kResourceCPU, Quantity::FromMilli(500 * (int64_t)(1 + next() % 8))},
+                             {kResourceMemory, Quantity::FromInt((int64_t)(1 + next() % 8) * Gi)},
+                             {kResourceNvidiaGPU, Quantity::FromInt(next() % 30 == 0 ? 1 : 0)}};
+            rr.Reservations[e == 0 ? "driver" : executorReservationName(e - 1)] = res;
+        }
+        rrs.push_back(rr);
+    }
+    NodeGroupResources overhead;
+    for (int i = 0; i < n; i += 3) overhead[nodes[i].Name] = Resources{Quantity::FromMilli(250), Quantity::FromInt(Gi / 2), Quantity()};
+    // ---- host mirror
+    NodeGroupResources usage = UsageForNodes(rrs);
+    NodeGroupSchedulingMetadata md = NodeSchedulingMetadataForNodes(nodes, usage, overhead);
+    NodeSorter sorter(std::nullopt, pool);
+    auto [wantD, wantX] = sorter.PotentialNodes(md, requested);
+    // ---- flat columns for the device
+    std::vector<std::string> sorted_names;
+    for (const Node& nd : nodes) sorted_names.push_back(nd.Name);
+    std::sort(sorted_names.begin(), sorted_names.end());
+    std::map<std::string, uint32_t> index, rank;
+    for (int i = 0; i < n; ++i) index[nodes[i].Name] = (uint32_t)i;
+    for (int i = 0; i < n; ++i) rank[sorted_names[i]] = (uint32_t)i;
+    std::set<std::string> req(requested.begin(), requested.end());
+    std::vector<int64_t> alloc[3], over[3], rreq[3];
+    std::vector<uint32_t> flags, zone, name_rank, exec_label, rnode;
+    for (const Node& nd : nodes) {
+        Resources a{nd.Allocatable.at(kResourceCPU), nd.Allocatable.at(kResourceMemory), nd.Allocatable.at(kResourceNvidiaGPU)};
+        int64_t v[3], o[3] = {0, 0, 0};
+        a.canonical(v);
+        if (overhead.count(nd.Name)) overhead.at(nd.Name).canonical(o);
+        for (int j = 0; j < 3; ++j) {
+            alloc[j].push_back(v[j]);
+            over[j].push_back(o[j]);
+        }
+        flags.push_back((nd.Unschedulable ? GF_NODE_UNSCHEDULABLE : 0u) | (nd.Ready ? GF_NODE_READY : 0u) |
+                        (req.count(nd.Name) ? GF_NODE_DRIVER_CANDIDATE : 0u));
+        const std::string& z = nd.labels.at(kLabelZoneFailureDomain);
+        zone.push_back(z == "az-a" ? 0u : (z == "az-b" ? 1u : 2u));
+        name_rank.push_back(rank.at(nd.Name));
+        auto l = nd.labels.find("pool");
+        exec_label.push_back(l == nd.labels.end() ? 0xFFFFFFFFu : (l->second == "spot" ? 0u : 1u));
+    }
+    for (const auto& rr : rrs)
+        for (const auto& [name, res] : rr.Reservations) {
+            rnode.push_back(index.at(res.Node));
+            Resources r{res.Resources.at(kResourceCPU), res.Resources.at(kResourceMemory), res.Resources.at(kResourceNvidiaGPU)};
+            int64_t v[3];
+            r.canonical(v);
+            for (int j = 0; j < 3; ++j) rreq[j].push_back(v[j]);
+        }
+    std::vector<uint32_t> D(n), X(n);
+    uint32_t nd = 0, nx = 0;
+    const int rc = gf_snapshot_build(g_ctx, n, alloc[0].data(), alloc[1].data(), alloc[2].data(), over[0].data(), over[1].data(),
+                                     over[2].data(), (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(),
+                                     rreq[2].data(), flags.data(), zone.data(), 3, name_rank.data(), nullptr, exec_label.data(),
+                                     D.data(), &nd, X.data(), &nx);
+    CHECK(rc == GF_OK);
+    if (rc != GF_OK) {
+        std::printf("   %s\n", gf_last_error(g_ctx));
+        return;
+    }
+    std::vector<std::string> gotD, gotX;
+    for (uint32_t i = 0; i < nd; ++i) gotD.push_back(nodes[D[i]].Name);
+    for (uint32_t i = 0; i < nx; ++i) gotX.push_back(nodes[X[i]].Name);
+    CHECK(gotD == wantD);
+    CHECK(gotX == wantX);
+    std::vector<int64_t> avail(3 * n), sched(3 * n);
+    CHECK(gf_snapshot_get(g_ctx, avail.data(), sched.data()) == GF_OK);
+    bool same = true;
+    for (int i = 0; i < n; ++i) {
+        int64_t a[3], s2[3];
+        md.at(nodes[i].Name).AvailableResources.canonical(a);
+        md.at(nodes[i].Name).SchedulableResources.canonical(s2);
+        for (int j = 0; j < 3; ++j) same = same && avail[3 * i + j] == a[j] && sched[3 * i + j] == s2[j];
+    }
+    CHECK(same);
+    // and a decision on the device-built snapshot equals the one through the string interface
+    Binpacker bp = SelectBinpacker("single-az-tightly-pack", g_ctx);
+    gf_app app{};
+    Resources::Create(1, 2 * Gi, 0).canonical(app.drv);
+    Resources::Create(2, 4 * Gi, 0).canonical(app.exe);
+    app.k = 40;
+    gf_result res{};
+    std::vector<uint32_t> exec(41);
+    CHECK(gf_spark_binpack(g_ctx, bp.Algo, &app, &res, exec.data(), 40) == GF_OK);
+    PackingResult want = bp.BinpackFunc(Resources::Create(1, 2 * Gi, 0), Resources::Create(2, 4 * Gi, 0), 40, wantD, wantX, md);
+    CHECK(want.served && want.HasCapacity == (res.has_capacity != 0));
+    if (want.HasCapacity && res.has_capacity) {
+        CHECK(nodes[res.driver_node].Name == want.DriverNode);
+        bool same_exec = true;
+        for (int i = 0; i < 40; ++i) same_exec = same_exec && nodes[exec[i]].Name == want.ExecutorNodes[i];
+        CHECK(same_exec);
+    }
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu" || mode == "all") {
@@ -500,6 +635,7 @@ int main(int argc, char** argv) {
         TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs();
         TestFifoAndBinpackers();
         TestMinimalFragmentationEdgeCase();
+        TestDeviceSnapshotBuildAgainstHostMirror();
         gf_destroy(g_ctx);
     }
     std::printf("%s: %d checks, %d failed\n", mode.c_str(), g_checked, g_failed);

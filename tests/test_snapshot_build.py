@@ -1,0 +1,98 @@
+"""Snapshot construction on the device (gf_snapshot_build: ResourceReservation replay, available / schedulable,
+priority orders) against the numpy restatement in oracle/pysnapshot.py, and the decisions made on the built snapshot
+against the oracle's decisions on the restated one."""
+import numpy as np
+import pytest
+
+import gangfit
+from gangfit import workloads as wl
+from oracle import binding as ob
+from oracle import pysnapshot as ps
+
+GIB = 1 << 30
+
+
+def _cluster(seed, n, n_rr, n_zones, with_overhead=True, labels=False):
+    rng = np.random.default_rng(seed)
+    shape = rng.integers(0, 4, size=n)
+    alloc = np.stack([np.array([16, 32, 64, 96])[shape] * 1000, np.array([64, 128, 256, 384])[shape] * GIB,
+                      np.where(rng.random(n) < 0.1, 8, 0)], axis=1).astype(np.int64)
+    overhead = None
+    if with_overhead:
+        overhead = np.stack([rng.integers(0, 8, size=n) * 250, rng.integers(0, 16, size=n) * (GIB // 4),
+                             np.zeros(n, dtype=np.int64)], axis=1).astype(np.int64)
+    # reservations: K+1 entries per ResourceReservation, concentrated so that some nodes are overcommitted
+    ks = rng.integers(1, 25, size=n_rr)
+    res_node = rng.integers(0, n + 3, size=int(ks.sum())).astype(np.uint32)  # a few entries point outside the listed nodes
+    res_req = np.stack([rng.choice([1000, 2000, 4000], size=len(res_node)), rng.choice([4, 8, 16], size=len(res_node)) * GIB,
+                        (rng.random(len(res_node)) < 0.02).astype(np.int64)], axis=1).astype(np.int64)
+    flags = (np.where(rng.random(n) < 0.05, ps.UNSCHEDULABLE, 0) | np.where(rng.random(n) < 0.95, ps.READY, 0) |
+             np.where(rng.random(n) < 0.8, ps.DRIVER_CANDIDATE, 0)).astype(np.uint32)
+    name_rank = rng.permutation(n).astype(np.uint32)
+    zone = rng.integers(0, n_zones, size=n).astype(np.uint32)
+    dl = el = None
+    if labels:
+        dl = rng.choice([0, 1, ps.UNRANKED], size=n).astype(np.uint32)
+        el = rng.choice([0, 1, 2, ps.UNRANKED], size=n).astype(np.uint32)
+    return dict(alloc=alloc, node_flags=flags, name_rank=name_rank, overhead=overhead, res_node=res_node, res_req=res_req,
+                zone=zone, n_zones=n_zones, driver_label_rank=dl, exec_label_rank=el)
+
+
+def test_numpy_restatement_small_known_answer():
+    """nodesorting_test.go:98-152 (TestAZAwareNodeSorting) through the flat interface: zone2 has less free memory."""
+    # names: zone1Node1, zone1Node2, zone1Node3, zone2Node1 -> ranks 0..3; zone ids in label order
+    alloc = [[1, 1, 0], [1, 2, 0], [2, 1, 0], [1, 1, 0]]
+    _, _, D, X = ps.build(alloc, [ps.READY | ps.DRIVER_CANDIDATE] * 4, [0, 1, 2, 3], zone=[0, 0, 0, 1], n_zones=2)
+    assert D.tolist() == [3, 0, 2, 1] and X.tolist() == [3, 0, 2, 1]
+    # usage and overhead: available = allocatable - (usage + overhead), schedulable = allocatable - overhead
+    avail, sched, D, X = ps.build([[8000, 8 * GIB, 1], [8000, 8 * GIB, 1]], [ps.READY | ps.DRIVER_CANDIDATE, ps.READY], [0, 1],
+                                  overhead=[[500, GIB, 0], [0, 0, 0]], res_node=[0, 0, 1, 7], res_req=[[1000, 1, 1], [1000, 1, 0],
+                                                                                                      [1000, 1, 0], [9, 9, 9]])
+    assert avail.tolist() == [[5500, 7 * GIB - 2, 0], [7000, 8 * GIB - 1, 1]]
+    assert sched.tolist() == [[7500, 7 * GIB, 1], [8000, 8 * GIB, 1]]
+    assert D.tolist() == [0] and X.tolist() == [0, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("labels", [False, True])
+@pytest.mark.parametrize("n,n_rr,n_zones", [(1, 0, 1), (5, 3, 2), (64, 40, 1), (1000, 300, 3), (20000, 4000, 4)])
+def test_device_build_matches_restatement(gf_ctx, n, n_rr, n_zones, labels):
+    c = _cluster(100 + n + n_zones, n, n_rr, n_zones, with_overhead=(n % 2 == 0), labels=labels)
+    D, X = gf_ctx.build_snapshot(**c)
+    avail, sched, rD, rX = ps.build(**c)
+    got_avail, got_sched = gf_ctx.snapshot()
+    assert np.array_equal(got_avail, avail)
+    assert np.array_equal(got_sched, sched)
+    assert np.array_equal(D, rD) and np.array_equal(X, rX)
+    # the decisions on the built snapshot: every registered packer family, independent and FIFO
+    w = wl.config(2, n_nodes=16, n_apps=min(64, 4 * n))
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+    oapps = ob.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+    for algo in (0, 1, 4):
+        gpu = gf_ctx.fit_batch(gangfit.GF_MODE_INDEPENDENT, algo, apps)
+        ref = ob.fit_independent(algo, avail, oapps, rD, rX, sched=sched, zone=c["zone"])
+        assert np.array_equal(gpu.results, ref.results)
+        gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps)
+        ref = ob.fit_fifo_chain(algo, avail, oapps, rD, rX, sched=sched, zone=c["zone"])
+        assert gpu.failed_at == ref.failed_at and np.array_equal(gpu.results, ref.results)
+        assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+
+
+@pytest.mark.gpu
+def test_config5_size_and_argument_errors(gf_ctx):
+    """100 000 nodes, 20 000 ResourceReservations (K+1 entries each) — BASELINE config 5's snapshot."""
+    c = _cluster(5, 100000, 20000, 3)
+    D, X = gf_ctx.build_snapshot(**c)
+    avail, sched, rD, rX = ps.build(**c)
+    got_avail, got_sched = gf_ctx.snapshot()
+    assert np.array_equal(got_avail, avail) and np.array_equal(got_sched, sched)
+    assert np.array_equal(D, rD) and np.array_equal(X, rX)
+    assert (avail < 0).any()  # the replay overcommits some nodes, as the workload intends
+    bad = dict(c)
+    bad["name_rank"] = np.zeros(100000, dtype=np.uint32)
+    with pytest.raises(gangfit.GangfitError):
+        gf_ctx.build_snapshot(**bad)
+    bad = dict(c)
+    bad["zone"] = np.full(100000, 7, dtype=np.uint32)
+    with pytest.raises(gangfit.GangfitError):
+        gf_ctx.build_snapshot(**bad)
