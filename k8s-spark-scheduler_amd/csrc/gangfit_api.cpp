@@ -116,6 +116,7 @@ struct gf_ctx {
     // GANGFIT_FIFO_KERNEL: "narrow" (default: narrow first, v2 as its wide fallback), "fused" (wide fused only),
     // "v2" (general-layout kernel only), "narrow+fused" (narrow first, wide fused as the fallback)
     bool fifo_use_narrow = true, fifo_wide_fused = false;
+    bool fifo_zoned_lds = true;  // GANGFIT_FIFO_ZONED=generic forces the global-memory chain for the zone-aware packers
     int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
@@ -255,10 +256,40 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
-        GF_HIP(ctx, gangfit::launch_fit_fifo_generic(inner, true, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
+        const bool az_aware = algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK;
+        const int32_t* run_if = nullptr;
+        // fast path: tightly-pack family, merged layout, narrow table, every candidate view gets its own wavefront
+        if (inner == GF_ALGO_TIGHTLY_PACK && ctx->merged && ctx->narrow_ok && ctx->fifo_zoned_lds && nz + (az_aware ? 1u : 0u) <= 16) {
+            // as many shape-index rows as LDS allows next to the masks (64 down to 4), then as much of the table as fits
+            uint32_t n_shapes = 64;
+            while (n_shapes > 4 && gangfit::fifo_zoned_lds_bytes(64, ctx->n_chunks, nz, n_shapes) > ctx->lds_budget) n_shapes /= 2;
+            const size_t fixed = gangfit::fifo_zoned_lds_bytes(0, ctx->n_chunks, nz, n_shapes);
+            if (ctx->lds_budget > fixed + 12 * 64) {
+                uint32_t lds_slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
+                lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
+                GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
+                GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
+                GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
+                                           hipMemcpyDeviceToDevice, stream));
+                gangfit::NarrowTable nt{};
+                nt.cpu = ctx->d_nwork.ptr;
+                nt.mem = nt.cpu + ctx->n_slots;
+                nt.gpu = nt.mem + ctx->n_slots;
+                nt.cmax = ctx->d_ncmax.ptr;
+                for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+                GF_HIP(ctx, gangfit::launch_fit_fifo_zoned_lds(az_aware, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr,
+                                                               lds_slots, n_shapes, n_apps, d_apps, ctx->d_napps.ptr,
+                                                               ctx->d_wide_needed.ptr, d_results, d_exec_nodes,
+                                                               ctx->d_zexec.ptr, half, d_failed,
+                                                               ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
+                run_if = ctx->d_wide_needed.ptr;  // the generic kernel below only runs when a request had no scaled form
+                zb.zexec = ctx->d_zexec.ptr;
+            }
+        }
+        GF_HIP(ctx, gangfit::launch_fit_fifo_generic(inner, true, az_aware,
                                                      reserves_executors(algo), make_table(ctx, ctx->d_work.ptr), zt,
                                                      ctx->d_sched.ptr, zb, n_apps, d_apps, d_results, d_exec_nodes,
-                                                     ctx->d_scratch.ptr, half, d_failed, stream));
+                                                     ctx->d_scratch.ptr, half, d_failed, run_if, stream));
         return GF_OK;
     }
     GF_HIP(ctx, gangfit::launch_fit_zoned(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
@@ -290,7 +321,8 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         gangfit::ZoneBuffers zb{nullptr, ctx->d_zexec.ptr, half, nullptr, nullptr, 0, nullptr};
         GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_MINIMAL_FRAGMENTATION, false, false, false,
                                                      make_table(ctx, ctx->d_work.ptr), zt, nullptr, zb, n_apps, d_apps,
-                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, stream));
+                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, nullptr,
+                                                     stream));
         return GF_OK;
     }
     ScanStats* stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
@@ -377,6 +409,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
         ctx->fifo_use_narrow = std::strncmp(k, "narrow", 6) == 0;
         ctx->fifo_wide_fused = std::strstr(k, "fused") != nullptr;
     }
+    if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
     if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
         const long v = std::atol(l);
         if (v >= 0 && (uint32_t)v <= ctx->lds_budget) ctx->lds_budget = (uint32_t)v;

@@ -155,7 +155,18 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
                                    const ZoneTable& zones, const int64_t* d_sched, const ZoneBuffers& buf,
                                    uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
                                    uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
-                                   hipStream_t stream);
+                                   const int32_t* d_run_if, hipStream_t stream);
+
+// LDS-resident chain for the zone-aware tightly-pack packers on the merged layout with a narrow table
+// (gangfit_fifo_zoned.inc).  Returns at once when a request of the batch has no scaled form (*d_wide_needed != 0 after
+// its own prepare step): the caller then launches launch_fit_fifo_generic with d_run_if = d_wide_needed.
+// d_spill: 2 * 16 rows of spill_stride uint32 (run-list tails beyond the LDS capacity).
+size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes);
+hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
+                                     const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
+                                     const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
+                                     uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
+                                     int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream);
 
 // ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
 // (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.

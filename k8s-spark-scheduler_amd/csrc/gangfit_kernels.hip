@@ -1162,6 +1162,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 #include "gangfit_fifo_fused.inc"
 #include "gangfit_fifo_narrow.inc"
 #include "gangfit_zones.inc"
+#include "gangfit_fifo_zoned.inc"
 #include "gangfit_shard.inc"
 #include "gangfit_executor.inc"
 
@@ -1443,7 +1444,7 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
                                    const ZoneTable& zones, const int64_t* d_sched, const ZoneBuffers& buf,
                                    uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,
                                    uint32_t* d_scratch, uint64_t scratch_half, int32_t* d_chain_failed_at,
-                                   hipStream_t stream) {
+                                   const int32_t* d_run_if, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     const uint32_t n_cand = zoned ? zones.n_zones + (az_aware ? 1u : 0u) : 1u;
     if (n_cand > 64) return hipErrorInvalidValue;
@@ -1452,7 +1453,7 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
 #define GF_GEN(ALGO, ZO, AZ, RE)                                                                                        \
     hipLaunchKernelGGL((fit_fifo_generic_kernel<ALGO, ZO, AZ, RE>), grid, block, 0, stream, table, zones, d_sched, n_apps, \
                        d_apps, d_results, d_exec_nodes, buf.zexec, buf.zexec_stride, d_scratch, scratch_half, buf.cnt,  \
-                       d_chain_failed_at)
+                       d_chain_failed_at, d_run_if)
     if (!zoned) {
         if (inner_algo == GF_ALGO_TIGHTLY_PACK)
             GF_GEN(GF_ALGO_TIGHTLY_PACK, false, false, true);
@@ -1475,6 +1476,34 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
     }
 #undef GF_GEN
     return hipGetLastError();
+}
+
+size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes) {
+    return fifo_zoned_fixed_lds(n_chunks, n_zones + 1, 16, n_shapes) + 12 * (size_t)lds_slots;
+}
+
+hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
+                                     const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
+                                     const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
+                                     uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
+                                     int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    if (zones.n_zones + (az_aware ? 1u : 0u) > 16 || !table.d_identity) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
+                       (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
+    const size_t lds = fifo_zoned_lds_bytes(lds_slots, table.n_chunks, zones.n_zones, n_shapes);
+    if (az_aware)
+        return launch_one_workgroup(fit_fifo_zoned_lds_kernel<true, 16>, 16, lds, stream, table, ntable, zones, d_sched,
+                                    lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps,
+                                    (const int32_t*)d_wide_needed, d_results, d_exec_nodes, d_spill, spill_stride,
+                                    d_chain_failed_at, d_stats);
+    return launch_one_workgroup(fit_fifo_zoned_lds_kernel<false, 16>, 16, lds, stream, table, ntable, zones, d_sched,
+                                lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
+                                d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
 }
 
 hipError_t launch_avg_efficiency(bool reserve_execs, const NodeTable& table, const EffTables& eff, uint32_t* d_cnt,

@@ -204,3 +204,43 @@ def test_zoned_fifo_chain_headline_shape(gf_ctx):
     assert gpu.failed_at == ref.failed_at
     _assert_same(gpu, ref, apps)
     assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+
+
+@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "48000"}],
+                         ids=["lds-chain", "generic-chain", "lds-chain-global-tail"])
+@pytest.mark.parametrize("algo", [SAZ, AZA])
+def test_zoned_fifo_chain_kernel_variants(algo, env):
+    """The LDS-resident chain of the zone-aware tightly-pack packers (gangfit_fifo_zoned.inc), its global-memory
+    fallback, and the hybrid LDS/global table, with gangs large enough to spill the in-LDS run lists (> 64 nodes)."""
+    import os
+
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = gangfit.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    rng = np.random.default_rng(2024 + algo)
+    try:
+        for rep in range(4):
+            n, a = (3000, 80) if rep < 2 else (700, 150)
+            avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, n, a, rep % 2 == 0, "merged", 1 + rep)
+            exe = np.maximum(exe, 1)
+            k = np.minimum(k, 400 if rep < 2 else 30).astype(np.int32)
+            flags = (rng.random(a) < 0.9).astype(np.uint32)
+            if rep == 3:  # a request that has no scaled form (cpu not a multiple of the table's 250 m unit): wide fallback
+                drv[5, 0] += 1
+            _setup(ctx, avail, sched, zone, D, X)
+            apps = gangfit.make_apps(drv, exe, k, flags)
+            gpu = ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps)
+            ref = ob.fit_fifo_chain(O_ALGO[algo], avail, ob.make_apps(drv, exe, k, flags), D, X, closed_form=True,
+                                    sched=sched, zone=zone)
+            assert gpu.failed_at == ref.failed_at
+            _assert_same(gpu, ref, apps)
+            assert np.array_equal(ctx.residual(), ref.avail_after)
+    finally:
+        ctx.close()
