@@ -1478,6 +1478,10 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
     return hipGetLastError();
 }
 
+namespace {
+inline dim3 app_grid_of(uint32_t n_apps) { return dim3((n_apps + kWavesPerBlock - 1) / kWavesPerBlock); }
+}  // namespace
+
 size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes) {
     return fifo_zoned_fixed_lds(n_chunks, n_zones + 1, 16, n_shapes) + 12 * (size_t)lds_slots;
 }
@@ -1497,13 +1501,17 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
     if (n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
     const size_t lds = fifo_zoned_lds_bytes(lds_slots, table.n_chunks, zones.n_zones, n_shapes);
     if (az_aware)
-        return launch_one_workgroup(fit_fifo_zoned_lds_kernel<true, 16>, 16, lds, stream, table, ntable, zones, d_sched,
-                                    lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps,
-                                    (const int32_t*)d_wide_needed, d_results, d_exec_nodes, d_spill, spill_stride,
-                                    d_chain_failed_at, d_stats);
-    return launch_one_workgroup(fit_fifo_zoned_lds_kernel<false, 16>, 16, lds, stream, table, ntable, zones, d_sched,
-                                lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
-                                d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
+        e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<true, 16>, 16, lds, stream, table, ntable, zones, d_sched,
+                                 lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
+                                 d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
+    else
+        e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<false, 16>, 16, lds, stream, table, ntable, zones, d_sched,
+                                 lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
+                                 d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
+                       n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);
+    return hipGetLastError();
 }
 
 hipError_t launch_avg_efficiency(bool reserve_execs, const NodeTable& table, const EffTables& eff, uint32_t* d_cnt,
