@@ -32,25 +32,51 @@ __global__ void usage_scatter_kernel(uint32_t n_res, uint32_t n_nodes, const uin
 
 // available = allocatable - (usage + overhead), schedulable = allocatable - overhead (resources.go:76, 89-90);
 // zone sums of the available memory / cpu feed the AZ order (nodesorting.go:124-134).
-__global__ void metadata_kernel(uint32_t n_nodes, const int64_t* __restrict__ alloc, const int64_t* __restrict__ overhead,
-                                const int64_t* __restrict__ usage, const uint32_t* __restrict__ zone, uint32_t n_zones,
-                                int64_t* __restrict__ avail, int64_t* __restrict__ sched,
-                                unsigned long long* __restrict__ zone_sum) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_nodes) return;
-    int64_t a[3];
-    for (int j = 0; j < 3; ++j) {
-        const size_t k = (size_t)j * n_nodes + n;
-        const int64_t o = overhead != nullptr ? overhead[k] : 0;
-        a[j] = alloc[k] - (usage[k] + o);
-        avail[k] = a[j];
-        sched[k] = alloc[k] - o;
+constexpr uint32_t kZoneLdsMax = 512;  // zones whose sums are first combined in LDS (one global atomic per block and zone)
+
+__global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const int64_t* __restrict__ alloc,
+                                                       const int64_t* __restrict__ overhead,
+                                                       const int64_t* __restrict__ usage, const uint32_t* __restrict__ zone,
+                                                       uint32_t n_zones, int64_t* __restrict__ avail,
+                                                       int64_t* __restrict__ sched,
+                                                       unsigned long long* __restrict__ zone_sum) {
+    __shared__ unsigned long long zacc[3 * kZoneLdsMax];  // memory | cpu | population per zone
+    const bool in_lds = n_zones <= kZoneLdsMax;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < 3 * n_zones; i += blockDim.x) zacc[i] = 0ull;
+        __syncthreads();
     }
-    const uint32_t z = zone[n];
-    if (z < n_zones) {
-        atomicAdd(&zone_sum[2 * (size_t)z], (unsigned long long)a[1]);      // memory
-        atomicAdd(&zone_sum[2 * (size_t)z + 1], (unsigned long long)a[0]);  // cpu
-        atomicAdd(&zone_sum[2 * (size_t)n_zones + z], 1ull);                // population
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_nodes) {
+        int64_t a[3];
+        for (int j = 0; j < 3; ++j) {
+            const size_t k = (size_t)j * n_nodes + n;
+            const int64_t o = overhead != nullptr ? overhead[k] : 0;
+            a[j] = alloc[k] - (usage[k] + o);
+            avail[k] = a[j];
+            sched[k] = alloc[k] - o;
+        }
+        const uint32_t z = zone[n];
+        if (z < n_zones) {
+            if (in_lds) {  // a few hundred thousand same-address global atomics would serialise
+                atomicAdd(&zacc[z], (unsigned long long)a[1]);
+                atomicAdd(&zacc[n_zones + z], (unsigned long long)a[0]);
+                atomicAdd(&zacc[2 * n_zones + z], 1ull);
+            } else {
+                atomicAdd(&zone_sum[2 * (size_t)z], (unsigned long long)a[1]);      // memory
+                atomicAdd(&zone_sum[2 * (size_t)z + 1], (unsigned long long)a[0]);  // cpu
+                atomicAdd(&zone_sum[2 * (size_t)n_zones + z], 1ull);                // population
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t z = threadIdx.x; z < n_zones; z += blockDim.x)
+            if (zacc[2 * n_zones + z] != 0ull) {
+                atomicAdd(&zone_sum[2 * (size_t)z], zacc[z]);
+                atomicAdd(&zone_sum[2 * (size_t)z + 1], zacc[n_zones + z]);
+                atomicAdd(&zone_sum[2 * (size_t)n_zones + z], zacc[2 * n_zones + z]);
+            }
     }
 }
 
