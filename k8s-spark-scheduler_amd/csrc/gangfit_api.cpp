@@ -232,6 +232,37 @@ int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
     return GF_OK;
 }
 
+// The LDS-resident minimal-fragmentation chain when the layout is merged, the table has a narrow form and the tables fit;
+// *run_if is then set to the flag the generic kernel must test (it only runs when a request had no scaled form).
+int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint32_t nz, uint32_t n_apps, const gf_app* d_apps,
+                    gf_result* d_results, uint32_t* d_exec_nodes, uint64_t half, int32_t* d_failed, hipStream_t stream,
+                    const int32_t** run_if) {
+    *run_if = nullptr;
+    if (!(ctx->merged && ctx->narrow_ok && ctx->fifo_zoned_lds) || (zoned && (nz == 0 || nz > 16))) return GF_OK;
+    const uint32_t zviews = zoned ? nz : 0u;
+    uint32_t n_shapes = 64;
+    while (n_shapes > 4 && gangfit::fifo_minfrag_lds_bytes(64, ctx->n_chunks, zviews, n_shapes) > ctx->lds_budget) n_shapes /= 2;
+    const size_t fixed = gangfit::fifo_minfrag_lds_bytes(0, ctx->n_chunks, zviews, n_shapes);
+    if (ctx->lds_budget <= fixed + 12 * 64) return GF_OK;
+    uint32_t lds_slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
+    lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
+    GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
+    GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, stream));
+    gangfit::NarrowTable nt{};
+    nt.cpu = ctx->d_nwork.ptr;
+    nt.mem = nt.cpu + ctx->n_slots;
+    nt.gpu = nt.mem + ctx->n_slots;
+    nt.cmax = ctx->d_ncmax.ptr;
+    for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+    GF_HIP(ctx, gangfit::launch_fit_fifo_minfrag_lds(zoned, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr, lds_slots,
+                                                     n_shapes, n_apps, d_apps, ctx->d_napps.ptr, ctx->d_wide_needed.ptr,
+                                                     d_results, d_exec_nodes, ctx->d_zexec.ptr, half, d_failed, stream));
+    *run_if = ctx->d_wide_needed.ptr;
+    return GF_OK;
+}
+
 int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
                  uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
     if (!ctx->have_sched)
@@ -286,6 +317,12 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
                 zb.zexec = ctx->d_zexec.ptr;
             }
         }
+        if (inner == GF_ALGO_MINIMAL_FRAGMENTATION) {
+            const int rc2 = try_minfrag_lds(ctx, true, zt, nz, n_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream,
+                                            &run_if);
+            if (rc2 != GF_OK) return rc2;
+            if (run_if) zb.zexec = ctx->d_zexec.ptr;
+        }
         GF_HIP(ctx, gangfit::launch_fit_fifo_generic(inner, true, az_aware,
                                                      reserves_executors(algo), make_table(ctx, ctx->d_work.ptr), zt,
                                                      ctx->d_sched.ptr, zb, n_apps, d_apps, d_results, d_exec_nodes,
@@ -318,10 +355,13 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
                                    hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
         gangfit::ZoneTable zt{nullptr, nullptr, 0, 0};
+        const int32_t* run_if = nullptr;
+        const int rc2 = try_minfrag_lds(ctx, false, zt, 0, n_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream, &run_if);
+        if (rc2 != GF_OK) return rc2;
         gangfit::ZoneBuffers zb{nullptr, ctx->d_zexec.ptr, half, nullptr, nullptr, 0, nullptr};
         GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_MINIMAL_FRAGMENTATION, false, false, false,
                                                      make_table(ctx, ctx->d_work.ptr), zt, nullptr, zb, n_apps, d_apps,
-                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, nullptr,
+                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, run_if,
                                                      stream));
         return GF_OK;
     }

@@ -1163,6 +1163,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 #include "gangfit_fifo_narrow.inc"
 #include "gangfit_zones.inc"
 #include "gangfit_fifo_zoned.inc"
+#include "gangfit_fifo_minfrag.inc"
 #include "gangfit_shard.inc"
 #include "gangfit_executor.inc"
 
@@ -1508,6 +1509,37 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
         e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<false, 16>, 16, lds, stream, table, ntable, zones, d_sched,
                                  lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
                                  d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
+                       n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);
+    return hipGetLastError();
+}
+
+size_t fifo_minfrag_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes) {
+    return fifo_minfrag_fixed_lds(n_chunks, n_zones + 1, n_shapes) + 12 * (size_t)lds_slots;
+}
+
+hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
+                                       const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
+                                       const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
+                                       uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
+                                       int32_t* d_chain_failed_at, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    if ((zoned && zones.n_zones > 16) || !table.d_identity || n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
+                       (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_shapes);
+    if (zoned)
+        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, 16, lds, stream, table, ntable, zones, d_sched, lds_slots,
+                                 n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at);
+    else
+        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<false>, 16, lds, stream, table, ntable, zones, d_sched, lds_slots,
+                                 n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);

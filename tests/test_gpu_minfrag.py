@@ -162,3 +162,44 @@ def test_headline_size(gf_ctx):
         ref = ob.fit_independent(oalgo, s.avail, oapps, s.driver_order, s.exec_order, sched=s.sched, zone=zone)
         _assert_same(gpu, ref, apps)
         assert ref.results["has_capacity"].mean() > 0.5
+
+
+@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "60000"}],
+                         ids=["lds-chain", "generic-chain", "lds-chain-global-tail"])
+@pytest.mark.parametrize("algo", [MF, SAZMF])
+def test_fifo_chain_kernel_variants(algo, env):
+    """The block-cooperative LDS chain (gangfit_fifo_minfrag.inc), the generic global-memory chain and the hybrid
+    LDS/global table on the same problems: gangs that need one node, several capacity levels, and more than 64 nodes
+    (spilled run lists); a request without a scaled form forces the wide fallback."""
+    import os
+
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = gangfit.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    oalgo = ob.ALGO_MINIMAL_FRAGMENTATION if algo == MF else ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION
+    rng = np.random.default_rng(77 + algo)
+    try:
+        for rep in range(5):
+            n, a = (3000, 60) if rep < 2 else (900, 120)
+            avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, n, a, rep % 2 == 0, "merged", 1 + rep % 3)
+            exe = np.maximum(exe, 1)
+            k = np.minimum(k, 600 if rep < 2 else 40).astype(np.int32)
+            flags = (rng.random(a) < 0.9).astype(np.uint32)
+            if rep == 4:
+                drv[3, 0] += 1  # not a multiple of the table's cpu unit
+            _setup(ctx, avail, sched, zone, D, X)
+            apps = gangfit.make_apps(drv, exe, k, flags)
+            gpu = ctx.fit_batch(FIFO, algo, apps)
+            ref = ob.fit_fifo_chain(oalgo, avail, ob.make_apps(drv, exe, k, flags), D, X, sched=sched, zone=zone)
+            assert gpu.failed_at == ref.failed_at
+            _assert_same(gpu, ref, apps)
+            assert np.array_equal(ctx.residual(), ref.avail_after)
+    finally:
+        ctx.close()
