@@ -202,170 +202,177 @@ def main():
     #      priority order; three KB-sized exchanges per batch over RCCL/xGMI.  Strong scaling over nodes; reported next
     #      to the app-sharded headline so that the driver's 1/2/4/8-GPU runs measure both.
     if not args.no_extras:
-        from gangfit import sharded
+        try:
+            from gangfit import sharded
 
-        comm = sharded.TorchComm() if dist is not None else sharded.SingleComm()
+            comm = sharded.TorchComm() if dist is not None else sharded.SingleComm()
 
-        def time_sharded(c, wk, steps, warmup):
-            eng = sharded.HipShardEngine(c, rank, world, dev)
-            sb = sharded.ShardedBatch(eng, comm, TIGHT, gangfit.make_apps(wk.drv, wk.exe, wk.k, wk.flags))
-            for _ in range(warmup):
-                sb.step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                sb.step()
-            barrier()
-            wall_s = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([wall_s], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                wall_s = float(t.item())
-            return {"decisions_per_s": sb.n_apps * steps / wall_s, "ms_per_batch": wall_s / steps * 1e3,
-                    "apps": sb.n_apps, "nodes": len(wk.snapshot.avail), "n_shards": world, "steps": steps,
-                    "collectives_per_batch": "2 all-gather (16 B/app) + 1 all-reduce (4 B/executor)"}
+            def time_sharded(c, wk, steps, warmup):
+                eng = sharded.HipShardEngine(c, rank, world, dev)
+                sb = sharded.ShardedBatch(eng, comm, TIGHT, gangfit.make_apps(wk.drv, wk.exe, wk.k, wk.flags))
+                for _ in range(warmup):
+                    sb.step()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    sb.step()
+                barrier()
+                wall_s = time.perf_counter() - t0
+                if dist is not None:
+                    t = torch.tensor([wall_s], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    wall_s = float(t.item())
+                return {"decisions_per_s": sb.n_apps * steps / wall_s, "ms_per_batch": wall_s / steps * 1e3,
+                        "apps": sb.n_apps, "nodes": len(wk.snapshot.avail), "n_shards": world, "steps": steps,
+                        "collectives_per_batch": "2 all-gather (16 B/app) + 1 all-reduce (4 B/executor)"}
 
-        node_sharded = {"headline": time_sharded(ctx, base, max(10, args.steps // 4), 5)}
-        # BASELINE config 4's size: 50 000 nodes x 10 000 apps (gang size = MinExecutorCount)
-        w4 = wl.config(4)
-        ctx4 = gangfit.Context(local_rank)
-        ctx4.set_snapshot(w4.snapshot.avail, w4.snapshot.sched)
-        ctx4.set_orders(w4.snapshot.driver_order, w4.snapshot.exec_order)
-        node_sharded["config4_50k_nodes_x_10k_apps"] = time_sharded(ctx4, w4, 10, 2)
-        if world == 1:  # the unsharded kernel on the same table, for the cost of the four-step path itself
-            a4, k4 = gangfit.with_offsets(gangfit.make_apps(w4.drv, w4.exe, w4.k, w4.flags))
-            d_a4 = torch.from_numpy(a4.view(np.uint8).copy()).to(dev)
-            d_r4 = torch.zeros(len(a4) * 16, dtype=torch.uint8, device=dev)
-            d_e4 = torch.zeros(k4 + 1, dtype=torch.int32, device=dev)
-            for _ in range(3):
-                ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
-            torch.cuda.synchronize()
-            node_sharded["config4_unsharded_one_gpu_decisions_per_s"] = len(a4) * 10 / (time.perf_counter() - t0)
-        ctx4.close()
-        out["node_sharded"] = node_sharded
+            node_sharded = {"headline": time_sharded(ctx, base, max(10, args.steps // 4), 5)}
+            # BASELINE config 4's size: 50 000 nodes x 10 000 apps (gang size = MinExecutorCount)
+            w4 = wl.config(4)
+            ctx4 = gangfit.Context(local_rank)
+            ctx4.set_snapshot(w4.snapshot.avail, w4.snapshot.sched)
+            ctx4.set_orders(w4.snapshot.driver_order, w4.snapshot.exec_order)
+            node_sharded["config4_50k_nodes_x_10k_apps"] = time_sharded(ctx4, w4, 10, 2)
+            if world == 1:  # the unsharded kernel on the same table, for the cost of the four-step path itself
+                a4, k4 = gangfit.with_offsets(gangfit.make_apps(w4.drv, w4.exe, w4.k, w4.flags))
+                d_a4 = torch.from_numpy(a4.view(np.uint8).copy()).to(dev)
+                d_r4 = torch.zeros(len(a4) * 16, dtype=torch.uint8, device=dev)
+                d_e4 = torch.zeros(k4 + 1, dtype=torch.int32, device=dev)
+                for _ in range(3):
+                    ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
+                torch.cuda.synchronize()
+                node_sharded["config4_unsharded_one_gpu_decisions_per_s"] = len(a4) * 10 / (time.perf_counter() - t0)
+            ctx4.close()
+            out["node_sharded"] = node_sharded
+        except Exception as e:  # the headline number above must survive a failure of this optional leg
+            out["node_sharded"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
-        # distribute-evenly on the same batch
-        wall_e, kern_e = timed(EVEN, args.steps, max(2, args.warmup // 4))
-        extras["distribute_evenly"] = {"decisions_per_s": len(apps) * args.steps / wall_e, "kernel_ms": kern_e}
-        # FIFO Filter: chain of (apps-1) earlier drivers + the filtered one, host entry point (H2D + kernel + D2H)
-        lat = []
-        n_calls = 60
-        for i in range(n_calls + 5):
-            rolled = np.roll(apps, -i)
-            t0 = time.perf_counter()
-            o = ctx.fit_batch(FIFO, TIGHT, rolled)
-            dt = time.perf_counter() - t0
-            if i >= 5:
-                lat.append(dt * 1e3)
-        extras["fifo_filter"] = {
-            "chain": f"{len(apps) - 1} earlier drivers + 1, tightly-pack, host entry point incl. H2D/D2H",
-            "p50_ms": _percentile(lat, 0.5), "p99_ms": _percentile(lat, 0.99), "calls": n_calls,
-            "decisions_per_s": len(apps) / (_percentile(lat, 0.5) * 1e-3), "chain_failed_at": o.failed_at,
-        }
-        # congested cluster (usage ~U[0.95,1]): ~half of the gangs do not fit -> full scans + driver fallback
-        wc = wl.headline(args.nodes, args.apps, congested=True)
-        sc = wc.snapshot
-        ctx.set_snapshot(sc.avail, sc.sched)
-        ctx.set_orders(sc.driver_order, sc.exec_order)
-        capps, ctotal = gangfit.with_offsets(gangfit.make_apps(wc.drv, wc.exe, wc.k, np.ones(len(wc.k), dtype=np.uint32)))
-        d_apps = torch.from_numpy(capps.view(np.uint8).copy()).to(dev)
-        d_exec = torch.zeros(ctotal + 1, dtype=torch.int32, device=dev)
-        apps, total_k = capps, ctotal
-        wall_c, kern_c = timed(TIGHT, max(10, args.steps // 4), 3)
-        ctx.scan_stats(enable=True, reset=True)
-        step(TIGHT)
-        torch.cuda.synchronize()
-        xv, dv = ctx.scan_stats(enable=False, reset=True)
-        cb = wl.algorithmic_bytes(len(sc.exec_order), wc.k)
-        cvis = xv * 24 + dv * 28 + len(capps) * 88 + 4 * int(wc.k.sum())
-        res = d_res.cpu().numpy().view(gangfit._native.RESULT_DTYPE)
-        lat = []
-        for i in range(20):
-            t0 = time.perf_counter()
-            ctx.fit_batch(FIFO, TIGHT, np.roll(capps, -i))
-            lat.append((time.perf_counter() - t0) * 1e3)
-        extras["congested"] = {
-            "workload": wc.name, "feasible_fraction": float(res["has_capacity"].mean()),
-            "decisions_per_s": len(capps) * max(10, args.steps // 4) / wall_c, "kernel_ms": kern_c,
-            "achieved_GBps_algorithmic": cb / (kern_c * 1e-3) / 1e9,
-            "achieved_GBps_visited": cvis / (kern_c * 1e-3) / 1e9,
-            "fifo_filter_p50_ms": _percentile(lat, 0.5), "fifo_filter_p99_ms": _percentile(lat, 0.99),
-        }
-        if not args.no_cpu_baseline:
-            extras["congested"]["cpu_baseline"] = cpu_baseline_congested(wc)
-
-        # ---- the rows of SURVEY.md 8f, each on the headline-sized cluster (nominal usage)
-        def host_ms(f, n=20, warm=3):
-            for _ in range(warm):
-                f()
-            ts = []
-            for _ in range(n):
-                t0 = time.perf_counter()
-                f()
-                ts.append((time.perf_counter() - t0) * 1e3)
-            return _percentile(ts, 0.5), _percentile(ts, 0.99)
-
-        happs = gangfit.make_apps(base.drv, base.exe, base.k, base.flags)
-        zone3 = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
-        ctx.set_snapshot(s.avail, s.sched)
-        ctx.set_zones(zone3)
-        ctx.set_orders(s.driver_order, s.exec_order)
-        SAZ, MF, SAZMF = (gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.GF_ALGO_MINIMAL_FRAGMENTATION,
-                          gangfit.GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)
-        p50, p99 = host_ms(lambda: ctx.fit_batch(FIFO, SAZ, happs))
-        extras["single_az_tightly_pack"] = {"zones": 3, "fifo_filter_p50_ms": p50, "fifo_filter_p99_ms": p99}
-        p50, _ = host_ms(lambda: ctx.fit_batch(IND, SAZ, happs))
-        extras["single_az_tightly_pack"]["independent_decisions_per_s_host_entry"] = len(happs) / (p50 * 1e-3)
-        for name, algo in (("minimal_fragmentation", MF), ("single_az_minimal_fragmentation", SAZMF)):
-            p50, _ = host_ms(lambda: ctx.fit_batch(IND, algo, happs), n=10)
-            f50, f99 = host_ms(lambda: ctx.fit_batch(FIFO, algo, happs), n=5, warm=1)
-            extras[name] = {"independent_decisions_per_s_host_entry": len(happs) / (p50 * 1e-3),
-                            "fifo_filter_p50_ms": f50, "fifo_filter_p99_ms": f99}
-        exe_reqs = np.ascontiguousarray(base.exe)
-        p50, _ = host_ms(lambda: ctx.executor_fit(exe_reqs))
-        m50, _ = host_ms(lambda: ctx.executor_fit(exe_reqs, minimal_fragmentation=True))
-        extras["executor_fit"] = {"requests": len(exe_reqs), "first_fit_requests_per_s": len(exe_reqs) / (p50 * 1e-3),
-                                  "minimal_fragmentation_requests_per_s": len(exe_reqs) / (m50 * 1e-3),
-                                  "note": "host entry point incl. H2D/D2H"}
-        # snapshot construction on the device: reservation replay + metadata + priority orders, then the host-side tables
-        snap = {}
-        for n_nodes, n_rr in ((10000, 2000), (100000, 20000)):
-            rng = np.random.default_rng(n_nodes)
-            shape = rng.integers(0, 4, size=n_nodes)
-            alloc = np.stack([np.array([16, 32, 64, 96])[shape] * 1000, np.array([64, 128, 256, 384])[shape] * wl.GIB,
-                              np.zeros(n_nodes, dtype=np.int64)], axis=1).astype(np.int64)
-            ks = rng.integers(2, 26, size=n_rr)
-            rnode = rng.integers(0, n_nodes, size=int(ks.sum())).astype(np.uint32)
-            rreq = np.stack([rng.choice([1000, 2000, 4000], size=len(rnode)), rng.choice([4, 8, 16], size=len(rnode)) * wl.GIB,
-                             np.zeros(len(rnode), dtype=np.int64)], axis=1).astype(np.int64)
-            flags = np.full(n_nodes, 2 | 4, dtype=np.uint32)
-            ranks = rng.permutation(n_nodes).astype(np.uint32)
-            zone = rng.integers(0, 3, size=n_nodes).astype(np.uint32)
-            p50, p99 = host_ms(lambda: ctx.build_snapshot(alloc, flags, ranks, res_node=rnode, res_req=rreq, zone=zone,
-                                                          n_zones=3), n=10, warm=2)
-            snap[f"{n_nodes}_nodes_{n_rr}_reservations"] = {"reservation_entries": int(len(rnode)), "p50_ms": p50, "p99_ms": p99}
-        extras["snapshot_build"] = snap
-        # BASELINE config 3: 10 000 nodes x 10 000 pending apps, both plain packers, device resident
-        w3 = wl.config(3)
-        ctx.set_snapshot(w3.snapshot.avail, w3.snapshot.sched)
-        ctx.set_orders(w3.snapshot.driver_order, w3.snapshot.exec_order)
-        apps, total_k = gangfit.with_offsets(gangfit.make_apps(w3.drv, w3.exe, w3.k, w3.flags))
-        d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
-        d_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
-        d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
-        c3 = {}
-        for name, algo in (("tightly_pack", TIGHT), ("distribute_evenly", EVEN)):
-            wall_3, kern_3 = timed(algo, 20, 3)
-            c3[name] = {"decisions_per_s": len(apps) * 20 / wall_3, "kernel_ms": kern_3,
-                        "achieved_GBps_algorithmic": wl.algorithmic_bytes(len(w3.snapshot.exec_order), w3.k) / (kern_3 * 1e-3) / 1e9}
-        extras["config3_10k_nodes_x_10k_apps"] = c3
         out["extras"] = extras
+        try:
+            # distribute-evenly on the same batch
+            wall_e, kern_e = timed(EVEN, args.steps, max(2, args.warmup // 4))
+            extras["distribute_evenly"] = {"decisions_per_s": len(apps) * args.steps / wall_e, "kernel_ms": kern_e}
+            # FIFO Filter: chain of (apps-1) earlier drivers + the filtered one, host entry point (H2D + kernel + D2H)
+            lat = []
+            n_calls = 60
+            for i in range(n_calls + 5):
+                rolled = np.roll(apps, -i)
+                t0 = time.perf_counter()
+                o = ctx.fit_batch(FIFO, TIGHT, rolled)
+                dt = time.perf_counter() - t0
+                if i >= 5:
+                    lat.append(dt * 1e3)
+            extras["fifo_filter"] = {
+                "chain": f"{len(apps) - 1} earlier drivers + 1, tightly-pack, host entry point incl. H2D/D2H",
+                "p50_ms": _percentile(lat, 0.5), "p99_ms": _percentile(lat, 0.99), "calls": n_calls,
+                "decisions_per_s": len(apps) / (_percentile(lat, 0.5) * 1e-3), "chain_failed_at": o.failed_at,
+            }
+            # congested cluster (usage ~U[0.95,1]): ~half of the gangs do not fit -> full scans + driver fallback
+            wc = wl.headline(args.nodes, args.apps, congested=True)
+            sc = wc.snapshot
+            ctx.set_snapshot(sc.avail, sc.sched)
+            ctx.set_orders(sc.driver_order, sc.exec_order)
+            capps, ctotal = gangfit.with_offsets(gangfit.make_apps(wc.drv, wc.exe, wc.k, np.ones(len(wc.k), dtype=np.uint32)))
+            d_apps = torch.from_numpy(capps.view(np.uint8).copy()).to(dev)
+            d_exec = torch.zeros(ctotal + 1, dtype=torch.int32, device=dev)
+            apps, total_k = capps, ctotal
+            wall_c, kern_c = timed(TIGHT, max(10, args.steps // 4), 3)
+            ctx.scan_stats(enable=True, reset=True)
+            step(TIGHT)
+            torch.cuda.synchronize()
+            xv, dv = ctx.scan_stats(enable=False, reset=True)
+            cb = wl.algorithmic_bytes(len(sc.exec_order), wc.k)
+            cvis = xv * 24 + dv * 28 + len(capps) * 88 + 4 * int(wc.k.sum())
+            res = d_res.cpu().numpy().view(gangfit._native.RESULT_DTYPE)
+            lat = []
+            for i in range(20):
+                t0 = time.perf_counter()
+                ctx.fit_batch(FIFO, TIGHT, np.roll(capps, -i))
+                lat.append((time.perf_counter() - t0) * 1e3)
+            extras["congested"] = {
+                "workload": wc.name, "feasible_fraction": float(res["has_capacity"].mean()),
+                "decisions_per_s": len(capps) * max(10, args.steps // 4) / wall_c, "kernel_ms": kern_c,
+                "achieved_GBps_algorithmic": cb / (kern_c * 1e-3) / 1e9,
+                "achieved_GBps_visited": cvis / (kern_c * 1e-3) / 1e9,
+                "fifo_filter_p50_ms": _percentile(lat, 0.5), "fifo_filter_p99_ms": _percentile(lat, 0.99),
+            }
+            if not args.no_cpu_baseline:
+                extras["congested"]["cpu_baseline"] = cpu_baseline_congested(wc)
+
+            # ---- the rows of SURVEY.md 8f, each on the headline-sized cluster (nominal usage)
+            def host_ms(f, n=20, warm=3):
+                for _ in range(warm):
+                    f()
+                ts = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    f()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                return _percentile(ts, 0.5), _percentile(ts, 0.99)
+
+            happs = gangfit.make_apps(base.drv, base.exe, base.k, base.flags)
+            zone3 = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+            ctx.set_snapshot(s.avail, s.sched)
+            ctx.set_zones(zone3)
+            ctx.set_orders(s.driver_order, s.exec_order)
+            SAZ, MF, SAZMF = (gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.GF_ALGO_MINIMAL_FRAGMENTATION,
+                              gangfit.GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)
+            p50, p99 = host_ms(lambda: ctx.fit_batch(FIFO, SAZ, happs))
+            extras["single_az_tightly_pack"] = {"zones": 3, "fifo_filter_p50_ms": p50, "fifo_filter_p99_ms": p99}
+            p50, _ = host_ms(lambda: ctx.fit_batch(IND, SAZ, happs))
+            extras["single_az_tightly_pack"]["independent_decisions_per_s_host_entry"] = len(happs) / (p50 * 1e-3)
+            for name, algo in (("minimal_fragmentation", MF), ("single_az_minimal_fragmentation", SAZMF)):
+                p50, _ = host_ms(lambda: ctx.fit_batch(IND, algo, happs), n=10)
+                f50, f99 = host_ms(lambda: ctx.fit_batch(FIFO, algo, happs), n=5, warm=1)
+                extras[name] = {"independent_decisions_per_s_host_entry": len(happs) / (p50 * 1e-3),
+                                "fifo_filter_p50_ms": f50, "fifo_filter_p99_ms": f99}
+            exe_reqs = np.ascontiguousarray(base.exe)
+            p50, _ = host_ms(lambda: ctx.executor_fit(exe_reqs))
+            m50, _ = host_ms(lambda: ctx.executor_fit(exe_reqs, minimal_fragmentation=True))
+            extras["executor_fit"] = {"requests": len(exe_reqs), "first_fit_requests_per_s": len(exe_reqs) / (p50 * 1e-3),
+                                      "minimal_fragmentation_requests_per_s": len(exe_reqs) / (m50 * 1e-3),
+                                      "note": "host entry point incl. H2D/D2H"}
+            # snapshot construction on the device: reservation replay + metadata + priority orders, then the host-side tables
+            snap = {}
+            for n_nodes, n_rr in ((10000, 2000), (100000, 20000)):
+                rng = np.random.default_rng(n_nodes)
+                shape = rng.integers(0, 4, size=n_nodes)
+                alloc = np.stack([np.array([16, 32, 64, 96])[shape] * 1000, np.array([64, 128, 256, 384])[shape] * wl.GIB,
+                                  np.zeros(n_nodes, dtype=np.int64)], axis=1).astype(np.int64)
+                ks = rng.integers(2, 26, size=n_rr)
+                rnode = rng.integers(0, n_nodes, size=int(ks.sum())).astype(np.uint32)
+                rreq = np.stack([rng.choice([1000, 2000, 4000], size=len(rnode)), rng.choice([4, 8, 16], size=len(rnode)) * wl.GIB,
+                                 np.zeros(len(rnode), dtype=np.int64)], axis=1).astype(np.int64)
+                flags = np.full(n_nodes, 2 | 4, dtype=np.uint32)
+                ranks = rng.permutation(n_nodes).astype(np.uint32)
+                zone = rng.integers(0, 3, size=n_nodes).astype(np.uint32)
+                p50, p99 = host_ms(lambda: ctx.build_snapshot(alloc, flags, ranks, res_node=rnode, res_req=rreq, zone=zone,
+                                                              n_zones=3), n=10, warm=2)
+                snap[f"{n_nodes}_nodes_{n_rr}_reservations"] = {"reservation_entries": int(len(rnode)), "p50_ms": p50, "p99_ms": p99}
+            extras["snapshot_build"] = snap
+            # BASELINE config 3: 10 000 nodes x 10 000 pending apps, both plain packers, device resident
+            w3 = wl.config(3)
+            ctx.set_snapshot(w3.snapshot.avail, w3.snapshot.sched)
+            ctx.set_orders(w3.snapshot.driver_order, w3.snapshot.exec_order)
+            apps, total_k = gangfit.with_offsets(gangfit.make_apps(w3.drv, w3.exe, w3.k, w3.flags))
+            d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
+            d_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
+            d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+            c3 = {}
+            for name, algo in (("tightly_pack", TIGHT), ("distribute_evenly", EVEN)):
+                wall_3, kern_3 = timed(algo, 20, 3)
+                c3[name] = {"decisions_per_s": len(apps) * 20 / wall_3, "kernel_ms": kern_3,
+                            "achieved_GBps_algorithmic": wl.algorithmic_bytes(len(w3.snapshot.exec_order), w3.k) / (kern_3 * 1e-3) / 1e9}
+            extras["config3_10k_nodes_x_10k_apps"] = c3
+            out["extras"] = extras
+        except Exception as e:  # keep what was measured; the headline line must still be printed
+            extras["error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl.headline(args.nodes, args.apps, seed=0x5EED0010))
