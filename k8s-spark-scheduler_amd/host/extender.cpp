@@ -217,3 +217,63 @@ bool SparkSchedulerExtender::DoesPodExceedClusterCapacity(const Pod& driver, con
 }
 
 }  // namespace gangfit::host
+
+namespace gangfit::host {
+
+std::vector<std::pair<std::string, bool>> SparkSchedulerExtender::scanForUnschedulablePods(
+    const std::vector<Pod>& allPods, int64_t timeoutNanos, const std::vector<Node>& availableNodes,
+    const NodeGroupResources& nonSchedulableOverhead, bool* served, std::string* err) {
+    std::vector<std::pair<std::string, bool>> out;
+    if (served) *served = true;
+    if (timeoutNanos <= 0) timeoutNanos = 600ll * 1000000000;  // 10 minutes (unschedulablepods.go:62-64)
+    std::vector<const Pod*> stale;
+    std::vector<gf_app> apps;
+    for (const Pod& pod : allPods) {
+        auto role = pod.labels.find(common::SparkRoleLabel);
+        if (pod.SchedulerName != common::SparkSchedulerName || !pod.NodeName.empty() || pod.Deleting ||
+            role == pod.labels.end() || role->second != common::Driver || pod.CreationTimestampNanos + timeoutNanos >= nowNanos)
+            continue;
+        std::string e;
+        auto r = sparkResources(pod, &e);
+        if (!r) {  // "failed to check if pod was unschedulable": the reference returns from the scan
+            if (err) *err = e;
+            break;
+        }
+        gf_app a{};
+        if (!r->DriverResources.canonical(a.drv) || !r->ExecutorResources.canonical(a.exe) || r->MinExecutorCount < 0 ||
+            r->MinExecutorCount > GF_MAX_K) {
+            if (served) *served = false;
+            if (err) *err = "pod " + pod.Name + " is not exactly representable";
+            return {};
+        }
+        a.k = r->MinExecutorCount;
+        stale.push_back(&pod);
+        apps.push_back(a);
+    }
+    if (apps.empty()) return out;
+    NodeGroupResources usage;  // zeroUsage: the cluster as if nothing ran on it
+    NodeGroupSchedulingMetadata metadata = NodeSchedulingMetadataForNodes(availableNodes, usage, nonSchedulableOverhead);
+    std::vector<std::string> names;
+    for (const Node& n : availableNodes) names.push_back(n.Name);
+    FlatSnapshot snap;
+    std::string e;
+    if (!flatten(metadata, names, names, &snap, &e) || !upload(binpacker_.ctx, snap, &e)) {
+        if (served) *served = false;
+        if (err) *err = e;
+        return {};
+    }
+    uint64_t total_k = 0;
+    for (const gf_app& a : apps) total_k += (uint64_t)a.k;
+    std::vector<gf_result> results(apps.size());
+    std::vector<uint32_t> exec(total_k + 1);
+    if (gf_fit_batch(binpacker_.ctx, GF_MODE_INDEPENDENT, binpacker_.Algo, (uint32_t)apps.size(), apps.data(), results.data(),
+                     exec.data(), total_k, nullptr) != GF_OK) {
+        if (served) *served = false;
+        if (err) *err = std::string("gf_fit_batch: ") + gf_last_error(binpacker_.ctx);
+        return {};
+    }
+    for (size_t i = 0; i < stale.size(); ++i) out.emplace_back(stale[i]->Name, results[i].has_capacity == 0);
+    return out;
+}
+
+}  // namespace gangfit::host

@@ -82,6 +82,16 @@ public:
                                         const std::vector<Node>& availableNodes,
                                         const std::set<std::string>& nodesHostingApp, bool isExtraExecutor);
 
+    // scanForUnschedulablePods (unschedulablepods.go:93-129) as ONE independent batch: every pending driver of this
+    // scheduler that is older than timeoutNanos is checked against the EMPTY cluster (the per-pod BinpackFunc calls of the
+    // reference batched into one launch).  Returns {pod name, exceedsCapacity} in listing order; like the reference the scan
+    // stops at the first pod whose resources cannot be parsed (*err says why).  availableNodes = the nodes the drivers'
+    // node affinity matches (one instance group per call).
+    std::vector<std::pair<std::string, bool>> scanForUnschedulablePods(const std::vector<Pod>& allPods, int64_t timeoutNanos,
+                                                                       const std::vector<Node>& availableNodes,
+                                                                       const NodeGroupResources& nonSchedulableOverhead,
+                                                                       bool* served, std::string* err);
+
     bool shouldSkipDriverFifo(const Pod& pod, const std::string& instanceGroup) const;
 
 private:

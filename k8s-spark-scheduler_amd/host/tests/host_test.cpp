@@ -372,6 +372,27 @@ static void TestUnschedulablePodMarker() {  // unschedulablepods_test.go:24-53
     CHECK(ext.DoesPodExceedClusterCapacity(Driver("100-executor-app", StaticAnnotations(100)), ext.nodes, {}, &served, &err) && served);
 }
 
+static void TestUnschedulablePodScanBatched() {  // scanForUnschedulablePods (unschedulablepods.go:93-129) in one launch
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    auto ext = NewTestExtender("single-az-tightly-pack", {node1, node2});
+    ext.nowNanos = 10000ll * 1000000000;
+    Pod fits = Driver("2-executor-app", StaticAnnotations(2), 1), too_big = Driver("100-executor-app", StaticAnnotations(100), 2),
+        young = Driver("young-app", StaticAnnotations(100), 9999), gpus = Driver("gpu-app", StaticAnnotations(2, "1", "1", "1", "1", true), 3);
+    Pod bound = Driver("bound-app", StaticAnnotations(100), 4);
+    bound.NodeName = "node1";
+    Pod executor = Driver("exec", StaticAnnotations(100), 5);
+    executor.labels[common::SparkRoleLabel] = common::Executor;
+    bool served = false;
+    std::string err;
+    auto r = ext.scanForUnschedulablePods({fits, too_big, young, gpus, bound, executor}, 600ll * 1000000000, ext.nodes, {}, &served, &err);
+    CHECK(served && r.size() == 3);
+    if (r.size() == 3) {
+        CHECK(r[0].first == "2-executor-app-spark-driver" && !r[0].second);
+        CHECK(r[1].first == "100-executor-app-spark-driver" && r[1].second);
+        CHECK(r[2].first == "gpu-app-spark-driver" && r[2].second);
+    }
+}
+
 static void TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs() {  // unschedulablepods_test.go:55-80
     Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
     auto ext = NewTestExtender("single-az-tightly-pack", {node1, node2});
@@ -632,6 +653,7 @@ int main(int argc, char** argv) {
         }
         TestScheduler();
         TestUnschedulablePodMarker();
+        TestUnschedulablePodScanBatched();
         TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs();
         TestFifoAndBinpackers();
         TestMinimalFragmentationEdgeCase();
