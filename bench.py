@@ -246,6 +246,16 @@ def main():
                     ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
                 torch.cuda.synchronize()
                 node_sharded["config4_unsharded_one_gpu_decisions_per_s"] = len(a4) * 10 / (time.perf_counter() - t0)
+                # the dynamic-allocation tail of config 4: (max - min) single-executor first fits for 10 % of the apps
+                # (rescheduleExecutor's loop, resource.go:658-662), as independent requests against the same snapshot
+                extra = np.repeat(w4.exe[::10], np.maximum(w4.k_max[::10] - w4.k[::10], 0), axis=0)
+                if len(extra):
+                    ctx4.executor_fit(extra[:8])
+                    t0 = time.perf_counter()
+                    ctx4.executor_fit(extra)
+                    node_sharded["config4_extra_executor_first_fits"] = {
+                        "requests": int(len(extra)), "requests_per_s": len(extra) / (time.perf_counter() - t0),
+                        "note": "host entry point incl. H2D/D2H"}
             ctx4.close()
             out["node_sharded"] = node_sharded
         except Exception as e:  # the headline number above must survive a failure of this optional leg
