@@ -11,6 +11,7 @@ _REPO_ROOT = os.path.dirname(_PKG_ROOT)
 CSRC = os.path.join(_PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(_PKG_ROOT, "libgangfit.so")
 HOST_LIB_PATH = os.path.join(_PKG_ROOT, "libgangfit_host.so")
+HOST_BENCH_PATH = os.path.join(_PKG_ROOT, "host_bench")  # end-to-end Filter timing through the host mirror
 HOST_TEST_PATH = os.path.join(_PKG_ROOT, "host_test")  # C++ tests of the host mirror (host/tests/host_test.cpp)
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 
@@ -60,6 +61,11 @@ def build_host(force: bool = False) -> str:
     if os.path.exists(test_src) and (force or _stale(HOST_TEST_PATH, [test_src, HOST_LIB_PATH] + hdrs)):
         cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", host_dir, test_src, "-L", _PKG_ROOT,
                "-lgangfit_host", "-lgangfit", "-Wl,-rpath,$ORIGIN", "-o", HOST_TEST_PATH]
+        subprocess.check_call(cmd)
+    bench_src = os.path.join(host_dir, "tests", "host_bench.cpp")
+    if os.path.exists(bench_src) and (force or _stale(HOST_BENCH_PATH, [bench_src, HOST_LIB_PATH] + hdrs)):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", host_dir, bench_src, "-L", _PKG_ROOT,
+               "-lgangfit_host", "-lgangfit", "-Wl,-rpath,$ORIGIN", "-o", HOST_BENCH_PATH]
         subprocess.check_call(cmd)
     return HOST_LIB_PATH
 

@@ -1,5 +1,7 @@
 #include "extender.hpp"
 
+#include <algorithm>
+
 namespace gangfit::host {
 
 std::string executorReservationName(int i) { return "executor-" + std::to_string(i + 1); }
@@ -273,6 +275,193 @@ std::vector<std::pair<std::string, bool>> SparkSchedulerExtender::scanForUnsched
         return {};
     }
     for (size_t i = 0; i < stale.size(); ++i) out.emplace_back(stale[i]->Name, results[i].has_capacity == 0);
+    return out;
+}
+
+}  // namespace gangfit::host
+
+namespace gangfit::host {
+
+bool FlatCluster::Build(const std::vector<Node>& nodes, FlatCluster* out, std::string* err) {
+    FlatCluster c;
+    const size_t n = nodes.size();
+    std::map<std::string, uint32_t> zone_ids;  // label order
+    for (const Node& nd : nodes) {
+        auto z = nd.labels.find(kLabelZoneFailureDomain);
+        zone_ids.emplace(z == nd.labels.end() ? kZoneLabelPlaceholder : z->second, 0u);
+    }
+    uint32_t zi = 0;
+    for (auto& kv : zone_ids) {
+        kv.second = zi++;
+        c.zone_labels.push_back(kv.first);
+    }
+    std::vector<std::pair<std::string, uint32_t>> by_name;
+    by_name.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Node& nd = nodes[i];
+        Resources a = Resources::Zero();
+        if (auto it = nd.Allocatable.find(kResourceCPU); it != nd.Allocatable.end()) a.CPU = it->second;
+        if (auto it = nd.Allocatable.find(kResourceMemory); it != nd.Allocatable.end()) a.Memory = it->second;
+        if (auto it = nd.Allocatable.find(kResourceNvidiaGPU); it != nd.Allocatable.end()) a.NvidiaGPU = it->second;
+        int64_t v[3];
+        if (!a.canonical(v) || v[0] < 0 || v[1] < 0 || v[2] < 0) {
+            if (err) *err = "allocatable of node " + nd.Name + " is not exactly representable";
+            return false;
+        }
+        for (int j = 0; j < 3; ++j) c.alloc[j].push_back(v[j]);
+        c.names.push_back(nd.Name);
+        if (!c.index.emplace(nd.Name, (uint32_t)i).second) {
+            if (err) *err = "duplicate node name " + nd.Name;
+            return false;
+        }
+        auto z = nd.labels.find(kLabelZoneFailureDomain);
+        c.zone.push_back(zone_ids.at(z == nd.labels.end() ? kZoneLabelPlaceholder : z->second));
+        c.base_flags.push_back((nd.Unschedulable ? GF_NODE_UNSCHEDULABLE : 0u) | (nd.Ready ? GF_NODE_READY : 0u));
+        by_name.emplace_back(nd.Name, (uint32_t)i);
+    }
+    std::sort(by_name.begin(), by_name.end());
+    c.name_rank.assign(n, 0);
+    for (size_t r = 0; r < n; ++r) c.name_rank[by_name[r].second] = (uint32_t)r;
+    *out = std::move(c);
+    return true;
+}
+
+bool FlatReservations::Build(const std::vector<ResourceReservation>& reservations,
+                             const NodeGroupResources& softReservationUsage, const FlatCluster& cluster,
+                             FlatReservations* out, std::string* err) {
+    FlatReservations f;
+    auto push = [&](const std::string& node, const Resources& r) {
+        auto it = cluster.index.find(node);
+        if (it == cluster.index.end()) return true;  // usage of a node outside this instance group is never read
+        int64_t v[3];
+        if (!r.canonical(v) || v[0] < 0 || v[1] < 0 || v[2] < 0) return false;
+        f.node.push_back(it->second);
+        for (int j = 0; j < 3; ++j) f.req[j].push_back(v[j]);
+        return true;
+    };
+    for (const ResourceReservation& rr : reservations)
+        for (const auto& [name, res] : rr.Reservations) {
+            Resources r = Resources::Zero();
+            if (auto it = res.Resources.find(kResourceCPU); it != res.Resources.end()) r.CPU = it->second;
+            if (auto it = res.Resources.find(kResourceMemory); it != res.Resources.end()) r.Memory = it->second;
+            if (auto it = res.Resources.find(kResourceNvidiaGPU); it != res.Resources.end()) r.NvidiaGPU = it->second;
+            if (!push(res.Node, r)) {
+                if (err) *err = "a reservation of " + rr.Name + " is not exactly representable";
+                return false;
+            }
+        }
+    for (const auto& [node, r] : softReservationUsage)
+        if (!push(node, r)) {
+            if (err) *err = "soft reservations on " + node + " are not exactly representable";
+            return false;
+        }
+    *out = std::move(f);
+    return true;
+}
+
+SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string& instanceGroup, const Pod& driver,
+                                                              const std::vector<std::string>& nodeNames,
+                                                              const FlatCluster& cluster, const FlatReservations* flat) {
+    SelectNodeResult out;
+    auto not_served = [&](const std::string& why) {
+        out.served = false;
+        out.error = why;
+        return out;
+    };
+    auto app_label = driver.labels.find(common::SparkAppIDLabel);
+    const std::string app_id = app_label == driver.labels.end() ? "" : app_label->second;
+    for (const ResourceReservation& rr : reservations)
+        if (rr.Name == app_id && rr.Namespace == driver.Namespace) {
+            auto d = rr.Reservations.find("driver");
+            out.node = d == rr.Reservations.end() ? "" : d->second.Node;
+            out.outcome = outcome::success;
+            return out;
+        }
+    const uint32_t n = (uint32_t)cluster.names.size();
+    // ---- the per-request columns: one entry per reservation (UsageForNodes' input), overhead, request flags
+    FlatReservations local;
+    if (flat == nullptr) {
+        std::string ferr;
+        if (!FlatReservations::Build(reservations, softReservationUsage, cluster, &local, &ferr)) return not_served(ferr);
+        flat = &local;
+    }
+    const std::vector<uint32_t>& rnode = flat->node;
+    const std::vector<int64_t>* rreq = flat->req;
+    std::vector<int64_t> over[3];
+    if (!overhead.empty()) {
+        for (int j = 0; j < 3; ++j) over[j].assign(n, 0);
+        for (const auto& [node, r] : overhead) {
+            auto it = cluster.index.find(node);
+            if (it == cluster.index.end()) continue;
+            int64_t v[3];
+            if (!r.canonical(v) || v[0] < 0 || v[1] < 0 || v[2] < 0) return not_served("overhead of " + node + " is not exactly representable");
+            for (int j = 0; j < 3; ++j) over[j][it->second] = v[j];
+        }
+    }
+    std::vector<uint32_t> flags = cluster.base_flags;
+    for (const std::string& name : nodeNames)
+        if (auto it = cluster.index.find(name); it != cluster.index.end()) flags[it->second] |= GF_NODE_DRIVER_CANDIDATE;
+    // ---- the applications: earlier drivers in creation order, then this one
+    std::string err;
+    auto resources = sparkResources(driver, &err);
+    if (!resources) {
+        out.outcome = outcome::failureInternal;
+        out.error = "failed to get spark resources: " + err;
+        return out;
+    }
+    std::vector<gf_app> apps;
+    if (isFIFO_)
+        for (const Pod* p : filterToEarliestAndSort(driver, pods)) {
+            auto r = sparkResources(*p, nullptr);
+            if (!r) continue;
+            gf_app a{};
+            if (!r->DriverResources.canonical(a.drv) || !r->ExecutorResources.canonical(a.exe) || r->MinExecutorCount < 0 ||
+                r->MinExecutorCount > GF_MAX_K)
+                return not_served("earlier driver " + p->Name + " is not exactly representable");
+            a.k = r->MinExecutorCount;
+            a.flags = shouldSkipDriverFifo(*p, instanceGroup) ? GF_APP_SKIPPABLE : 0u;
+            apps.push_back(a);
+        }
+    gf_app cur{};
+    if (!resources->DriverResources.canonical(cur.drv) || !resources->ExecutorResources.canonical(cur.exe) ||
+        resources->MinExecutorCount < 0 || resources->MinExecutorCount > GF_MAX_K)
+        return not_served("application resources are not exactly representable");
+    cur.k = resources->MinExecutorCount;
+    apps.push_back(cur);
+    // ---- snapshot + orders on the device, then the chain
+    gf_ctx* ctx = binpacker_.ctx;
+    if (gf_snapshot_build(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(),
+                          overhead.empty() ? nullptr : over[0].data(), overhead.empty() ? nullptr : over[1].data(),
+                          overhead.empty() ? nullptr : over[2].data(), (uint32_t)rnode.size(), rnode.data(), rreq[0].data(),
+                          rreq[1].data(), rreq[2].data(), flags.data(), cluster.zone.data(), (uint32_t)cluster.zone_labels.size(),
+                          cluster.name_rank.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != GF_OK)
+        return not_served(std::string("gf_snapshot_build: ") + gf_last_error(ctx));
+    uint64_t total_k = 0;
+    for (const gf_app& a : apps) total_k += (uint64_t)a.k;
+    std::vector<gf_result> results(apps.size());
+    std::vector<uint32_t> exec(total_k + 1);
+    int32_t failed_at = -1;
+    if (gf_fit_batch(ctx, GF_MODE_FIFO_CHAIN, binpacker_.Algo, (uint32_t)apps.size(), apps.data(), results.data(), exec.data(),
+                     total_k, &failed_at) != GF_OK)
+        return not_served(std::string("gf_fit_batch: ") + gf_last_error(ctx));
+    if (failed_at >= 0) {
+        out.outcome = outcome::failureEarlierDriver;
+        out.error = "earlier drivers do not fit to the cluster";
+        return out;
+    }
+    const gf_result& last = results.back();
+    if (!last.has_capacity) {
+        out.outcome = outcome::failureFit;
+        out.error = "application does not fit to the cluster";
+        return out;
+    }
+    std::vector<std::string> executorNodes;
+    const uint64_t off = total_k - (uint64_t)cur.k;
+    for (uint32_t i = 0; i < last.exec_len; ++i) executorNodes.push_back(cluster.names[exec[off + i]]);
+    out.node = cluster.names[last.driver_node];
+    out.outcome = outcome::success;
+    out.created = newResourceReservation(out.node, executorNodes, driver, resources->DriverResources,
+                                         resources->ExecutorResources);
     return out;
 }
 

@@ -15,6 +15,7 @@
 #include <optional>
 #include <set>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "binpacker.hpp"
@@ -52,6 +53,29 @@ struct SelectNodeResult {
     std::optional<ResourceReservation> created;  // what CreateReservations would persist
 };
 
+// The node side of the cluster in the flat form gf_snapshot_build consumes.  Built when the node set changes (an informer
+// event in the Go host), reused by every Filter: names in lexicographic order give the name ranks, zone ids follow the
+// label order (the tie-break documented at the C ABI).
+struct FlatCluster {
+    std::vector<std::string> names;                  // node index -> name (the order of `nodes` at Build time)
+    std::unordered_map<std::string, uint32_t> index;
+    std::vector<uint32_t> name_rank, zone, base_flags;  // base_flags: GF_NODE_UNSCHEDULABLE / GF_NODE_READY
+    std::vector<std::string> zone_labels;            // zone id -> label
+    std::vector<int64_t> alloc[3];
+    static bool Build(const std::vector<Node>& nodes, FlatCluster* out, std::string* err);
+};
+
+// UsageForNodes' input in flat form: one (node index, cpu milli, memory bytes, gpus) entry per reservation of every
+// ResourceReservation plus the soft reservations (GetReservedResources, resourcereservations.go:258-263).  A host keeps it
+// next to its ResourceReservation cache and updates it on the same events; the replay itself (the sum per node) happens on
+// the device at every Filter.
+struct FlatReservations {
+    std::vector<uint32_t> node;
+    std::vector<int64_t> req[3];
+    static bool Build(const std::vector<ResourceReservation>& reservations, const NodeGroupResources& softReservationUsage,
+                      const FlatCluster& cluster, FlatReservations* out, std::string* err);
+};
+
 class SparkSchedulerExtender {
 public:
     SparkSchedulerExtender(Binpacker binpacker, NodeSorter sorter, bool isFIFO, FifoConfig fifo)
@@ -69,6 +93,14 @@ public:
     // result because affinity matching is k8s API bookkeeping (resource.go:292-298).
     SelectNodeResult selectDriverNode(const std::string& instanceGroup, const Pod& driver,
                                       const std::vector<std::string>& nodeNames, const std::vector<Node>& availableNodes);
+
+    // The same decision with the snapshot built on the device (gf_snapshot_build): the reservation replay, the
+    // available / schedulable columns and NodeSorter.PotentialNodes never touch a string-keyed map.  `cluster` must
+    // describe exactly the nodes the driver's affinity matches.  Label-priority re-sorts are not configured on this path.
+    // `flat` (nullable) = the reservations already in flat form; when null they are flattened from `reservations` here.
+    SelectNodeResult selectDriverNodeFlat(const std::string& instanceGroup, const Pod& driver,
+                                          const std::vector<std::string>& nodeNames, const FlatCluster& cluster,
+                                          const FlatReservations* flat = nullptr);
 
     // unschedulablepods.go:132-166: does the application fit an EMPTY cluster (usage = 0, the given overhead)?
     // nodes are used in lister order for both candidate lists.

@@ -1,0 +1,149 @@
+// host_bench.cpp — the driver Filter end to end through the C++ mirror of the reference's interface (string node names,
+// Quantity-valued annotations, ResourceReservation objects): BASELINE's "p99 Filter latency at 10k nodes x 1k pending
+// apps" measured over the whole span the reference times (internal/extender/resource.go:142-154 `schedule.time`), not
+// just the kernel.  Two routes:
+//   map   selectDriverNode      — UsageForNodes / NodeSchedulingMetadataForNodes / PotentialNodes on string-keyed maps
+//                                 like the Go host, then ONE FIFO-chain call
+//   flat  selectDriverNodeFlat  — flat columns -> gf_snapshot_build (replay + metadata + sort on the device) -> the chain
+// usage: host_bench [n_nodes] [n_pending] [n_reservations] [packer]
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "extender.hpp"
+
+using namespace gangfit::host;
+using Clock = std::chrono::steady_clock;
+
+static uint64_t g_rng = 0x5EED0010;
+static uint64_t next() {
+    g_rng += 0x9E3779B97F4A7C15ull;
+    uint64_t z = g_rng;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static double pct(std::vector<double> v, double q) {
+    std::sort(v.begin(), v.end());
+    return v[std::min(v.size() - 1, (size_t)(q * (v.size() - 1) + 0.5))];
+}
+
+int main(int argc, char** argv) {
+    const int n_nodes = argc > 1 ? std::atoi(argv[1]) : 10000;
+    const int n_pending = argc > 2 ? std::atoi(argv[2]) : 1000;
+    const int n_rr = argc > 3 ? std::atoi(argv[3]) : 2000;
+    const std::string packer = argc > 4 ? argv[4] : "tightly-pack";
+    const int64_t Gi = 1024ll * 1024 * 1024;
+    gf_ctx* ctx = nullptr;
+    if (gf_init(nullptr, 0, &ctx) != GF_OK) {
+        std::printf("no gfx950 device (there is no CPU fallback)\n");
+        return 2;
+    }
+    SparkSchedulerExtender ext(SelectBinpacker(packer, ctx), NodeSorter(), true, FifoConfig{});
+    const char* zones[] = {"az-a", "az-b", "az-c"};
+    const int cpus[] = {16, 32, 64, 96}, mems[] = {64, 128, 256, 384};
+    std::vector<std::string> nodeNames;
+    for (int i = 0; i < n_nodes; ++i) {
+        Node nd;
+        char buf[32];
+        std::snprintf(buf, sizeof buf, "node-%06d", (int)(next() % 1000000));
+        nd.Name = std::string(buf) + "-" + std::to_string(i);
+        nd.labels[kLabelZoneFailureDomain] = zones[next() % 3];
+        const int shape = (int)(next() % 4);
+        nd.Allocatable = {{kResourceCPU, Quantity::FromInt(cpus[shape])}, {kResourceMemory, Quantity::FromInt(mems[shape] * Gi)},
+                          {kResourceNvidiaGPU, Quantity::FromInt(0)}};
+        nd.Ready = true;
+        nodeNames.push_back(nd.Name);
+        ext.nodes.push_back(std::move(nd));
+    }
+    for (int r = 0; r < n_rr; ++r) {  // running applications: K + 1 reservations each
+        ResourceReservation rr;
+        rr.Name = "running-" + std::to_string(r);
+        rr.Namespace = "namespace";
+        const int k = 1 + (int)(next() % 24);
+        for (int e = 0; e <= k; ++e) {
+            Reservation res;
+            res.Node = ext.nodes[next() % n_nodes].Name;
+            res.Resources = {{kResourceCPU, Quantity::FromInt(1 + (int64_t)(next() % 2))},
+                             {kResourceMemory, Quantity::FromInt((int64_t)(2 + next() % 6) * Gi)},
+                             {kResourceNvidiaGPU, Quantity::FromInt(0)}};
+            rr.Reservations[e == 0 ? "driver" : executorReservationName(e - 1)] = std::move(res);
+        }
+        ext.reservations.push_back(std::move(rr));
+    }
+    const char* dcpu[] = {"1", "2", "4"};
+    const char* dmem[] = {"2Gi", "4Gi", "8Gi"};
+    const char* ecpu[] = {"1", "2", "4", "8"};
+    const char* emem[] = {"4Gi", "8Gi", "16Gi", "32Gi"};
+    for (int p = 0; p < n_pending; ++p) {
+        Pod pod;
+        pod.Name = "pending-" + std::to_string(p) + "-spark-driver";
+        pod.Namespace = "namespace";
+        pod.labels = {{common::SparkRoleLabel, common::Driver}, {common::SparkAppIDLabel, "pending-" + std::to_string(p)}};
+        int k = 1;
+        while (k < 512 && next() % 12 != 0) ++k;
+        pod.Annotations = {{common::DriverCPU, dcpu[next() % 3]},   {common::DriverMemory, dmem[next() % 3]},
+                           {common::ExecutorCPU, ecpu[next() % 4]}, {common::ExecutorMemory, emem[next() % 4]},
+                           {common::ExecutorCount, std::to_string(k)}};
+        pod.SchedulerName = common::SparkSchedulerName;
+        pod.InstanceGroup = "batch-medium-priority";
+        pod.CreationTimestampNanos = (int64_t)(p + 1) * 1000000000;
+        ext.pods.push_back(std::move(pod));
+    }
+    ext.nowNanos = (int64_t)(n_pending + 10) * 1000000000;
+    const Pod& driver = ext.pods.back();  // the youngest: all the others are earlier drivers
+    FlatCluster cluster;
+    std::string err;
+    auto t0 = Clock::now();
+    if (!FlatCluster::Build(ext.nodes, &cluster, &err)) {
+        std::printf("FlatCluster::Build: %s\n", err.c_str());
+        return 1;
+    }
+    const double build_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+    FlatReservations flat;
+    t0 = Clock::now();
+    if (!FlatReservations::Build(ext.reservations, ext.softReservationUsage, cluster, &flat, &err)) {
+        std::printf("FlatReservations::Build: %s\n", err.c_str());
+        return 1;
+    }
+    const double flat_rr_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+
+    SelectNodeResult a = ext.selectDriverNode("batch-medium-priority", driver, nodeNames, ext.nodes);
+    SelectNodeResult b = ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster);
+    bool same = a.served && b.served && a.outcome == b.outcome && a.node == b.node && a.created.has_value() == b.created.has_value();
+    if (same && a.created)
+        for (const auto& [name, res] : a.created->Reservations)
+            same = same && b.created->Reservations.count(name) && b.created->Reservations.at(name).Node == res.Node;
+    std::printf("routes agree: %s (outcome %s, node %s, %zu reservations)%s%s\n", same ? "yes" : "NO", b.outcome.c_str(),
+                b.node.c_str(), b.created ? b.created->Reservations.size() : 0, b.served ? "" : "  flat not served: ",
+                b.served ? "" : b.error.c_str());
+    std::vector<double> map_ms, flat_ms, cached_ms;
+    for (int i = 0; i < 8; ++i) {
+        t0 = Clock::now();
+        ext.selectDriverNode("batch-medium-priority", driver, nodeNames, ext.nodes);
+        map_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+    }
+    for (int i = 0; i < 40; ++i) {
+        t0 = Clock::now();
+        ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster);
+        flat_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+    }
+    for (int i = 0; i < 40; ++i) {  // the reservations kept in flat form next to the host's reservation cache
+        t0 = Clock::now();
+        ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster, &flat);
+        cached_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+    }
+    std::printf("{\"nodes\": %d, \"pending_drivers\": %d, \"resource_reservations\": %d, \"packer\": \"%s\", "
+                "\"filter_map_route_ms\": {\"p50\": %.3f, \"p99\": %.3f}, \"filter_flat_route_ms\": {\"p50\": %.3f, \"p99\": %.3f}, "
+                "\"filter_flat_route_cached_reservations_ms\": {\"p50\": %.3f, \"p99\": %.3f}, \"reservation_entries\": %zu, "
+                "\"flat_cluster_build_ms\": %.3f, \"flat_reservations_build_ms\": %.3f, \"routes_agree\": %s}\n",
+                n_nodes, n_pending, n_rr, packer.c_str(), pct(map_ms, 0.5), pct(map_ms, 0.99), pct(flat_ms, 0.5),
+                pct(flat_ms, 0.99), pct(cached_ms, 0.5), pct(cached_ms, 0.99), flat.node.size(), build_ms, flat_rr_ms,
+                same ? "true" : "false");
+    gf_destroy(ctx);
+    return same ? 0 : 1;
+}

@@ -32,3 +32,17 @@ def test_host_mirror_cpu_half():
 def test_host_mirror_through_the_device():
     out = _run("gpu")
     assert "gpu:" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packer", ["tightly-pack", "distribute-evenly", "single-az-tightly-pack", "az-aware-tightly-pack",
+                                    "single-az-minimal-fragmentation"])
+def test_flat_route_agrees_with_map_route(packer):
+    """selectDriverNode on string-keyed maps (the reference's shape) and selectDriverNodeFlat (snapshot built on the
+    device by gf_snapshot_build) must produce the same Filter result and the same reservation; host_bench exits 1 if
+    they do not."""
+    _binary()
+    assert os.path.exists(build.HOST_BENCH_PATH)
+    p = subprocess.run([build.HOST_BENCH_PATH, "700", "120", "90", packer], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "routes agree: yes" in p.stdout, p.stdout[-3000:]
