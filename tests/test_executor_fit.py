@@ -31,6 +31,34 @@ def test_reference_minimal_fragmentation_attracts_to_hosting_node():
     assert ob.executor_fit(avail, [1000, 1, 0], [0, 1], minimal_fragmentation=True) == 0
 
 
+# TestDynamicAllocationScheduling (resource_test.go:172-372, single-az-tightly-pack): where the soft reservation of an
+# executor above the minimum lands.  Restated at the first-fit boundary; node shape 8 cpu / 8 GiB / 1 gpu, pods 1 cpu / 1 B
+# (driver + 1 gpu).  (avail per node, executor order = free memory ascending then name, expected node)
+T2_CASES = [
+    # :197-208 driver + executor-0 on node1 -> node1 sorts first and still fits: "node1"
+    ("soft reservation over min executor count", [[6000, 8 * GIB - 2, 0], [8000, 8 * GIB, 1]], [0, 1], 0),
+    # :209-225 driver and executor-0 went to node2 -> "soft reservations are created on full nodes first": "node2"
+    ("full nodes first", [[8000, 8 * GIB, 1], [6000, 8 * GIB - 2, 0]], [1, 0], 1),
+    # :226-243 two soft reservations in a row stay on node1
+    ("second extra executor", [[5000, 8 * GIB - 3, 0], [8000, 8 * GIB, 1]], [0, 1], 0),
+    # :262-292 the application lives in zone2 (node2): only zone2's nodes are candidates although node1 has less free memory
+    ("same AZ as the application", [[6000, 8 * GIB - 2, 0], [7000, 8 * GIB - 1, 0]], [1], 1),
+]
+
+
+@pytest.mark.parametrize("name,avail,order,want", T2_CASES, ids=[c[0] for c in T2_CASES])
+def test_reference_dynamic_allocation_soft_reservation_nodes(name, avail, order, want):
+    assert ob.executor_fit(avail, [1000, 1, 0], order) == want
+
+
+@pytest.mark.gpu
+def test_gpu_reference_dynamic_allocation_cases(gf_ctx):
+    for name, avail, order, want in T2_CASES:
+        gf_ctx.set_snapshot(avail)
+        gf_ctx.set_orders([0], order)
+        assert gf_ctx.executor_fit([[1000, 1, 0]]).tolist() == [want], name
+
+
 def test_oracle_edge_cases():
     avail = [[1, 1, 0], [5, 5, 0], [9, 9, 1]]
     assert ob.executor_fit(avail, [2, 2, 0], [0, 1, 2]) == 1
