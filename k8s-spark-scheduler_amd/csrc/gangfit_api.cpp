@@ -127,6 +127,9 @@ struct gf_ctx {
     DeviceBuf<uint64_t> d_zmasks;      // [2][n_zones][zstride]: executor masks, then driver masks
     PinnedBuf<uint64_t> h_zmasks;
     uint32_t n_zones = 0, zstride = 0;
+    uint32_t zd_row0 = 0;              // row of d_zmasks where the driver masks start (n_zones, or the zone count of a device build)
+    bool host_stale = false;           // the host mirrors (avail / sched / h_node_slot) still sit on the device (gf_snapshot_build)
+    bool snapshot_finalize_on_device = true;  // GANGFIT_SNAPSHOT_FINALIZE=host builds the slot tables through gf_orders_set
     DeviceBuf<gf_result> d_zres;
     DeviceBuf<uint32_t> d_zexec;
     DeviceBuf<double> d_zavg, d_avg;
@@ -277,7 +280,7 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     GF_HIP(ctx, ctx->d_avg.reserve(4 * (size_t)n_apps));
     int rc = ensure_cnt(ctx, n_dec < 16 ? 16 : n_dec, stream);
     if (rc != GF_OK) return rc;
-    gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)nz * ctx->zstride, nz, ctx->zstride};
+    gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)ctx->zd_row0 * ctx->zstride, nz, ctx->zstride};
     gangfit::ZoneBuffers zb{ctx->d_zres.ptr, ctx->d_zexec.ptr, half, ctx->d_zavg.ptr, ctx->d_cnt.ptr, ctx->cnt_rows,
                             ctx->d_avg.ptr};
     if (mode == GF_MODE_FIFO_CHAIN) {
@@ -450,6 +453,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
         ctx->fifo_wide_fused = std::strstr(k, "fused") != nullptr;
     }
     if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
+    if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;
     if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
         const long v = std::atol(l);
         if (v >= 0 && (uint32_t)v <= ctx->lds_budget) ctx->lds_budget = (uint32_t)v;
@@ -538,6 +542,29 @@ int gf_device_info_get(gf_ctx* ctx, gf_device_info* out) {
     return GF_OK;
 }
 
+namespace {
+// After a device-side gf_snapshot_build the host mirrors of the snapshot are fetched only when something asks for them.
+int materialize_host(gf_ctx* ctx) {
+    if (!ctx->host_stale) return GF_OK;
+    const size_t N = ctx->n_nodes;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, ctx->h_bcols.reserve(6 * N + 1));
+    GF_HIP(ctx, ctx->h_border.reserve(N + 1));
+    if (N) {
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_bcols.ptr, ctx->d_node_tab.ptr, 6 * N * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, ctx->d_node_slot.ptr, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < 3; ++j) {
+        ctx->avail[j].assign(ctx->h_bcols.ptr + (size_t)j * N, ctx->h_bcols.ptr + (size_t)(j + 1) * N);
+        ctx->sched[j].assign(ctx->h_bcols.ptr + (size_t)(3 + j) * N, ctx->h_bcols.ptr + (size_t)(4 + j) * N);
+    }
+    ctx->h_node_slot.assign(ctx->h_border.ptr, ctx->h_border.ptr + N);
+    ctx->host_stale = false;
+    return GF_OK;
+}
+}  // namespace
+
 int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_milli, const int64_t* avail_mem_bytes,
                     const int64_t* avail_gpu, const int64_t* sched_cpu_milli, const int64_t* sched_mem_bytes,
                     const int64_t* sched_gpu) {
@@ -559,6 +586,7 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
                 if (sc[j][n] < 0 || sc[j][n] >= GF_MAX_ABS_QUANTITY)
                     return fail(ctx, GF_ERR_INVALID, "schedulable[%d][%u] outside [0, 2^62)", j, n);
     ctx->zone.clear();
+    ctx->host_stale = false;
     for (int j = 0; j < 3; ++j) {
         ctx->avail[j].assign(av[j], av[j] + n_nodes);
         if (ctx->have_sched)
@@ -598,6 +626,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_orders_set");
+    if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     if ((n_d > 0 && !driver_order) || (n_x > 0 && !exec_order))
         return fail(ctx, GF_ERR_INVALID, "order arrays must not be NULL");
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -872,6 +901,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
                                        hipMemcpyHostToDevice, ctx->stream));
         ctx->n_zones = nz;
         ctx->zstride = zstride;
+        ctx->zd_row0 = nz;
     }
     GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_x = n_x_slots;
@@ -997,8 +1027,10 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     hipStream_t st = ctx->stream;
     // ---- device buffers
     const size_t N = n, R = n_res, Z = n_zones;
-    GF_HIP(ctx, ctx->d_bi64.reserve(15 * N + 2 * N + 3 * R + 3 * Z + 8));
-    GF_HIP(ctx, ctx->d_bu32.reserve(4 * N + R + 2 * Z + 8));
+    const size_t NCH = (N + 1 + 63) / 64;  // chunks of the slot space (nodes + sentinel)
+    GF_HIP(ctx, hipStreamSynchronize(st));  // nothing in flight may still read buffers that are about to grow
+    GF_HIP(ctx, ctx->d_bi64.reserve(15 * N + 2 * N + 3 * R + 3 * Z + 3 * NCH + 16));
+    GF_HIP(ctx, ctx->d_bu32.reserve(5 * N + R + 5 * Z + 16));
     const size_t temp = gangfit::snapshot_sort_temp_bytes(n);
     GF_HIP(ctx, ctx->d_btemp.reserve(temp + 16));
     int64_t* d_alloc = ctx->d_bi64.ptr;
@@ -1017,6 +1049,13 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     uint32_t* d_res_node = d_perm_b + N;
     uint32_t* d_zone_order = d_res_node + R;
     uint32_t* d_zone_rank = d_zone_order + Z;
+    uint32_t* d_zfirst = d_zone_rank + Z;
+    uint32_t* d_zhasx = d_zfirst + Z;
+    uint32_t* d_zeval = d_zhasx + Z;
+    uint32_t* d_scalars = d_zeval + Z;  // 4
+    uint32_t* d_flags = d_scalars + 4;  // N
+    unsigned long long* d_gcd_part = reinterpret_cast<unsigned long long*>(d_zone_sum + 3 * Z);
+    long long* d_units = reinterpret_cast<long long*>(d_gcd_part + 3 * NCH);
     for (int j = 0; j < 3; ++j) {
         GF_HIP(ctx, hipMemcpyAsync(d_alloc + j * N, cols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
         if (with_over) GF_HIP(ctx, hipMemcpyAsync(d_over + j * N, ocols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
@@ -1051,6 +1090,99 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     b.d_temp = ctx->d_btemp.ptr;
     b.temp_bytes = temp;
     GF_HIP(ctx, gangfit::launch_snapshot_build(b, st));
+    if (ctx->snapshot_finalize_on_device && !driver_label_rank && !exec_label_rank) {
+        // ---- the slot tables on the device too: nothing of size O(n_nodes) returns to the host unless the caller asks
+        //      for the orders.  (Label re-sorts can break the merged layout: those go through gf_orders_set below.)
+        const uint32_t n_slots = n + 1, n_chunks = (uint32_t)NCH;
+        GF_HIP(ctx, hipMemcpyAsync(d_flags, node_flags, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_work.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_sched.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_slot_node.reserve(n_slots));
+        GF_HIP(ctx, ctx->d_dslot.reserve((size_t)n_slots + 1));
+        GF_HIP(ctx, ctx->d_node_slot.reserve(N + 1));
+        GF_HIP(ctx, ctx->d_cmax.reserve(3 * (size_t)n_chunks));
+        GF_HIP(ctx, ctx->d_masks.reserve(2 * (size_t)n_chunks));
+        GF_HIP(ctx, ctx->d_node_tab.reserve(6 * N + 1));
+        GF_HIP(ctx, ctx->d_zmasks.reserve(2 * Z * (size_t)n_chunks + 1));
+        GF_HIP(ctx, ctx->d_nsnap.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_nwork.reserve(3 * (size_t)n_slots));
+        GF_HIP(ctx, ctx->d_ncmax.reserve(3 * (size_t)n_chunks));
+        gangfit::SnapshotFinalize f{};
+        f.n_nodes = n;
+        f.n_slots = n_slots;
+        f.n_chunks = n_chunks;
+        f.n_zones = n_zones;
+        f.d_avail = d_avail;
+        f.d_sched = d_sched;
+        f.d_perm = d_perm_b;
+        f.d_zone = d_zone;
+        f.d_flags = d_flags;
+        f.d_snap = ctx->d_snap.ptr;
+        f.d_sched_slot = ctx->d_sched.ptr;
+        f.d_slot_node = ctx->d_slot_node.ptr;
+        f.d_node_slot = ctx->d_node_slot.ptr;
+        f.d_dslot = ctx->d_dslot.ptr;
+        f.d_masks = ctx->d_masks.ptr;
+        f.d_cmax = ctx->d_cmax.ptr;
+        f.d_node_tab = ctx->d_node_tab.ptr;
+        f.d_gcd_part = d_gcd_part;
+        f.d_units = d_units;
+        f.d_zfirst = d_zfirst;
+        f.d_zhasx = d_zhasx;
+        f.d_zeval = d_zeval;
+        f.d_scalars = d_scalars;
+        f.d_zmasks = ctx->d_zmasks.ptr;
+        f.d_nsnap = ctx->d_nsnap.ptr;
+        f.d_ncmax = ctx->d_ncmax.ptr;
+        GF_HIP(ctx, gangfit::launch_snapshot_finalize(f, st));
+        GF_HIP(ctx, ctx->h_bcols.reserve(6 * N + 8));
+        GF_HIP(ctx, ctx->h_border.reserve(N + 8));
+        long long* h_units = reinterpret_cast<long long*>(ctx->h_bcols.ptr);  // 3 values, then the scalars
+        uint32_t* h_scalars = ctx->h_border.ptr;
+        GF_HIP(ctx, hipMemcpyAsync(h_units, d_units, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
+        GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        GF_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t nz = h_scalars[0];
+        for (int j = 0; j < 3; ++j) ctx->unit[j] = (int64_t)h_units[j];
+        ctx->narrow_ok = h_scalars[1] == 0;
+        ctx->have_sched = h_scalars[2] == 0;  // a negative schedulable value (overhead above allocatable) disables the efficiencies
+        ctx->n_nodes = n;
+        ctx->have_snapshot = true;
+        ctx->zone.clear();
+        if (zone_of_node) ctx->zone.assign(zone_of_node, zone_of_node + N);
+        ctx->n_x = ctx->n_d = n;
+        ctx->n_slots = n_slots;
+        ctx->n_chunks = n_chunks;
+        ctx->d_identity = true;
+        ctx->merged = true;
+        ctx->n_zones = nz;
+        ctx->zstride = n_chunks;
+        ctx->zd_row0 = n_zones;
+        ctx->have_orders = true;
+        ctx->work_valid = false;
+        ctx->host_stale = true;
+        if (driver_order_out || exec_order_out || n_d_out || n_x_out) {  // the two lists, for callers that want them
+            GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            GF_HIP(ctx, hipStreamSynchronize(st));
+            uint32_t nd = 0, nx = 0;
+            for (size_t i = 0; i < N; ++i) {
+                const uint32_t node = ctx->h_border.ptr[i];
+                const uint32_t fl = node_flags[node];
+                if (fl & GF_NODE_DRIVER_CANDIDATE) {
+                    if (driver_order_out) driver_order_out[nd] = node;
+                    ++nd;
+                }
+                if (!(fl & GF_NODE_UNSCHEDULABLE) && (fl & GF_NODE_READY)) {
+                    if (exec_order_out) exec_order_out[nx] = node;
+                    ++nx;
+                }
+            }
+            if (n_d_out) *n_d_out = nd;
+            if (n_x_out) *n_x_out = nx;
+        }
+        return GF_OK;
+    }
     GF_HIP(ctx, ctx->h_bcols.reserve(6 * N));
     GF_HIP(ctx, ctx->h_border.reserve(N));
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_bcols.ptr, d_avail, 6 * N * sizeof(int64_t), hipMemcpyDeviceToHost, st));  // avail | sched
@@ -1091,6 +1223,7 @@ int gf_snapshot_get(gf_ctx* ctx, int64_t* avail_out, int64_t* sched_out) {
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "no snapshot");
+    if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     for (uint32_t i = 0; i < ctx->n_nodes; ++i)
         for (int j = 0; j < 3; ++j) {
             if (avail_out) avail_out[3 * (size_t)i + j] = ctx->avail[j][i];
@@ -1227,6 +1360,7 @@ int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const 
     if (n_apps == 0) return GF_OK;
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede");
     if (!ctx->have_sched) return fail(ctx, GF_ERR_STATE, "efficiencies need the schedulable columns of gf_snapshot_set");
+    if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     // validate the lists on the host: every placed node must own a slot (it came out of one of the two orders)
     uint64_t total_k = 0;
@@ -1317,6 +1451,7 @@ int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
     if (!ctx || !avail_out) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_orders || !ctx->work_valid) return fail(ctx, GF_ERR_STATE, "no FIFO chain has run on the current orders");
+    if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, ctx->h_table.reserve(3 * (size_t)ctx->n_slots));
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_table.ptr, ctx->d_work.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),

@@ -239,6 +239,34 @@ struct SnapshotBuild {
     void* d_temp;                // radix-sort scratch
     size_t temp_bytes;
 };
+// The slot tables of the merged layout built from the device-resident snapshot columns (what gf_orders_set builds on the
+// host): every node gets the slot of its position in the priority order.
+struct SnapshotFinalize {
+    uint32_t n_nodes, n_slots, n_chunks, n_zones;
+    const int64_t* d_avail;     // 3 * n_nodes, by node
+    const int64_t* d_sched;     // 3 * n_nodes, by node
+    const uint32_t* d_perm;     // n_nodes: priority order -> node
+    const uint32_t* d_zone;     // n_nodes
+    const uint32_t* d_flags;    // n_nodes: GF_NODE_*
+    int64_t* d_snap;            // 3 * n_slots
+    int64_t* d_sched_slot;      // 3 * n_slots
+    uint32_t* d_slot_node;      // n_slots
+    uint32_t* d_node_slot;      // n_nodes
+    uint32_t* d_dslot;          // n_slots (identity)
+    uint64_t* d_masks;          // 2 * n_chunks: executor | driver candidate bits
+    int64_t* d_cmax;            // 3 * n_chunks
+    int64_t* d_node_tab;        // 6 * n_nodes
+    unsigned long long* d_gcd_part;  // 3 * n_chunks
+    long long* d_units;         // 3
+    uint32_t* d_zfirst;         // n_zones
+    uint32_t* d_zhasx;          // n_zones
+    uint32_t* d_zeval;          // n_zones: zone -> index in the evaluation list, GF_NO_NODE = not evaluated
+    uint32_t* d_scalars;        // [0] = zones in the evaluation list, [1] = no narrow form
+    uint64_t* d_zmasks;         // 2 * n_zones * n_chunks: executor rows, then (from row n_zones) driver rows
+    int32_t* d_nsnap;           // 3 * n_slots
+    int32_t* d_ncmax;           // 3 * n_chunks
+};
+hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t stream);
 size_t snapshot_sort_temp_bytes(uint32_t n_nodes);
 hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream);
 

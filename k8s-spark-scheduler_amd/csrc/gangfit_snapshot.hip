@@ -124,6 +124,167 @@ __global__ void gather_zone_rank_kernel(uint32_t n, const uint32_t* __restrict__
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------- slot tables
+// What gf_orders_set builds on the host for the merged layout, built from the device-resident columns instead: slot s
+// = position s of the priority order (every node gets a slot; nodes that are neither driver nor executor candidates
+// simply have no candidate bit), one sentinel slot behind them.
+
+__device__ __forceinline__ uint64_t gcd_u64(uint64_t a, uint64_t b) {
+    while (b) {
+        const uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// One thread per slot, 64-slot chunks = wavefronts.  Tables, candidate masks, chunk maxima, per-chunk gcds, zone facts.
+__global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = s >> 6;
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n = f.n_nodes, ns = f.n_slots;
+    const bool in_range = s < ns;
+    const bool real = s < n;
+    const uint32_t node = real ? f.d_perm[s] : GF_NO_NODE;
+    int64_t a[3] = {-(INT64_C(1) << 62), -(INT64_C(1) << 62), -(INT64_C(1) << 62)};  // sentinel: never fits, never hosts
+    int64_t sc[3] = {0, 0, 0};
+    uint32_t flags = 0, z = 0;
+    if (real) {
+        for (int j = 0; j < 3; ++j) {
+            a[j] = f.d_avail[(size_t)j * n + node];
+            sc[j] = f.d_sched[(size_t)j * n + node];
+            f.d_node_tab[(size_t)j * n + node] = a[j];
+            f.d_node_tab[(size_t)(3 + j) * n + node] = sc[j];
+        }
+        flags = f.d_flags[node];
+        z = f.d_zone[node];
+        f.d_node_slot[node] = s;
+        if (sc[0] < 0 || sc[1] < 0 || sc[2] < 0) atomicOr(&f.d_scalars[2], 1u);
+    }
+    if (in_range) {
+        for (int j = 0; j < 3; ++j) {
+            f.d_snap[(size_t)j * ns + s] = a[j];
+            f.d_sched_slot[(size_t)j * ns + s] = sc[j];
+        }
+        f.d_slot_node[s] = node;
+        f.d_dslot[s] = s;
+    }
+    const bool xbit = real && !(flags & GF_NODE_UNSCHEDULABLE) && (flags & GF_NODE_READY);
+    const bool dbit = real && (flags & GF_NODE_DRIVER_CANDIDATE);
+    const uint64_t xm = __ballot(xbit), dm = __ballot(dbit);
+    int64_t m[3];
+    uint64_t g[3];
+    for (int j = 0; j < 3; ++j) {
+        m[j] = in_range ? a[j] : INT64_MIN;
+        g[j] = real ? (uint64_t)(a[j] < 0 ? -a[j] : a[j]) : 0ull;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t om = __shfl_xor(m[j], d, 64);
+            m[j] = om > m[j] ? om : m[j];
+            g[j] = gcd_u64(g[j], (uint64_t)__shfl_xor((long long)g[j], d, 64));
+        }
+    }
+    if (lane == 0 && c < f.n_chunks) {
+        f.d_masks[c] = xm;
+        f.d_masks[f.n_chunks + c] = dm;
+        for (int j = 0; j < 3; ++j) {
+            f.d_cmax[(size_t)j * f.n_chunks + c] = m[j];
+            f.d_gcd_part[(size_t)j * f.n_chunks + c] = g[j];
+        }
+    }
+    // zones by first appearance in the driver order, and whether they own an executor candidate (single_az.go:36-41)
+    if (dbit && z < f.n_zones) atomicMin(&f.d_zfirst[z], s);
+    if (xbit && z < f.n_zones) atomicOr(&f.d_zhasx[z], 1u);
+}
+
+// One workgroup: the per-dimension units (gcd over the chunk gcds) and the zone evaluation list.
+__global__ __launch_bounds__(256) void finalize_reduce_kernel(SnapshotFinalize f) {
+    __shared__ unsigned long long part[3][256];
+    for (int j = 0; j < 3; ++j) {
+        uint64_t g = 0;
+        for (uint32_t c = threadIdx.x; c < f.n_chunks; c += blockDim.x) g = gcd_u64(g, f.d_gcd_part[(size_t)j * f.n_chunks + c]);
+        part[j][threadIdx.x] = g;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < 3; ++j) {
+            uint64_t g = 0;
+            for (uint32_t t = 0; t < blockDim.x; ++t) g = gcd_u64(g, part[j][t]);
+            f.d_units[j] = g ? (long long)g : 1ll;
+        }
+        // evaluation list: zones that have a driver candidate AND an executor candidate, ordered by their first driver slot
+        uint32_t nz = 0;
+        for (uint32_t z = 0; z < f.n_zones; ++z) f.d_zeval[z] = GF_NO_NODE;
+        for (;;) {
+            uint32_t best = GF_NO_NODE, best_first = GF_NO_NODE;
+            for (uint32_t z = 0; z < f.n_zones; ++z)
+                if (f.d_zeval[z] == GF_NO_NODE && f.d_zhasx[z] && f.d_zfirst[z] < best_first) {
+                    best = z;
+                    best_first = f.d_zfirst[z];
+                }
+            if (best == GF_NO_NODE) break;
+            f.d_zeval[best] = nz++;
+        }
+        f.d_scalars[0] = nz;  // [1] = "a scaled value does not fit 2^30" (next kernel), [2] = "negative schedulable value"
+    }
+}
+
+// One thread per slot: the narrow (scaled int32) table + its chunk maxima, and the per-zone candidate masks.
+__global__ __launch_bounds__(256) void finalize_narrow_zones_kernel(SnapshotFinalize f) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = s >> 6;
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n = f.n_nodes, ns = f.n_slots;
+    const bool real = s < n;
+    const uint32_t node = real ? f.d_slot_node[s] : GF_NO_NODE;
+    int32_t v[3] = {INT32_MIN / 2, INT32_MIN / 2, INT32_MIN / 2};
+    bool bad = false;
+    if (real)
+        for (int j = 0; j < 3; ++j) {
+            const int64_t q = f.d_snap[(size_t)j * ns + s] / f.d_units[j];
+            bad = bad || q >= (INT64_C(1) << 30) || q <= -(INT64_C(1) << 30);
+            v[j] = (int32_t)q;
+        }
+    if (__ballot(bad) && lane == 0) atomicOr(&f.d_scalars[1], 1u);
+    for (int j = 0; j < 3; ++j) {
+        if (s < ns) f.d_nsnap[(size_t)j * ns + s] = v[j];
+        int32_t m = s < ns ? v[j] : INT32_MIN;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t o = __shfl_xor(m, d, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0 && c < f.n_chunks) f.d_ncmax[(size_t)j * f.n_chunks + c] = m;
+    }
+    uint32_t ei = GF_NO_NODE;
+    bool xbit = false, dbit = false;
+    if (real) {
+        const uint32_t flags = f.d_flags[node], z = f.d_zone[node];
+        xbit = !(flags & GF_NODE_UNSCHEDULABLE) && (flags & GF_NODE_READY);
+        dbit = flags & GF_NODE_DRIVER_CANDIDATE;
+        if (z < f.n_zones) ei = f.d_zeval[z];
+    }
+    const uint32_t nz = f.d_scalars[0];
+    for (uint32_t e = 0; e < nz; ++e) {
+        const uint64_t zx = __ballot(ei == e && xbit), zd = __ballot(ei == e && dbit);
+        if (lane == 0 && c < f.n_chunks) {
+            f.d_zmasks[(size_t)e * f.n_chunks + c] = zx;
+            f.d_zmasks[((size_t)f.n_zones + e) * f.n_chunks + c] = zd;
+        }
+    }
+}
+
+hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(f.d_zfirst, 0xFF, (size_t)f.n_zones * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(f.d_zhasx, 0, (size_t)f.n_zones * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(f.d_scalars, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    const dim3 block(256), grid((unsigned)(((size_t)f.n_chunks * 64 + 255) / 256));
+    hipLaunchKernelGGL(finalize_slots_kernel, grid, block, 0, stream, f);
+    hipLaunchKernelGGL(finalize_reduce_kernel, dim3(1), block, 0, stream, f);
+    hipLaunchKernelGGL(finalize_narrow_zones_kernel, grid, block, 0, stream, f);
+    return hipGetLastError();
+}
+
 size_t snapshot_sort_temp_bytes(uint32_t n_nodes) {
     size_t bytes = 0;
     int64_t* k = nullptr;
