@@ -76,8 +76,8 @@ def cpu_baseline_congested(w, max_apps: int = 48):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)  # ~22 ms timed: the closing barrier of an N-GPU run stays below 1 %
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--nodes", type=int, default=10000)
     ap.add_argument("--apps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -226,7 +226,7 @@ def main():
                         "apps": sb.n_apps, "nodes": len(wk.snapshot.avail), "n_shards": world, "steps": steps,
                         "collectives_per_batch": "2 all-gather (16 B/app) + 1 all-reduce (4 B/executor)"}
 
-            node_sharded = {"headline": time_sharded(ctx, base, max(10, args.steps // 4), 5)}
+            node_sharded = {"headline": time_sharded(ctx, base, max(10, min(args.steps, 200) // 4), 5)}
             # BASELINE config 4's size: 50 000 nodes x 10 000 apps (gang size = MinExecutorCount)
             w4 = wl.config(4)
             ctx4 = gangfit.Context(local_rank)
@@ -266,8 +266,8 @@ def main():
         out["extras"] = extras
         try:
             # distribute-evenly on the same batch
-            wall_e, kern_e = timed(EVEN, args.steps, max(2, args.warmup // 4))
-            extras["distribute_evenly"] = {"decisions_per_s": len(apps) * args.steps / wall_e, "kernel_ms": kern_e}
+            wall_e, kern_e = timed(EVEN, min(args.steps, 400), max(2, args.warmup // 4))
+            extras["distribute_evenly"] = {"decisions_per_s": len(apps) * min(args.steps, 400) / wall_e, "kernel_ms": kern_e}
             # FIFO Filter: chain of (apps-1) earlier drivers + the filtered one, host entry point (H2D + kernel + D2H)
             lat = []
             n_calls = 60
@@ -292,7 +292,7 @@ def main():
             d_apps = torch.from_numpy(capps.view(np.uint8).copy()).to(dev)
             d_exec = torch.zeros(ctotal + 1, dtype=torch.int32, device=dev)
             apps, total_k = capps, ctotal
-            wall_c, kern_c = timed(TIGHT, max(10, args.steps // 4), 3)
+            wall_c, kern_c = timed(TIGHT, max(10, min(args.steps, 400) // 4), 3)
             ctx.scan_stats(enable=True, reset=True)
             step(TIGHT)
             torch.cuda.synchronize()
@@ -307,7 +307,7 @@ def main():
                 lat.append((time.perf_counter() - t0) * 1e3)
             extras["congested"] = {
                 "workload": wc.name, "feasible_fraction": float(res["has_capacity"].mean()),
-                "decisions_per_s": len(capps) * max(10, args.steps // 4) / wall_c, "kernel_ms": kern_c,
+                "decisions_per_s": len(capps) * max(10, min(args.steps, 400) // 4) / wall_c, "kernel_ms": kern_c,
                 "achieved_GBps_algorithmic": cb / (kern_c * 1e-3) / 1e9,
                 "achieved_GBps_visited": cvis / (kern_c * 1e-3) / 1e9,
                 "fifo_filter_p50_ms": _percentile(lat, 0.5), "fifo_filter_p99_ms": _percentile(lat, 0.99),

@@ -177,11 +177,31 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
     uint64_t g[3];
     for (int j = 0; j < 3; ++j) {
         m[j] = in_range ? a[j] : INT64_MIN;
-        g[j] = real ? (uint64_t)(a[j] < 0 ? -a[j] : a[j]) : 0ull;
+        uint64_t v = real ? (uint64_t)(a[j] < 0 ? -a[j] : a[j]) : 0ull;
+        uint64_t any = v;
         for (int d = 1; d < 64; d <<= 1) {
             const int64_t om = __shfl_xor(m[j], d, 64);
             m[j] = om > m[j] ? om : m[j];
-            g[j] = gcd_u64(g[j], (uint64_t)__shfl_xor((long long)g[j], d, 64));
+            any |= (uint64_t)__shfl_xor((long long)any, d, 64);
+        }
+        // gcd of the chunk: the common power of two comes from the OR of the magnitudes; what is left of byte / milli
+        // quantities almost always fits 32 bits, where Euclid's steps are cheap (gfx950 has no 64-bit divider)
+        const int tz = any ? __builtin_ctzll(any) : 0;
+        v >>= tz;
+        if (__ballot(v >> 32) == 0) {
+            uint32_t w = (uint32_t)v;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t o = (uint32_t)__shfl_xor((int)w, d, 64);
+                while (o) {
+                    const uint32_t t = w % o;
+                    w = o;
+                    o = t;
+                }
+            }
+            g[j] = (uint64_t)w << tz;
+        } else {
+            for (int d = 1; d < 64; d <<= 1) v = gcd_u64(v, (uint64_t)__shfl_xor((long long)v, d, 64));
+            g[j] = v << tz;
         }
     }
     if (lane == 0 && c < f.n_chunks) {
@@ -193,8 +213,19 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
         }
     }
     // zones by first appearance in the driver order, and whether they own an executor candidate (single_az.go:36-41)
-    if (dbit && z < f.n_zones) atomicMin(&f.d_zfirst[z], s);
-    if (xbit && z < f.n_zones) atomicOr(&f.d_zhasx[z], 1u);
+    // (one atomic per wavefront and zone: a hundred thousand same-address atomics would serialise)
+    uint64_t todo = __ballot((dbit || xbit) && z < f.n_zones);
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t zl = (uint32_t)__shfl((int)z, leader, 64);
+        const uint64_t same = __ballot(z == zl && z < f.n_zones && real);
+        const uint64_t dsame = __ballot(z == zl && dbit), xsame = __ballot(z == zl && xbit);
+        if (lane == leader) {
+            if (dsame) atomicMin(&f.d_zfirst[zl], (s - (uint32_t)lane) + (uint32_t)(__ffsll((unsigned long long)dsame) - 1));
+            if (xsame) atomicOr(&f.d_zhasx[zl], 1u);
+        }
+        todo &= ~same;
+    }
 }
 
 // One workgroup: the per-dimension units (gcd over the chunk gcds) and the zone evaluation list.
