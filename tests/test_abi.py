@@ -72,3 +72,18 @@ def test_product_path_never_touches_the_oracle():
                 if re.search(r"gangfit_oracle|pyoracle|from oracle|import oracle|oracle/", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/gangfit.h must compile as C99 (what cgo feeds it to) with the promised
+    record layouts."""
+    import subprocess
+
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "gangfit.h"\n'
+                   "int main(void) { return sizeof(gf_app) == 64 && sizeof(gf_result) == 16 && sizeof(gf_shard_partial) == 16 &&\n"
+                   "                        sizeof(gf_shard_driver) == 16 && sizeof(gf_avg_efficiency) == 32 ? 0 : 1; }\n")
+    exe = tmp_path / "hdr"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
