@@ -165,9 +165,14 @@ def main():
             traffic = json.load(open(pmc_path)).get("fit_independent_tight_headline_bytes_per_launch")
         except Exception:
             traffic = None
+    try:
+        measured_peak = ctx.hbm_probe(2 << 30, 10)  # stream copy, read + write, on this device
+    except Exception:
+        measured_peak = None
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "traffic": traffic,
+        "measured_stream_copy_peak": measured_peak,
         "kernel": "fit_independent_kernel<tightly-pack>",
         "kernel_ms": kern_ms,
         "algorithmic_bytes_per_launch": alg_bytes,

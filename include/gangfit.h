@@ -274,6 +274,11 @@ int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[10]);
  * reference code on n_cases adversarial inputs per lane.  *mismatches == 0 means pass. */
 int gf_selftest(gf_ctx *ctx, uint64_t seed, uint32_t n_cases, uint32_t *mismatches);
 
+/* Stream-copy probe: copies `bytes` (a multiple of 16; use far more than the 256 MiB of last-level cache) `iters` times
+ * between two scratch buffers and reports read + write bandwidth in GB/s — the achievable HBM peak the rooflines in
+ * bench.py are set against, next to the spec figure. */
+int gf_hbm_probe(gf_ctx *ctx, uint64_t bytes, uint32_t iters, double *gb_per_s);
+
 /* Device properties the host uses to size launches (also lets a caller verify it is talking to a gfx950). */
 typedef struct gf_device_info {
     char name[128];

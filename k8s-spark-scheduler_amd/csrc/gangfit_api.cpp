@@ -536,6 +536,38 @@ void gf_destroy(gf_ctx* ctx) {
 
 const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* gb_per_s) {
+    if (!ctx || !gb_per_s || bytes < 16 || iters == 0) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    bytes &= ~UINT64_C(15);
+    void *src = nullptr, *dst = nullptr;
+    GF_HIP(ctx, hipMalloc(&src, bytes));
+    if (hipMalloc(&dst, bytes) != hipSuccess) {
+        (void)hipFree(src);
+        return fail(ctx, GF_ERR_HIP, "hipMalloc of the probe buffer failed");
+    }
+    int rc = GF_OK;
+    float ms = 0.0f;
+    do {
+        if (hipMemsetAsync(src, 1, bytes, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }
+        if (gangfit::launch_stream_copy(src, dst, bytes, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }  // warm-up
+        if (hipEventRecord(ctx->ev_begin, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }
+        for (uint32_t i = 0; i < iters && rc == GF_OK; ++i)
+            if (gangfit::launch_stream_copy(i & 1 ? dst : src, i & 1 ? src : dst, bytes, ctx->stream) != hipSuccess) rc = GF_ERR_HIP;
+        if (rc != GF_OK) break;
+        if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+            hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess)
+            rc = GF_ERR_HIP;
+    } while (false);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (rc != GF_OK) return fail(ctx, rc, "stream-copy probe failed");
+    *gb_per_s = ms > 0.0f ? 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9 : 0.0;
+    return GF_OK;
+}
+
 int gf_device_info_get(gf_ctx* ctx, gf_device_info* out) {
     if (!ctx || !out) return GF_ERR_INVALID;
     *out = ctx->info;

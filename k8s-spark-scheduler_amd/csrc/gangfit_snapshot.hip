@@ -316,6 +316,28 @@ hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t strea
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------- stream-copy probe
+// The achievable HBM bandwidth of THIS device, for the roofline next to the spec figure: a plain
+// grid-stride copy with 16-byte accesses, far larger than L2 + MALL.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 32), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, n16);
+    return hipGetLastError();
+}
+
 size_t snapshot_sort_temp_bytes(uint32_t n_nodes) {
     size_t bytes = 0;
     int64_t* k = nullptr;

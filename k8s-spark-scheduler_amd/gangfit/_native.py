@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch",
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats",
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
-    "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
+    "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
 ]
 
 
@@ -106,6 +106,8 @@ def load() -> C.CDLL:
     L.gf_avg_packing_efficiency.argtypes = [p, i32, u32, p, p, p, u64, p]
     L.gf_packing_efficiencies.restype = i32
     L.gf_packing_efficiencies.argtypes = [p, i32, p, p, p, p]
+    L.gf_hbm_probe.restype = i32
+    L.gf_hbm_probe.argtypes = [p, u64, u32, C.POINTER(C.c_double)]
     L.gf_snapshot_build.restype = i32
     L.gf_snapshot_build.argtypes = [p, u32, p, p, p, p, p, p, u32, p, p, p, p, p, p, u32, p, p, p, p, p, p, p]
     L.gf_snapshot_get.restype = i32

@@ -231,6 +231,12 @@ class Context:
         self.last_fifo_phases = [int(v) for v in out[4:10]]  # stage, driver scan, executor scan, slow path, commit
         return int(out[0]), int(out[1])
 
+    def hbm_probe(self, nbytes: int = 2 << 30, iters: int = 10) -> float:
+        """Achievable HBM bandwidth (read + write GB/s) of a plain stream copy on this device."""
+        out = C.c_double(0.0)
+        self._check(self._lib.gf_hbm_probe(self._h, nbytes, iters, C.byref(out)))
+        return float(out.value)
+
     def selftest(self, seed: int = 1, n_cases: int = 256) -> int:
         bad = C.c_uint32(0)
         self._check(self._lib.gf_selftest(self._h, seed, n_cases, C.byref(bad)))

@@ -36,6 +36,11 @@ def test_device_is_gfx950(gf_ctx):
     assert info["compute_units"] >= 200
 
 
+def test_hbm_stream_copy_probe(gf_ctx):
+    """The roofline's measured companion of the 8 TB/s spec figure: a plain copy must move terabytes per second."""
+    assert gf_ctx.hbm_probe(1 << 30, 4) > 1000.0
+
+
 def test_wave_primitives_selftest(gf_ctx):
     # DPP prefix scan and the f64-reciprocal exact division vs plain serial code / 64-bit divide, on device
     assert gf_ctx.selftest(seed=1, n_cases=512) == 0
