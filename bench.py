@@ -61,6 +61,41 @@ def cpu_baseline(w, budget_s: float = 10.0):
     }
 
 
+def _cpu_worker(args):
+    n_nodes, n_apps, budget_s, closed = args
+    from gangfit import workloads as wl
+    from oracle import binding as ob
+
+    w = wl.headline(n_nodes, n_apps, seed=0x5EED0010)
+    s = w.snapshot
+    apps = ob.make_apps(w.drv, w.exe, w.k, w.flags)
+    ob.fit_independent(0, s.avail, apps[:8], s.driver_order, s.exec_order)
+    n_done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        ob.fit_independent(0, s.avail, apps, s.driver_order, s.exec_order, closed_form=closed)
+        n_done += len(apps)
+    return n_done, time.perf_counter() - t0
+
+
+def cpu_baseline_variants(n_nodes, n_apps, budget_s: float = 4.0):
+    """next to the single-thread literal port, the array-form (closed-form) restatement on one core and a
+    'generous' all-cores figure (independent decisions, one process per core)."""
+    import multiprocessing as mp
+
+    n_done, dt = _cpu_worker((n_nodes, n_apps, budget_s, True))
+    out = {"closed_form_1_core": {"value": n_done / dt, "unit": "decisions/s", "cores": 1, "kind": "port"}}
+    cores = os.cpu_count() or 1
+    try:
+        with mp.get_context("spawn").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(n_nodes, n_apps, budget_s, False)] * cores)
+        out["literal_all_cores"] = {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "decisions/s",
+                                    "cores": cores, "kind": "port",
+                                    "sample": f"{cores} processes x {budget_s:.0f} s of whole-batch passes"}
+    except Exception as e:
+        out["literal_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def cpu_baseline_congested(w, max_apps: int = 48):
     from oracle import binding as ob
 
@@ -391,6 +426,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl.headline(args.nodes, args.apps, seed=0x5EED0010))
+        try:
+            out["cpu_baseline_variants"] = cpu_baseline_variants(args.nodes, args.apps)
+        except Exception as e:
+            out["cpu_baseline_variants"] = {"error": f"{type(e).__name__}: {e}"}
 
     ctx.close()
     if dist is not None:
