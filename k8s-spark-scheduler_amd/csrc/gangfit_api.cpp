@@ -108,6 +108,8 @@ struct gf_ctx {
     DeviceBuf<gangfit::DevApp> d_dev_apps;  // FIFO chain: app records with reciprocals (prepare_apps_kernel)
     DeviceBuf<gangfit::NApp> d_napps;       // the same in the narrow domain
     DeviceBuf<int32_t> d_wide_needed;       // set by prepare_apps_kernel when a request has no narrow form
+    DeviceBuf<int32_t> d_capmat;            // minimal-fragmentation chain: capacity per (request shape, slot)
+    bool fifo_minfrag_matrix = true;        // GANGFIT_MINFRAG_MATRIX=0 recomputes capacities in every pass
     // narrow (scaled int32) form of the table: value = scaled * unit[dim]; exists when every |value / unit| < 2^30
     bool narrow_ok = false;
     int64_t unit[3] = {1, 1, 1};
@@ -259,9 +261,15 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     nt.gpu = nt.mem + ctx->n_slots;
     nt.cmax = ctx->d_ncmax.ptr;
     for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+    // capacity matrix: one int32 per (request shape, slot); skipped (capacities recomputed per pass) beyond 1 GiB
+    int32_t* capmat = nullptr;
+    if ((uint64_t)n_shapes * ctx->n_slots * sizeof(int32_t) <= (UINT64_C(1) << 30) && ctx->fifo_minfrag_matrix) {
+        GF_HIP(ctx, ctx->d_capmat.reserve((size_t)n_shapes * ctx->n_slots));
+        capmat = ctx->d_capmat.ptr;
+    }
     GF_HIP(ctx, gangfit::launch_fit_fifo_minfrag_lds(zoned, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr, lds_slots,
                                                      n_shapes, n_apps, d_apps, ctx->d_napps.ptr, ctx->d_wide_needed.ptr,
-                                                     d_results, d_exec_nodes, ctx->d_zexec.ptr, half, d_failed, stream));
+                                                     d_results, d_exec_nodes, ctx->d_zexec.ptr, half, d_failed, capmat, stream));
     *run_if = ctx->d_wide_needed.ptr;
     return GF_OK;
 }
@@ -453,6 +461,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
         ctx->fifo_wide_fused = std::strstr(k, "fused") != nullptr;
     }
     if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
+    if (const char* z = std::getenv("GANGFIT_MINFRAG_MATRIX")) ctx->fifo_minfrag_matrix = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;
     if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
         const long v = std::atol(l);
@@ -490,6 +499,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_dev_apps.release();
     ctx->d_napps.release();
     ctx->d_wide_needed.release();
+    ctx->d_capmat.release();
     ctx->d_nsnap.release();
     ctx->d_nwork.release();
     ctx->d_ncmax.release();

@@ -175,7 +175,8 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                        const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                        const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                       int32_t* d_chain_failed_at, hipStream_t stream);
+                                       int32_t* d_chain_failed_at, int32_t* d_capmat /* n_shapes x n_slots, nullable */,
+                                       hipStream_t stream);
 
 // ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
 // (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.

@@ -1523,7 +1523,7 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                        const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                        const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                       int32_t* d_chain_failed_at, hipStream_t stream) {
+                                       int32_t* d_chain_failed_at, int32_t* d_capmat, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     if ((zoned && zones.n_zones > 16) || !table.d_identity || n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
@@ -1533,13 +1533,13 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_shapes);
     if (zoned)
-        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, 16, lds, stream, table, ntable, zones, d_sched, lds_slots,
+        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
                                  n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at);
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat);
     else
-        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<false>, 16, lds, stream, table, ntable, zones, d_sched, lds_slots,
+        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<false>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
                                  n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at);
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);

@@ -164,8 +164,9 @@ def test_headline_size(gf_ctx):
         assert ref.results["has_capacity"].mean() > 0.5
 
 
-@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "60000"}],
-                         ids=["lds-chain", "generic-chain", "lds-chain-global-tail"])
+@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "60000"},
+                                 {"GANGFIT_MINFRAG_MATRIX": "0"}],
+                         ids=["lds-chain", "generic-chain", "lds-chain-global-tail", "lds-chain-no-capacity-matrix"])
 @pytest.mark.parametrize("algo", [MF, SAZMF])
 def test_fifo_chain_kernel_variants(algo, env):
     """The block-cooperative LDS chain (gangfit_fifo_minfrag.inc), the generic global-memory chain and the hybrid
