@@ -118,6 +118,7 @@ struct gf_ctx {
     // GANGFIT_FIFO_KERNEL: "narrow" (default: narrow first, v2 as its wide fallback), "fused" (wide fused only),
     // "v2" (general-layout kernel only), "narrow+fused" (narrow first, wide fused as the fallback)
     bool fifo_use_narrow = true, fifo_wide_fused = false;
+    bool fifo_solo = true;     // narrow chain = one controlling wavefront (gangfit_fifo_solo.inc); GANGFIT_FIFO_SOLO=0 selects the block-cooperative kernel
     bool fifo_zoned_lds = true;  // GANGFIT_FIFO_ZONED=generic forces the global-memory chain for the zone-aware packers
     int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
@@ -401,6 +402,8 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         if (plan.lds_slots_v2 > ctx->n_slots) plan.lds_slots_v2 = ctx->n_slots;
         plan.lds_slots_fused = front(gangfit::fifo_fused_lds_bytes(0, ctx->n_chunks), 24, block);
         plan.lds_slots_narrow = front(gangfit::fifo_narrow_lds_bytes(0, ctx->n_chunks), 12, block);
+        plan.solo = ctx->fifo_solo;
+        plan.lds_slots_solo = front(gangfit::fifo_solo_lds_bytes(0, ctx->n_chunks), 12, 64);
         gangfit::NarrowTable nt{};
         if (plan.narrow) {
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
@@ -460,6 +463,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
         ctx->fifo_use_narrow = std::strncmp(k, "narrow", 6) == 0;
         ctx->fifo_wide_fused = std::strstr(k, "fused") != nullptr;
     }
+    if (const char* z = std::getenv("GANGFIT_FIFO_SOLO")) ctx->fifo_solo = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
     if (const char* z = std::getenv("GANGFIT_MINFRAG_MATRIX")) ctx->fifo_minfrag_matrix = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;

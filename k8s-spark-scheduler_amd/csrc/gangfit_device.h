@@ -113,18 +113,22 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t
 //   fused  (gangfit_fifo_fused.inc)   — merged layout, wide table, fused scan
 //   narrow (gangfit_fifo_narrow.inc)  — merged layout, scaled int32 table: the fast path; when a request of the batch is not
 //                                       representable it returns at once and the wide kernel (guarded the other way) runs
+//   solo   (gangfit_fifo_solo.inc)    — the narrow kernel's contract with ONE wavefront walking the chain (default)
 // followed by expand_translate_kernel (run heads -> placement list, slot ids -> node indices).
 struct FifoPlan {
     int n_waves;                // wavefronts of the workgroup (1 / 4 / 16 for v2; 4 / 8 / 16 for fused and narrow)
     bool narrow;                // launch the narrow kernel first (merged layout and the table has a narrow form)
+    bool solo;                  // narrow kernel = the one-controlling-wavefront chain (gangfit_fifo_solo.inc)
     bool wide_fused;            // wide kernel = fused instead of v2 (merged layout only)
     uint32_t lds_slots_v2;      // table slots each kernel keeps in LDS
     uint32_t lds_slots_fused;
     uint32_t lds_slots_narrow;
+    uint32_t lds_slots_solo;
 };
 size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 size_t fifo_fused_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
+size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
                            uint32_t n_apps, const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps,
                            int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,

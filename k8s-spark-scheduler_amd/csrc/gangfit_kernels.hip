@@ -1161,6 +1161,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 
 #include "gangfit_fifo_fused.inc"
 #include "gangfit_fifo_narrow.inc"
+#include "gangfit_fifo_solo.inc"
 #include "gangfit_zones.inc"
 #include "gangfit_fifo_zoned.inc"
 #include "gangfit_fifo_minfrag.inc"
@@ -1265,6 +1266,17 @@ size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
            12 * (size_t)n_chunks + 12 * (size_t)lds_slots + 16;
 }
 
+size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
+    const size_t nw = (n_chunks + 63u) / 64u;
+    size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nw +
+                 8 * (size_t)n_chunks;
+    off = (off + 15) & ~(size_t)15;
+    off += sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 + 4 * kMaxShapes +
+           4 * (size_t)n_chunks + 12 * (size_t)n_chunks;
+    off = (off + 15) & ~(size_t)15;
+    return off + 12 * (size_t)lds_slots;
+}
+
 namespace {
 template <class Kernel, class... Args>
 hipError_t launch_one_workgroup(Kernel kernel, int n_waves, size_t lds, hipStream_t stream, Args... args) {
@@ -1331,6 +1343,25 @@ hipError_t launch_narrow(const FifoPlan& P, const NodeTable& T, const NarrowTabl
 }
 
 template <int ALGO>
+hipError_t launch_solo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps, NApp* d_napps,
+                       const int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                       uint64_t half, int32_t* d_failed, ScanStats* d_stats, hipStream_t stream) {
+    const size_t lds = fifo_solo_lds_bytes(P.lds_slots_solo, T.n_chunks);
+    constexpr int NW = 16;  // wavefront 0 walks the chain; all sixteen share the prologue and the epilogue
+    const bool resident = P.lds_slots_solo >= T.n_slots;
+#define GF_SOLO(PR, RE)                                                                                                     \
+    return launch_one_workgroup(fit_fifo_solo_kernel<ALGO, NW, PR, RE>, NW, lds, stream, T, NT, P.lds_slots_solo, n_apps,    \
+                                d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats)
+    if (d_stats != nullptr) {
+        if (resident) GF_SOLO(true, true);
+        GF_SOLO(true, false);
+    }
+    if (resident) GF_SOLO(false, true);
+    GF_SOLO(false, false);
+#undef GF_SOLO
+}
+
+template <int ALGO>
 hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
                             const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps, int32_t* d_wide_needed,
                             gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half,
@@ -1356,8 +1387,12 @@ hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowT
         if (e != hipSuccess) return e;
     }
     if (P.narrow) {
-        e = launch_narrow<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,
-                                d_failed, d_stats, stream);
+        if (P.solo)
+            e = launch_solo<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,
+                                  d_failed, d_stats, stream);
+        else
+            e = launch_narrow<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,
+                                    d_failed, d_stats, stream);
         if (e != hipSuccess) return e;
     }
     if (fused)

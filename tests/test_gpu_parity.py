@@ -150,6 +150,72 @@ def test_fifo_chain_random(gf_ctx, algo, n, layout):
         assert np.array_equal(gf_ctx.residual(), ref.avail_after)
 
 
+_CHAIN_VARIANTS = [{}, {"GANGFIT_FIFO_SOLO": "0"}, {"GANGFIT_LDS_BUDGET": "24000"},
+                   {"GANGFIT_FIFO_SOLO": "0", "GANGFIT_LDS_BUDGET": "24000"}, {"GANGFIT_FIFO_KERNEL": "fused"},
+                   {"GANGFIT_FIFO_KERNEL": "v2"}]
+_CHAIN_IDS = ["solo", "block-cooperative", "solo-global-tail", "block-cooperative-global-tail", "wide-fused", "wide-v2"]
+
+
+def _ctx_with_env(env):
+    import os
+
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return gangfit.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("env", _CHAIN_VARIANTS, ids=_CHAIN_IDS)
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_fifo_chain_kernel_variants(algo, env):
+    """Every chain kernel of the plain packers on the same problems (merged layout): the one-controlling-wavefront chain
+    (gangfit_fifo_solo.inc; whole table in LDS, and with a global-memory tail), the block-cooperative narrow kernel,
+    the wide kernels.  Cases: few request shapes (exact chunk index), more than 64 distinct shapes (chunk-maxima path),
+    a depleting cluster where most of the queue cannot fit (capacity bound learnt per shape, driver fallback, several
+    distribute-evenly passes), a request without a scaled form (wide fallback)."""
+    ctx = _ctx_with_env(env)
+    rng = np.random.default_rng(4242 + algo)
+    try:
+        for rep in range(6):
+            n, a = ((3000, 150), (900, 200), (5000, 120), (700, 260), (2000, 150), (1500, 100))[rep]
+            avail, D, X, drv, exe, k = _random_problem(rng, n, a, tight_cluster=rep in (1, 3), layout="merged")
+            exe = np.maximum(exe, 1)
+            k = np.minimum(k, 60 if rep != 2 else 700).astype(np.int32)
+            if rep in (0, 1, 2):  # a handful of templates: few distinct shapes, long runs of the same shape
+                t = rng.integers(0, 5, size=a)
+                drv, exe = drv[t], exe[t]
+            if rep == 3:  # the cluster runs dry: most apps are skipped, the same shapes keep coming back
+                t = rng.integers(0, 3, size=a)
+                drv, exe = drv[t], exe[t]
+                k = rng.integers(20, 200, size=a).astype(np.int32)
+            if rep == 4:  # more than 64 distinct request vectors
+                drv = rng.integers(0, 40, size=(a, 3)).astype(np.int64)
+                exe = rng.integers(1, 40, size=(a, 3)).astype(np.int64)
+                avail = avail * 8
+            flags = (rng.random(a) < (0.97 if rep in (0, 5) else 1.0)).astype(np.uint32)  # reps 1-4: nothing aborts the chain
+            if rep == 5:
+                avail = avail * 6
+                drv[7, 1] = 5  # not a multiple of the table's unit
+            ctx.set_snapshot(avail)
+            ctx.set_orders(D, X)
+            apps = _gpu_apps(drv, exe, k, flags)
+            gpu = ctx.fit_batch(FIFO, algo, apps)
+            ref = ob.fit_fifo_chain(algo, avail, ob.make_apps(drv, exe, k, flags), D, X)
+            assert gpu.failed_at == ref.failed_at, f"rep {rep}"
+            _assert_same(gpu, ref, apps)
+            assert np.array_equal(ctx.residual(), ref.avail_after), f"rep {rep}"
+            if rep == 3:
+                assert 0.02 < ref.results["has_capacity"].mean() < 0.9
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("number", [1, 2])
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
 def test_baseline_configs_small(gf_ctx, number, algo):
