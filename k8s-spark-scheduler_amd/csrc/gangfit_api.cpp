@@ -120,7 +120,7 @@ struct gf_ctx {
     bool fifo_use_narrow = true, fifo_wide_fused = false;
     bool fifo_solo = true;     // narrow chain = one controlling wavefront (gangfit_fifo_solo.inc); GANGFIT_FIFO_SOLO=0 selects the block-cooperative kernel
     bool fifo_zoned_lds = true;  // GANGFIT_FIFO_ZONED=generic forces the global-memory chain for the zone-aware packers
-    int fifo_waves = 16;       // wavefronts of the FIFO-chain workgroup (1, 4 or 16); GANGFIT_FIFO_WAVES overrides
+    int fifo_waves = 8;        // wavefronts of the block-cooperative FIFO-chain kernels (1, 4, 8 or 16; 8 measured best with the exact chunk index); GANGFIT_FIFO_WAVES overrides
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
     // zone views + efficiency tables (single-AZ packers, LIB/binpack/single_az.go; efficiency.go)
@@ -403,7 +403,13 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         plan.lds_slots_fused = front(gangfit::fifo_fused_lds_bytes(0, ctx->n_chunks), 24, block);
         plan.lds_slots_narrow = front(gangfit::fifo_narrow_lds_bytes(0, ctx->n_chunks), 12, block);
         plan.solo = ctx->fifo_solo;
-        plan.lds_slots_solo = front(gangfit::fifo_solo_lds_bytes(0, ctx->n_chunks), 12, 64);
+        {  // whole 64-slot chunk blocks (784 bytes each: three dimensions + the two candidate masks)
+            const size_t fixed = gangfit::fifo_solo_lds_bytes(0, ctx->n_chunks);
+            const size_t per_chunk = gangfit::fifo_solo_lds_bytes(64, ctx->n_chunks) - fixed;
+            const size_t fit = ctx->lds_budget > fixed ? (ctx->lds_budget - fixed) / per_chunk : 0;
+            const size_t whole = (ctx->n_slots + 63u) / 64u;
+            plan.lds_slots_solo = (uint32_t)((fit < whole ? fit : whole) * 64u);
+        }
         gangfit::NarrowTable nt{};
         if (plan.narrow) {
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));

@@ -1267,14 +1267,14 @@ size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
 }
 
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
-    const size_t nw = (n_chunks + 63u) / 64u;
-    size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nw +
+    const size_t nw = (n_chunks + 63u) / 64u, nwp = nw < 4 ? 4 : nw;
+    size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nwp +
                  8 * (size_t)n_chunks;
     off = (off + 15) & ~(size_t)15;
     off += sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 + 4 * kMaxShapes +
            4 * (size_t)n_chunks + 12 * (size_t)n_chunks;
     off = (off + 15) & ~(size_t)15;
-    return off + 12 * (size_t)lds_slots;
+    return off + (size_t)(lds_slots / 64u) * (kBlkDwords * 4u);  // lds_slots is a multiple of 64
 }
 
 namespace {

@@ -61,7 +61,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    """The in-tree library; GANGFIT_LIB points tuning experiments at another build of the same sources."""
+    return os.environ.get("GANGFIT_LIB") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:
