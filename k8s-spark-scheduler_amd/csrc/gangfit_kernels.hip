@@ -201,8 +201,16 @@ struct GlobalView {
     const uint64_t* dm;  // driver-candidate bits per chunk (merged layout)
     uint32_t n_chunks;
     // can ANY slot of chunk c offer r in every dimension?  false => capacity 0 / driver does not fit, for the whole chunk
+    __device__ __forceinline__ void chunk_maxima(uint32_t c, int64_t& m0, int64_t& m1, int64_t& m2) const {
+        m0 = cmax_cpu[c];
+        m1 = cmax_mem[c];
+        m2 = cmax_gpu[c];
+    }
     __device__ __forceinline__ bool chunk_may_hold(uint32_t c, int64_t r0, int64_t r1, int64_t r2) const {
-        return cmax_cpu[c] >= r0 && cmax_mem[c] >= r1 && cmax_gpu[c] >= r2;
+        // three loads in flight together: with && the second maximum is only requested after the first one has arrived
+        int64_t m0, m1, m2;
+        chunk_maxima(c, m0, m1, m2);
+        return (bool)((m0 >= r0) & (m1 >= r1) & (m2 >= r2));
     }
     __device__ __forceinline__ uint64_t chunk_xmask(uint32_t c) const { return xm[c]; }
     __device__ __forceinline__ uint64_t chunk_dmask(uint32_t c) const { return dm[c]; }
@@ -241,8 +249,16 @@ struct HybridView {
     lds_u64* xm;  // candidate bit masks, LDS copies
     lds_u64* dm;
     uint32_t n_chunks;
+    __device__ __forceinline__ void chunk_maxima(uint32_t c, int64_t& m0, int64_t& m1, int64_t& m2) const {
+        m0 = cmax_cpu[c];
+        m1 = cmax_mem[c];
+        m2 = cmax_gpu[c];
+    }
     __device__ __forceinline__ bool chunk_may_hold(uint32_t c, int64_t r0, int64_t r1, int64_t r2) const {
-        return cmax_cpu[c] >= r0 && cmax_mem[c] >= r1 && cmax_gpu[c] >= r2;
+        // three loads in flight together: with && the second maximum is only requested after the first one has arrived
+        int64_t m0, m1, m2;
+        chunk_maxima(c, m0, m1, m2);
+        return (bool)((m0 >= r0) & (m1 >= r1) & (m2 >= r2));
     }
     __device__ __forceinline__ uint64_t chunk_xmask(uint32_t c) const { return xm[c]; }
     __device__ __forceinline__ uint64_t chunk_dmask(uint32_t c) const { return dm[c]; }
@@ -283,6 +299,25 @@ struct HybridView {
         }
     }
 };
+
+// Slot j's values together with its candidate bit: the mask word and the three values are requested in ONE round trip
+// (testing the bit first costs a second, dependent miss per chunk on a cold L2).  The asm keeps the compiler from sinking
+// the value loads below the bit test again.
+#define GF_KEEP(x) asm volatile("" : "+v"(x))
+template <bool DRV, class View>
+__device__ __forceinline__ bool load_with_cand(const View& V, uint32_t j, uint32_t limit, int64_t& a0, int64_t& a1,
+                                               int64_t& a2) {
+    a0 = a1 = a2 = 0;
+    bool cand = false;
+    if (j < limit) {
+        V.load(j, a0, a1, a2);
+        cand = DRV ? V.dcand(j) : V.xcand(j);
+        GF_KEEP(a0);
+        GF_KEEP(a1);
+        GF_KEEP(a2);
+    }
+    return cand;
+}
 
 // Index tables that never change during a launch.
 struct Orders {
@@ -328,14 +363,25 @@ __device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t w
 // A cleared bit is a proof that every slot of the chunk has capacity 0 for an executor of size r (cap_dim: a < e -> 0;
 // reserving the driver only lowers a) resp. fails the driver-fit check for a driver of size r.
 // DRV selects which candidate mask must be non-empty (driver scan vs executor scan).
+// cand receives lane l's candidate word of chunk 64g + l (0 beyond the limit): read_lane(cand, b) is the mask of the chunk
+// whose bit b is set, so the scans need not load it again.  The maxima and the mask are requested together (one round trip).
+template <bool DRV, class View>
+__device__ __forceinline__ uint64_t chunk_group_mask(const View& V, uint32_t g, uint32_t chunk_limit, int64_t r0,
+                                                     int64_t r1, int64_t r2, int lane, uint64_t& cand) {
+    const uint32_t c = g * kWave + lane;
+    bool ok = false;
+    cand = 0;
+    if (c < chunk_limit) {
+        cand = DRV ? V.chunk_dmask(c) : V.chunk_xmask(c);
+        ok = V.chunk_may_hold(c, r0, r1, r2) & (cand != 0);
+    }
+    return __ballot(ok);
+}
 template <bool DRV, class View>
 __device__ __forceinline__ uint64_t chunk_group_mask(const View& V, uint32_t g, uint32_t chunk_limit, int64_t r0,
                                                      int64_t r1, int64_t r2, int lane) {
-    const uint32_t c = g * kWave + lane;
-    bool ok = false;
-    if (c < chunk_limit)
-        ok = V.chunk_may_hold(c, r0, r1, r2) && (DRV ? V.chunk_dmask(c) : V.chunk_xmask(c)) != 0;
-    return __ballot(ok);
+    uint64_t cand;
+    return chunk_group_mask<DRV>(V, g, chunk_limit, r0, r1, r2, lane, cand);
 }
 
 // First position p in [from, n_d) of driverNodePriorityOrder whose node passes the driver-fit check, else -1.
@@ -345,14 +391,17 @@ __device__ __forceinline__ int64_t wave_first_fitting_driver(const View& V, cons
     if (O.d_identity) {  // position == slot: prune whole chunks with the maxima index
         const uint32_t dc = (O.n_d + kWave - 1) / kWave;
         for (uint32_t g = (from / kWave) / kWave; g * kWave < dc; ++g) {
-            uint64_t m = chunk_group_mask<true>(V, g, dc, app.drv0, app.drv1, app.drv2, lane);
+            uint64_t cand;
+            uint64_t m = chunk_group_mask<true>(V, g, dc, app.drv0, app.drv1, app.drv2, lane, cand);
             visited += kWave;
             while (m) {
-                const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                const int bit = __ffsll((unsigned long long)m) - 1;
+                const uint32_t c = g * kWave + (uint32_t)bit;
                 m &= m - 1;
                 const uint32_t i = c * kWave + lane;
+                const uint64_t cdm = (uint64_t)read_lane((int64_t)cand, bit);
                 bool fit = false;
-                if (i < O.n_d && i >= from && V.dcand(i)) {
+                if (i < O.n_d && i >= from && ((cdm >> lane) & 1ull)) {
                     int64_t a0, a1, a2;
                     V.load(i, a0, a1, a2);
                     fit = driver_fits(a0, a1, a2, app);
@@ -410,27 +459,81 @@ __device__ __forceinline__ int64_t wave_next_feasible_driver(const View& V, cons
     return -1;
 }
 
+// Lane l's view of chunk l (group 0 of the chunk index) for both roles: the three maxima and the two candidate words.
+// Nothing here depends on the application, so the independent kernel requests it BEFORE its app record: the two misses
+// overlap instead of following each other.
+struct Group0 {
+    int64_t m0 = 0, m1 = 0, m2 = 0;
+    uint64_t dcand = 0, xcand = 0;
+    bool ind = false, inx = false;
+};
+template <class View>
+__device__ __forceinline__ Group0 load_group0(const View& V, const Orders& O, int lane) {
+    Group0 g;
+    const uint32_t dc = (O.n_d + kWave - 1) / kWave, xc = (O.n_x + kWave - 1) / kWave;
+    const uint32_t c = (uint32_t)lane;
+    g.ind = c < dc && c < V.n_chunks;  // general layout: driver positions may outnumber the slots
+    g.inx = c < xc && c < V.n_chunks;
+    if (g.ind | g.inx) {
+        V.chunk_maxima(c, g.m0, g.m1, g.m2);
+        if (g.ind) g.dcand = V.chunk_dmask(c);
+        if (g.inx) g.xcand = V.chunk_xmask(c);
+    }
+    return g;
+}
+
+// What wave_decide_merged already holds when the executor scan starts: the chunk mask of group 0 and the slots of the
+// first candidate chunk, requested together with the driver's (a decision is a chain of dependent global round trips —
+// every launch starts with cold L2s — so requests that do not depend on each other must be in flight together).
+struct ScanPre {
+    bool on = false;
+    uint64_t m = 0;     // group 0: chunks that may hold an executor
+    uint64_t cand = 0;  // lane l: executor-candidate word of chunk l
+    int c = -1;         // preloaded chunk, -1 = none
+    int64_t a0 = 0, a1 = 0, a2 = 0;
+    uint32_t node = 0;  // slot_node of this lane's slot in chunk c (SLOTS = false)
+};
+
 // tightlyPackExecutors with the driver reserved on slot ds.  Returns the sum of clamped capacities over the visited
 // prefix (>= K  <=>  feasible; the scan stops at the first chunk where K is reached).  Writes placements.
 // Only chunks the maxima index cannot rule out are loaded; a ruled-out chunk contributes exactly 0.
 template <class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& O, const App& app, uint32_t ds,
                                                    uint32_t* __restrict__ out, int lane,
-                                                   unsigned long long& visited) {
+                                                   unsigned long long& visited, const ScanPre& pre = ScanPre()) {
     const int64_t K = app.k;
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
     for (uint32_t g = 0; g * kWave < xc; ++g) {
-        uint64_t m = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+        uint64_t cand;
+        uint64_t m;
+        if (pre.on && g == 0) {
+            m = pre.m;
+            cand = pre.cand;
+        } else {
+            m = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane, cand);
+        }
         visited += kWave;
         while (m) {
-            const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+            const int bit = __ffsll((unsigned long long)m) - 1;
+            const uint32_t c = g * kWave + (uint32_t)bit;
             m &= m - 1;
             const uint32_t j = c * kWave + lane;
+            const uint64_t cxm = (uint64_t)read_lane((int64_t)cand, bit);
+            const bool have = pre.on && (int)c == pre.c;  // wave-uniform
             int32_t cp = 0;
-            if (j < O.n_x && V.xcand(j)) {
+            uint32_t node = 0;
+            if (j < O.n_x && ((cxm >> lane) & 1ull)) {
                 int64_t a0, a1, a2;
-                V.load(j, a0, a1, a2);
+                if (have) {
+                    a0 = pre.a0;
+                    a1 = pre.a1;
+                    a2 = pre.a2;
+                    node = pre.node;
+                } else {
+                    V.load(j, a0, a1, a2);
+                    if (!SLOTS) node = O.slot_node[j];  // requested with the slot, not after the capacities are known
+                }
                 if (j == ds) {
                     a0 -= app.drv0;
                     a1 -= app.drv1;
@@ -445,8 +548,7 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
                 const int64_t start = taken + (int64_t)(incl - cp);
                 const int64_t room = K - start;
                 const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
-                uint32_t id = j;
-                if (!SLOTS && t > 0) id = O.slot_node[j];
+                const uint32_t id = SLOTS ? j : node;
                 emit_runs(out, start, t, id, lane);
             }
             taken += tot;
@@ -462,22 +564,41 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
 template <class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_even_pass1(const View& V, const Orders& O, const App& app, uint32_t ds,
                                                    uint32_t* __restrict__ out, uint32_t* __restrict__ surv, int lane,
-                                                   unsigned long long& visited) {
+                                                   unsigned long long& visited, const ScanPre& pre = ScanPre()) {
     const int64_t K = app.k;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
     for (uint32_t g = 0; g * kWave < xc; ++g) {
-        uint64_t cm = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane);
+        uint64_t cand;
+        uint64_t cm;
+        if (pre.on && g == 0) {
+            cm = pre.m;
+            cand = pre.cand;
+        } else {
+            cm = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane, cand);
+        }
         visited += kWave;
         while (cm) {
-            const uint32_t c = g * kWave + (uint32_t)(__ffsll((unsigned long long)cm) - 1);
+            const int bit = __ffsll((unsigned long long)cm) - 1;
+            const uint32_t c = g * kWave + (uint32_t)bit;
             cm &= cm - 1;
             const uint32_t j = c * kWave + lane;
+            const uint64_t cxm = (uint64_t)read_lane((int64_t)cand, bit);
+            const bool have = pre.on && (int)c == pre.c;  // wave-uniform
             bool flag = false;
-            if (j < O.n_x && V.xcand(j)) {
+            uint32_t node = 0;
+            if (j < O.n_x && ((cxm >> lane) & 1ull)) {
                 int64_t a0, a1, a2;
-                V.load(j, a0, a1, a2);
+                if (have) {
+                    a0 = pre.a0;
+                    a1 = pre.a1;
+                    a2 = pre.a2;
+                    node = pre.node;
+                } else {
+                    V.load(j, a0, a1, a2);
+                    if (!SLOTS) node = O.slot_node[j];
+                }
                 if (j == ds) {
                     a0 -= app.drv0;
                     a1 -= app.drv1;
@@ -489,7 +610,7 @@ __device__ __forceinline__ int64_t wave_even_pass1(const View& V, const Orders& 
             const uint64_t m = __ballot(flag);
             const int64_t pos = taken + (int64_t)__popcll((unsigned long long)(m & lt_mask));
             if (flag && pos < K) {
-                out[pos] = SLOTS ? j : O.slot_node[j];
+                out[pos] = SLOTS ? j : node;
                 surv[pos] = j;
             }
             taken += (int64_t)__popcll((unsigned long long)m);
@@ -558,16 +679,17 @@ struct Decision {
     bool feasible;
     uint32_t ds;    // driver slot
     int64_t pass1;  // DistributeEvenly: number of pass-1 placements (= distinct executor nodes); TightlyPack: unused
+    uint32_t ds_node = GF_NO_NODE;  // slot_node[ds] when the decision already holds it (requested with the driver's chunk)
 };
 
 template <int ALGO, class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, const App& app, uint32_t ds,
                                              uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
                                              uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
-                                             unsigned long long& xvis) {
-    if (ALGO == GF_ALGO_TIGHTLY_PACK) return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis);
+                                             unsigned long long& xvis, const ScanPre& pre = ScanPre()) {
+    if (ALGO == GF_ALGO_TIGHTLY_PACK) return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre);
     if (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) return wave_minfrag<View, SLOTS>(V, O, app, ds, out, lane, xvis);
-    pass1 = wave_even_pass1<View, SLOTS>(V, O, app, ds, out, scratch_a, lane, xvis);
+    pass1 = wave_even_pass1<View, SLOTS>(V, O, app, ds, out, scratch_a, lane, xvis, pre);
     if (pass1 >= (int64_t)app.k) return pass1;
     return wave_even_general<View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, pass1, lane);
 }
@@ -608,24 +730,77 @@ template <int ALGO, class View, bool SLOTS>
 __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, const App& app,
                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
                                                 uint32_t* __restrict__ scratch_b, int lane, unsigned long long& xvis,
-                                                unsigned long long& dvis) {
+                                                unsigned long long& dvis, const Group0* g0p = nullptr) {
     Decision dec;
     dec.feasible = false;
     dec.ds = 0;
     dec.pass1 = 0;
     const int64_t K = app.k;
-    // (1) first driver candidate that passes the driver-fit check (binpack.go:67-71)
-    const int64_t p0 = wave_first_fitting_driver(V, O, app, 0, lane, dvis);
+    int64_t p0 = -1;
+    uint32_t p0_node = GF_NO_NODE;
+    ScanPre pre;
+    if (O.d_identity && ALGO != GF_ALGO_MINIMAL_FRAGMENTATION) {
+        // Merged layout (driver position == slot): the chunk masks of group 0 for BOTH roles in one round trip (the
+        // maxima are the same words), then the first candidate chunk of both roles — and the node ids — in one more.
+        const uint32_t dc = (O.n_d + kWave - 1) / kWave;
+        const Group0 g0 = g0p != nullptr ? *g0p : load_group0(V, O, lane);
+        const uint64_t dcand = g0.dcand;
+        pre.cand = g0.xcand;
+        const bool okd = g0.ind & (g0.m0 >= app.drv0) & (g0.m1 >= app.drv1) & (g0.m2 >= app.drv2) & (dcand != 0);
+        const bool okx = g0.inx & (g0.m0 >= app.exe0) & (g0.m1 >= app.exe1) & (g0.m2 >= app.exe2) & (pre.cand != 0);
+        const uint64_t md = __ballot(okd);
+        pre.m = __ballot(okx);
+        pre.on = true;
+        dvis += kWave;
+        const int bd = md ? __ffsll((unsigned long long)md) - 1 : -1;
+        pre.c = (K > 0 && pre.m) ? __ffsll((unsigned long long)pre.m) - 1 : -1;
+        const uint32_t limit = O.n_d > O.n_x ? O.n_d : O.n_x;
+        int64_t d0 = 0, d1 = 0, d2 = 0;
+        const uint32_t id = (uint32_t)(bd < 0 ? 0 : bd) * kWave + lane, ix = (uint32_t)(pre.c < 0 ? 0 : pre.c) * kWave + lane;
+        uint32_t dnode = GF_NO_NODE;
+        if (bd >= 0 && id < limit) {
+            V.load(id, d0, d1, d2);
+            if (!SLOTS) dnode = O.slot_node[id];  // the result needs the driver's node id: not one more round trip at the end
+        }
+        if (pre.c >= 0 && ix < limit) {
+            if (pre.c != bd) V.load(ix, pre.a0, pre.a1, pre.a2);
+            if (!SLOTS) pre.node = O.slot_node[ix];
+        }
+        if (pre.c >= 0 && pre.c == bd) {
+            pre.a0 = d0;
+            pre.a1 = d1;
+            pre.a2 = d2;
+        }
+        uint32_t from = dc > (uint32_t)kWave ? (uint32_t)kWave * kWave : O.n_d;  // where the generic search resumes
+        if (bd >= 0) {
+            const uint64_t cdm = (uint64_t)read_lane((int64_t)dcand, bd);
+            const bool fit = id < O.n_d && ((cdm >> lane) & 1ull) && driver_fits(d0, d1, d2, app);
+            dvis += chunk_len(O.n_d, (uint32_t)bd * kWave, kWave);
+            const uint64_t fm = __ballot(fit);
+            if (fm) {
+                const int fl = __ffsll((unsigned long long)fm) - 1;
+                p0 = (int64_t)bd * kWave + fl;
+                p0_node = read_lane(dnode, fl);
+            }
+            from = ((uint32_t)bd + 1) * kWave;
+        }
+        if (p0 < 0 && (bd >= 0 || dc > (uint32_t)kWave))  // a stale maximum, or candidates beyond group 0
+            p0 = wave_first_fitting_driver(V, O, app, from, lane, dvis);
+    } else {
+        // (1) first driver candidate that passes the driver-fit check (binpack.go:67-71)
+        p0 = wave_first_fitting_driver(V, O, app, 0, lane, dvis);
+    }
     if (p0 < 0) return dec;
     const uint32_t ds = O.driver_slot((uint32_t)p0);
     dec.ds = ds;
+    dec.ds_node = p0_node;
     if (K == 0) {  // pack_tightly.go:42-44 / distribute_evenly.go:46-48: nothing to place
         dec.feasible = true;
         return dec;
     }
     // (2) executors with the driver reserved on that candidate — the common case ends here
     int64_t pass1 = 0;
-    const int64_t S_d = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis);
+    const int64_t S_d = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis, pre);
     if (S_d >= K) {
         dec.feasible = true;
         dec.pass1 = pass1;
@@ -678,18 +853,24 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     if (a >= n_apps) return;
-    const App app = load_app(apps, a);
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
+    // every launch starts with cold L2s: the chunk index of group 0 and the app record are requested together
+    //      (unconditionally — a branch here would make the compiler wait for the loads at the join; the general layout
+    //      ignores the values, the buffers exist in both layouts)
+    const Group0 g0 = load_group0(V, O, lane);
+    const bool merged = T.d_identity != 0 && ALGO != GF_ALGO_MINIMAL_FRAGMENTATION;
+    const App app = load_app(apps, a);
     unsigned long long xvis = 0, dvis = 0;
-    const Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off,
-                                                              scratch + app.exec_off,
-                                                              scratch + scratch_half + app.exec_off, lane, xvis, dvis);
+    Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
+                                                        scratch + scratch_half + app.exec_off, lane, xvis, dvis,
+                                                        merged ? &g0 : nullptr);
     if (lane == 0) {
         gf_result r;
         r.has_capacity = dec.feasible ? 1 : 0;
-        r.driver_node = dec.feasible ? T.slot_node[dec.ds] : GF_NO_NODE;
+        if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
+        r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
         r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
         r.evaluated = 1;
         results[a] = r;
