@@ -1717,14 +1717,24 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
     const size_t lds = fifo_zoned_lds_bytes(lds_slots, table.n_chunks, zones.n_zones, n_shapes);
-    if (az_aware)
-        e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<true, 16>, 16, lds, stream, table, ntable, zones, d_sched,
-                                 lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
-                                 d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
-    else
-        e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<false, 16>, 16, lds, stream, table, ntable, zones, d_sched,
-                                 lds_slots, n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,
-                                 d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats);
+    // one wavefront per candidate view; the rest of the workgroup only helps with the prologue and shares every barrier and
+    // the per-app control flow, i.e. takes issue slots from the views' wavefronts: no more wavefronts than views need
+    const uint32_t n_cand = zones.n_zones + (az_aware ? 1u : 0u);
+    const int wg_waves = n_cand <= 4 ? 4 : (n_cand <= 8 ? 8 : 16);
+#define GF_ZL(AZ, NWV)                                                                                                      \
+    e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<AZ, NWV>, NWV, lds, stream, table, ntable, zones, d_sched, lds_slots, \
+                             n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,      \
+                             d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats)
+    if (az_aware) {
+        if (wg_waves == 4) GF_ZL(true, 4);
+        else if (wg_waves == 8) GF_ZL(true, 8);
+        else GF_ZL(true, 16);
+    } else {
+        if (wg_waves == 4) GF_ZL(false, 4);
+        else if (wg_waves == 8) GF_ZL(false, 8);
+        else GF_ZL(false, 16);
+    }
+#undef GF_ZL
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);
