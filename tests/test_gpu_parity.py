@@ -216,6 +216,49 @@ def test_fifo_chain_kernel_variants(algo, env):
         ctx.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_SOLO": "0"}], ids=["solo", "block-cooperative"])
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_fifo_chain_beyond_the_lds_front(algo, env):
+    """24 000 nodes: the table does not fit the LDS front (global tail) and a shape's index row has more than four words
+    (the words beyond the first four are read on demand) — against the closed-form oracle, nominal and congested."""
+    ctx = _ctx_with_env(env)
+    try:
+        for congested in (False, True):
+            w = wl.headline(24000, 400, congested=congested)
+            s = w.snapshot
+            ctx.set_snapshot(s.avail, s.sched)
+            ctx.set_orders(s.driver_order, s.exec_order)
+            apps = _gpu_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+            oapps = ob.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+            gpu = ctx.fit_batch(FIFO, algo, apps)
+            ref = ob.fit_fifo_chain(algo, s.avail, oapps, s.driver_order, s.exec_order, closed_form=True)
+            assert gpu.failed_at == ref.failed_at == -1
+            _assert_same(gpu, ref, apps)
+            assert np.array_equal(ctx.residual(), ref.avail_after)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n_apps", [1, 2, 31, 32, 33, 64, 65, 97])
+def test_fifo_chain_staging_boundaries(gf_ctx, n_apps):
+    """Chains whose length sits on the boundaries of the app-record staging (halves of 32 records)."""
+    rng = np.random.default_rng(900 + n_apps)
+    avail, D, X, drv, exe, k = _random_problem(rng, 700, n_apps, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 30).astype(np.int32)
+    k[:: 5] = 0  # driver-only applications in between
+    flags = np.ones(n_apps, dtype=np.uint32)
+    gf_ctx.set_snapshot(avail)
+    gf_ctx.set_orders(D, X)
+    for algo in (TIGHT, EVEN):
+        apps = _gpu_apps(drv, exe, k, flags)
+        gpu = gf_ctx.fit_batch(FIFO, algo, apps)
+        ref = ob.fit_fifo_chain(algo, avail, ob.make_apps(drv, exe, k, flags), D, X)
+        assert gpu.failed_at == ref.failed_at
+        _assert_same(gpu, ref, apps)
+        assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+
+
 @pytest.mark.parametrize("number", [1, 2])
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
 def test_baseline_configs_small(gf_ctx, number, algo):
