@@ -16,7 +16,7 @@ t_end = time.time() + budget
 n_cases = 0
 ctxs = {}
 for name, env in (("default", {}), ("generic", {"GANGFIT_FIFO_ZONED": "generic", "GANGFIT_FIFO_KERNEL": "v2"}),
-                  ("small-lds", {"GANGFIT_LDS_BUDGET": "50000"})):
+                  ("small-lds", {"GANGFIT_LDS_BUDGET": "50000"}), ("block-cooperative", {"GANGFIT_FIFO_SOLO": "0"})):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     ctxs[name] = gangfit.Context(0)
@@ -57,6 +57,9 @@ while time.time() < t_end:
         sched[:, 1] *= 1 << 20
         drv[:, 1] *= 1 << 20
         exe[:, 1] *= 1 << 20
+    if rng.random() < 0.5:  # a handful of templates: few distinct request shapes, runs of equal shapes (the indexed chains)
+        t = rng.integers(0, min(a, int(rng.integers(1, 8))), size=a)
+        drv, exe = drv[t], exe[t]
     kcap = int(rng.choice([5, 40, 300, 3000]))
     k = np.minimum(k, kcap).astype(np.int32)
     flags = (rng.random(a) < 0.85).astype(np.uint32)
