@@ -8,6 +8,8 @@ import torch
 import gangfit
 from gangfit import workloads as wl
 w = wl.headline(10000, 4000)
+if os.environ.get("K"):
+    w.k[:] = int(os.environ["K"])  # every gang the same size
 s = w.snapshot
 dev = torch.device("cuda:0")
 with gangfit.Context(0) as ctx:
