@@ -200,6 +200,7 @@ struct GlobalView {
     const uint64_t* xm;  // executor-candidate bits per chunk
     const uint64_t* dm;  // driver-candidate bits per chunk (merged layout)
     uint32_t n_chunks;
+    static constexpr bool kCompactScan = true;  // tightly-pack scans gather sparse chunks first (wave_tight_scan_compact)
     // can ANY slot of chunk c offer r in every dimension?  false => capacity 0 / driver does not fit, for the whole chunk
     __device__ __forceinline__ void chunk_maxima(uint32_t c, int64_t& m0, int64_t& m1, int64_t& m2) const {
         m0 = cmax_cpu[c];
@@ -482,6 +483,15 @@ __device__ __forceinline__ Group0 load_group0(const View& V, const Orders& O, in
     return g;
 }
 
+template <class View, class = void>
+struct HasCompactScan {
+    static constexpr bool value = false;
+};
+template <class View>
+struct HasCompactScan<View, decltype((void)View::kCompactScan)> {
+    static constexpr bool value = true;
+};
+
 // What wave_decide_merged already holds when the executor scan starts: the chunk mask of group 0 and the slots of the
 // first candidate chunk, requested together with the driver's (a decision is a chain of dependent global round trips —
 // every launch starts with cold L2s — so requests that do not depend on each other must be in flight together).
@@ -555,6 +565,119 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
             if (taken >= K) return taken;
         }
     }
+    return taken;
+}
+
+// tightlyPackExecutors for tables read from global memory, same result as wave_tight_scan.  A launch is as slow as its
+// slowest wavefront, and that is the gang whose executors sit on a few slots of many chunks (gpu executors on the headline
+// cluster: about six gpu nodes per 64-slot chunk with a device or two left, 7-20 chunks per gang).  A chunk visit costs
+// ~450 instructions whatever the number of slots that can hold an executor (exact int64 capacities, the DPP scan, the run
+// emission), so the slots that pass the cheap "holds at least one" test are first GATHERED, in slot order, into one
+// 64-lane batch (ds_permute: no LDS memory involved) and the expensive part runs once per batch instead of once per
+// chunk.  A chunk with many such slots is its own batch and is not moved.  The batch is processed as soon as it holds
+// K - taken slots (each is good for at least one executor, so the scan ends there — as lazy as the reference's loop up
+// to the chunk it stops in), when the next chunk does not fit in, and at the end of the candidates.
+template <class View, bool SLOTS>
+__device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const Orders& O, const App& app, uint32_t ds,
+                                                           uint32_t* __restrict__ out, int lane,
+                                                           unsigned long long& visited, const ScanPre& pre = ScanPre()) {
+    constexpr uint32_t kDenseLanes = 20;
+    const int64_t K = app.k;
+    const uint32_t xc = (O.n_x + kWave - 1) / kWave;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    int64_t taken = 0;
+    int64_t q0 = 0, q1 = 0, q2 = 0;  // the batch: table values (driver already reserved) and what a placement names
+    uint32_t qid = 0;
+    uint32_t fill = 0;  // lanes [0, fill) of the batch are occupied (wave-uniform)
+    // capacities, prefix, run emission for the lanes marked live; true when K is reached
+    auto process = [&](bool live, int64_t a0, int64_t a1, int64_t a2, uint32_t id) {
+        const int32_t cp = live ? cap3(a0, a1, a2, app) : 0;
+        const int32_t incl = wave_inclusive_scan(cp);
+        const int32_t tot = read_lane(incl, kWave - 1);
+        const int64_t start = taken + (int64_t)(incl - cp);
+        const int64_t room = K - start;
+        const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
+        emit_runs(out, start, t, id, lane);
+        taken += tot;
+        return taken >= K;
+    };
+    for (uint32_t g = 0; g * kWave < xc; ++g) {
+        uint64_t cand;
+        uint64_t m;
+        if (pre.on && g == 0) {
+            m = pre.m;
+            cand = pre.cand;
+        } else {
+            m = chunk_group_mask<false>(V, g, xc, app.exe0, app.exe1, app.exe2, lane, cand);
+        }
+        visited += kWave;
+        while (m) {
+            const int bit = __ffsll((unsigned long long)m) - 1;
+            const uint32_t c = g * kWave + (uint32_t)bit;
+            m &= m - 1;
+            const uint32_t j = c * kWave + lane;
+            const uint64_t cxm = (uint64_t)read_lane((int64_t)cand, bit);
+            const bool have = pre.on && (int)c == pre.c;  // wave-uniform
+            const bool in = j < O.n_x && ((cxm >> lane) & 1ull);
+            int64_t a0 = 0, a1 = 0, a2 = 0;
+            uint32_t node = 0;
+            if (in) {
+                if (have) {
+                    a0 = pre.a0;
+                    a1 = pre.a1;
+                    a2 = pre.a2;
+                    node = pre.node;
+                } else {
+                    V.load(j, a0, a1, a2);
+                    if (!SLOTS) node = O.slot_node[j];  // requested with the slot, not after the capacities are known
+                }
+                if (j == ds) {
+                    a0 -= app.drv0;
+                    a1 -= app.drv1;
+                    a2 -= app.drv2;
+                }
+            }
+            visited += chunk_len(O.n_x, c * kWave, kWave);
+            const bool fit = in && cap_ge1(a0, a1, a2, app);
+            const uint64_t fm = __ballot(fit);
+            const uint32_t n = (uint32_t)__popcll((unsigned long long)fm);
+            if (n == 0) continue;
+            const uint32_t id = SLOTS ? j : node;
+            if (fill + n > (uint32_t)kWave) {  // no room: the batch first (slot order is kept)
+                if (process((uint32_t)lane < fill, q0, q1, q2, qid)) return taken;
+                fill = 0;
+            }
+            if (fill == 0 && n > kDenseLanes) {  // a dense chunk is its own batch
+                if (process(fit, a0, a1, a2, id)) return taken;
+                continue;
+            }
+            // gather: the r-th fitting lane goes to lane fill + r; the other lanes take the remaining destinations so that
+            // the permutation is a bijection (every lane must take part in ds_permute), and what they send is ignored
+            const uint32_t rank = (uint32_t)__popcll((unsigned long long)(fm & lt_mask));
+            const uint32_t dest = fit ? fill + rank : ((fill + n + ((uint32_t)lane - rank)) & 63u);
+            const int addr = (int)(dest << 2);
+            const uint32_t r0l = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)a0);
+            const uint32_t r0h = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)((uint64_t)a0 >> 32));
+            const uint32_t r1l = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)a1);
+            const uint32_t r1h = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)((uint64_t)a1 >> 32));
+            const uint32_t r2l = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)a2);
+            const uint32_t r2h = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)(uint32_t)((uint64_t)a2 >> 32));
+            const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_permute(addr, (int)id);
+            const bool mine = (uint32_t)lane >= fill && (uint32_t)lane < fill + n;
+            if (mine) {
+                q0 = (int64_t)(((uint64_t)r0h << 32) | r0l);
+                q1 = (int64_t)(((uint64_t)r1h << 32) | r1l);
+                q2 = (int64_t)(((uint64_t)r2h << 32) | r2l);
+                qid = rid;
+            }
+            fill += n;
+            if (taken + (int64_t)fill >= K) {  // enough slots: each of them holds at least one executor
+                process((uint32_t)lane < fill, q0, q1, q2, qid);
+                return taken;
+            }
+        }
+    }
+    if (fill > 0) process((uint32_t)lane < fill, q0, q1, q2, qid);
     return taken;
 }
 
@@ -687,7 +810,12 @@ __device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, con
                                              uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
                                              uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
                                              unsigned long long& xvis, const ScanPre& pre = ScanPre()) {
-    if (ALGO == GF_ALGO_TIGHTLY_PACK) return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre);
+    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
+        if constexpr (HasCompactScan<View>::value)
+            return wave_tight_scan_compact<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre);
+        else
+            return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre);
+    }
     if (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) return wave_minfrag<View, SLOTS>(V, O, app, ds, out, lane, xvis);
     pass1 = wave_even_pass1<View, SLOTS>(V, O, app, ds, out, scratch_a, lane, xvis, pre);
     if (pass1 >= (int64_t)app.k) return pass1;
