@@ -17,5 +17,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -T -f csv -d "$OUT/pmc_fet
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -T -f csv -d "$OUT/pmc_write" -o pmc -- $BENCH --no-extras > "$OUT/pmc_write.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -T -f csv -d "$OUT/pmc_l2" -o pmc -- $BENCH --no-extras > "$OUT/pmc_l2.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -T -f csv -d "$OUT/pmc_sq" -o pmc -- $BENCH --no-extras > "$OUT/pmc_sq.log" 2>&1
+# the whole Filter through the C++ mirror of the reference's interface (three configurations; profiles/<tag>_host_filter.txt)
+if [ -x "$ROOT/k8s-spark-scheduler_amd/host_bench" ]; then
+  ( cd "$ROOT/k8s-spark-scheduler_amd" && timeout 100 ./host_bench 10000 1000 2000 tightly-pack; timeout 100 ./host_bench 10000 1000 2000 single-az-tightly-pack; timeout 200 ./host_bench 100000 1000 20000 tightly-pack ) > "$OUT/host_filter.txt" 2>&1
+fi
 find "$OUT" -name '*.csv' | head -40
 grep -h '^{' "$OUT"/*.log | head -5
