@@ -22,7 +22,12 @@
  *     to the Go function so that Filter semantics never change.
  *   - Thread safety: every gf_ctx entry point is serialised by a per-context mutex (Predicate and the
  *     UnschedulablePodMarker goroutine may call concurrently: cmd/server.go:230, internal/extender/unschedulablepods.go:77-91).
- *     The *_dev entry points are asynchronous on the given stream and must be externally ordered per context.
+ *     A SEQUENCE of calls that belongs together (gf_snapshot_set / gf_zones_set / gf_orders_set or gf_snapshot_build, then
+ *     a fit on that snapshot) is NOT atomic by itself: bracket it with gf_ctx_lock / gf_ctx_unlock (or an equivalent
+ *     mutex of the caller — the Go shim's Context.mu), otherwise another thread's snapshot can slip in between and the
+ *     fit still returns GF_OK.  The *_dev entry points are asynchronous on the given stream: their host side (buffer
+ *     growth, state flags) takes the context mutex, but the device work of two such calls on DIFFERENT streams is not
+ *     ordered by the library.
  */
 #ifndef GANGFIT_H
 #define GANGFIT_H
@@ -34,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GF_VERSION 120 /* 0.1.2 */
+#define GF_VERSION 200 /* 0.2.0 */
 
 /* ---- status codes ---- */
 #define GF_OK 0
@@ -105,6 +110,12 @@ int gf_version(void);
  * Replaces nothing in the reference; the shim calls it right after SelectBinpacker (cmd/server.go:145). */
 int gf_init(const int *device_ids, int n_dev, gf_ctx **out);
 void gf_destroy(gf_ctx *ctx);
+
+/* Sequence lock of a context: gf_ctx_lock blocks until no other caller holds it.  Unlike the internal per-call mutex it may
+ * be released from a different OS thread than the one that took it (a goroutine can migrate between two cgo calls).  Not
+ * re-entrant.  Every other entry point may be called with or without holding it. */
+void gf_ctx_lock(gf_ctx *ctx);
+void gf_ctx_unlock(gf_ctx *ctx);
 
 /* Message for the last failing call on this context (C-owned, valid until the next call on ctx). */
 const char *gf_last_error(gf_ctx *ctx);
@@ -212,6 +223,28 @@ int gf_packing_efficiencies(gf_ctx *ctx, gf_algo algo, const gf_app *app, const 
  *   node_out   n_req node indices, GF_NO_NODE = "not enough capacity to reschedule the executor" (failure-fit) */
 int gf_executor_fit(gf_ctx *ctx, int minimal_fragmentation, uint32_t n_req, const int64_t *exe, const int64_t *reserved,
                     const uint32_t *hosts_app, uint32_t *node_out);
+
+/* findNodes of the failover reconciler (internal/extender/failover.go:412-436; call site :368): reserve space for k
+ * executors of each of n_req stale applications by walking the executor order of gf_orders_set (the reconciler's
+ * orderedNodes) — tightly-pack with no driver, PARTIAL results (fewer than k nodes is not an error, :369-372), and the
+ * reference's over-add kept: the `reserved[n].Add(executorResources)` that fails the comparison is not taken back before
+ * the `break` (:424-427), so the returned `reserved` map holds (placed(n) + 1) x exe for every node that was filled up and
+ * placed(n) x exe for the node on which k was reached.
+ *   chained != 0  the requests run in order and each one's `reserved` map is subtracted from the working table before the
+ *                 next (`r.availableResources[instanceGroup].Sub(reservedResources)`, :159); gf_residual_get returns the
+ *                 table afterwards.  chained == 0: n_req independent calls against the snapshot.
+ *   exe           n_req x 3 executor requests (canonical units, >= 0); k: n_req counts in [0, GF_MAX_K]
+ *   results       per request: executors placed and the last node the loop reached (GF_NO_NODE if none).  The caller
+ *                 rebuilds `reserved` from them: every node of the order up to last_node gets (multiplicity in the
+ *                 placement list + 1) x exe, except last_node itself when placed == k (no over-add there).
+ *   exec_nodes    concatenated placements; request q owns [sum of k before q, + results[q].placed)
+ *   reserved_adds nullable, n_req x n_nodes: the `reserved` map in units of exe (0 = no entry) */
+typedef struct gf_find_result {
+    uint32_t placed;
+    uint32_t last_node;
+} gf_find_result; /* 8 bytes */
+int gf_find_nodes(gf_ctx *ctx, int chained, uint32_t n_req, const int64_t *exe, const int32_t *k, gf_find_result *results,
+                  uint32_t *exec_nodes, uint64_t exec_nodes_cap, uint32_t *reserved_adds);
 
 /* ---- node-range sharding of an INDEPENDENT batch across the GPUs of one box ----
  * One gf_ctx per GPU, each given the same snapshot and orders; gf_shard_set tells it which contiguous range of the

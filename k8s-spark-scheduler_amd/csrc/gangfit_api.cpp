@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
@@ -75,6 +76,9 @@ struct PinnedBuf {
 
 struct gf_ctx {
     std::recursive_mutex mu;  // recursive: gf_snapshot_build installs its result through the public setters
+    std::mutex seq_m;         // gf_ctx_lock / gf_ctx_unlock: a flag, not a held mutex, so any thread may release it
+    std::condition_variable seq_cv;
+    bool seq_held = false;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -152,6 +156,13 @@ struct gf_ctx {
     // single-executor requests (gf_executor_fit)
     DeviceBuf<int64_t> d_xexe, d_xreserved;
     DeviceBuf<uint32_t> d_xhosts, d_xout;
+
+    // findNodes requests (gf_find_nodes)
+    DeviceBuf<int32_t> d_fk;
+    DeviceBuf<uint64_t> d_foff;
+    DeviceBuf<gf_find_result> d_fres;
+    DeviceBuf<uint32_t> d_fadds;
+    PinnedBuf<uint64_t> h_foff;
 
     // batch buffers
     DeviceBuf<gf_app> d_apps;
@@ -536,6 +547,11 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_xreserved.release();
     ctx->d_xhosts.release();
     ctx->d_xout.release();
+    ctx->d_fk.release();
+    ctx->d_foff.release();
+    ctx->d_fres.release();
+    ctx->d_fadds.release();
+    ctx->h_foff.release();
     ctx->d_apps.release();
     ctx->d_results.release();
     ctx->d_exec.release();
@@ -552,6 +568,22 @@ void gf_destroy(gf_ctx* ctx) {
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+void gf_ctx_lock(gf_ctx* ctx) {
+    if (!ctx) return;
+    std::unique_lock<std::mutex> l(ctx->seq_m);
+    ctx->seq_cv.wait(l, [ctx] { return !ctx->seq_held; });
+    ctx->seq_held = true;
+}
+
+void gf_ctx_unlock(gf_ctx* ctx) {
+    if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> l(ctx->seq_m);
+        ctx->seq_held = false;
+    }
+    ctx->seq_cv.notify_one();
 }
 
 const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -1015,6 +1047,7 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
                      gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_chain_failed_at,
                      void* stream) {
     if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);  // launch() grows buffers and flips state flags
     if (n_apps > 0 && (!d_apps || !d_results)) return fail(ctx, GF_ERR_INVALID, "device apps/results must not be NULL");
     if (mode == GF_MODE_FIFO_CHAIN && !d_chain_failed_at) d_chain_failed_at = ctx->d_failed.ptr;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
@@ -1317,6 +1350,59 @@ int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, cons
                                              reserved ? ctx->d_xreserved.ptr : nullptr, n_req, ctx->d_xexe.ptr,
                                              with_hosts ? ctx->d_xhosts.ptr : nullptr, words, ctx->d_xout.ptr, st));
     GF_HIP(ctx, hipMemcpyAsync(node_out, ctx->d_xout.ptr, (size_t)n_req * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    return GF_OK;
+}
+
+int gf_find_nodes(gf_ctx* ctx, int chained, uint32_t n_req, const int64_t* exe, const int32_t* k, gf_find_result* results,
+                  uint32_t* exec_nodes, uint64_t exec_nodes_cap, uint32_t* reserved_adds) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (n_req == 0) return GF_OK;
+    if (!exe || !k || !results) return fail(ctx, GF_ERR_INVALID, "exe/k/results must not be NULL");
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede gf_find_nodes");
+    for (size_t i = 0; i < 3 * (size_t)n_req; ++i)
+        if (exe[i] < 0 || exe[i] >= GF_MAX_ABS_QUANTITY) return fail(ctx, GF_ERR_INVALID, "executor request outside [0, 2^62)");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, ctx->h_foff.reserve(n_req));
+    uint64_t total_k = 0;
+    for (uint32_t q = 0; q < n_req; ++q) {
+        if (k[q] < 0 || k[q] > GF_MAX_K) return fail(ctx, GF_ERR_INVALID, "k[%u] = %d outside [0, %d]", q, k[q], GF_MAX_K);
+        ctx->h_foff.ptr[q] = total_k;
+        total_k += (uint64_t)k[q];
+    }
+    if (total_k > exec_nodes_cap || (total_k > 0 && !exec_nodes))
+        return fail(ctx, GF_ERR_CAPACITY, "exec_nodes holds %llu entries, %llu needed", (unsigned long long)exec_nodes_cap,
+                    (unsigned long long)total_k);
+    const uint32_t n = ctx->n_nodes;
+    hipStream_t st = ctx->stream;
+    GF_HIP(ctx, ctx->d_xexe.reserve(3 * (size_t)n_req));
+    GF_HIP(ctx, ctx->d_fk.reserve(n_req));
+    GF_HIP(ctx, ctx->d_foff.reserve(n_req));
+    GF_HIP(ctx, ctx->d_fres.reserve(n_req));
+    GF_HIP(ctx, ctx->d_exec.reserve(total_k + 1));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_xexe.ptr, exe, 3 * (size_t)n_req * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_fk.ptr, k, (size_t)n_req * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_foff.ptr, ctx->h_foff.ptr, (size_t)n_req * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    uint32_t* d_adds = nullptr;
+    if (reserved_adds && n > 0) {
+        GF_HIP(ctx, ctx->d_fadds.reserve((size_t)n_req * n));
+        GF_HIP(ctx, hipMemsetAsync(ctx->d_fadds.ptr, 0, (size_t)n_req * n * sizeof(uint32_t), st));
+        d_adds = ctx->d_fadds.ptr;
+    }
+    if (chained) {  // every reconcile starts from the snapshot (availableResourcesPerInstanceGroup, failover.go:286-322)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                   hipMemcpyDeviceToDevice, st));
+        ctx->work_valid = true;
+    }
+    GF_HIP(ctx, gangfit::launch_find_nodes(chained != 0, make_table(ctx, chained ? ctx->d_work.ptr : ctx->d_snap.ptr), n_req,
+                                           ctx->d_xexe.ptr, ctx->d_fk.ptr, ctx->d_foff.ptr, ctx->d_fres.ptr, ctx->d_exec.ptr,
+                                           d_adds, st));
+    GF_HIP(ctx, hipMemcpyAsync(results, ctx->d_fres.ptr, (size_t)n_req * sizeof(gf_find_result), hipMemcpyDeviceToHost, st));
+    if (total_k)
+        GF_HIP(ctx, hipMemcpyAsync(exec_nodes, ctx->d_exec.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (d_adds)
+        GF_HIP(ctx, hipMemcpyAsync(reserved_adds, d_adds, (size_t)n_req * n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     GF_HIP(ctx, hipStreamSynchronize(st));
     return GF_OK;
 }

@@ -219,6 +219,13 @@ hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& tabl
                                const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
                                hipStream_t stream);
 
+// findNodes of the failover reconciler (gangfit_findnodes.inc): n_req requests against the executor order; chained = one
+// wavefront walks them in order on `table` (the mutable working copy) and subtracts each request's `reserved` map.
+// d_adds_out: n_req x n_nodes (zeroed by the caller) or nullptr.
+hipError_t launch_find_nodes(bool chained, const NodeTable& table, uint32_t n_req, const int64_t* d_exe, const int32_t* d_k,
+                             const uint64_t* d_exec_off, gf_find_result* d_results, uint32_t* d_exec_nodes,
+                             uint32_t* d_adds_out, hipStream_t stream);
+
 // Snapshot construction on the device (gangfit_snapshot.hip): reservation replay, available / schedulable columns,
 // zone order, node priority order.  All pointers are device buffers owned by the host layer; columns are SoA
 // (cpu | memory | gpu, n_nodes each).  On return (stream order) d_avail / d_sched hold the columns and d_perm_b the

@@ -1476,6 +1476,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
 #include "gangfit_fifo_minfrag.inc"
 #include "gangfit_shard.inc"
 #include "gangfit_executor.inc"
+#include "gangfit_findnodes.inc"
 
 // ------------------------------------------------------------------------------------------------ self-test
 
@@ -2007,6 +2008,19 @@ hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& tabl
     else
         hipLaunchKernelGGL(executor_fit_kernel<false>, app_grid(n_req), block, 0, stream, table, d_reserved, n_req, d_exe,
                            d_hosts, hosts_stride, d_node_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_find_nodes(bool chained, const NodeTable& table, uint32_t n_req, const int64_t* d_exe, const int32_t* d_k,
+                             const uint64_t* d_exec_off, gf_find_result* d_results, uint32_t* d_exec_nodes,
+                             uint32_t* d_adds_out, hipStream_t stream) {
+    if (n_req == 0) return hipSuccess;
+    if (chained)
+        hipLaunchKernelGGL(find_nodes_kernel<true>, dim3(1), dim3(kWave * kWavesPerBlock), 0, stream, table, n_req, d_exe, d_k,
+                           d_exec_off, d_results, d_exec_nodes, d_adds_out);
+    else
+        hipLaunchKernelGGL(find_nodes_kernel<false>, app_grid(n_req), dim3(kWave * kWavesPerBlock), 0, stream, table, n_req,
+                           d_exe, d_k, d_exec_off, d_results, d_exec_nodes, d_adds_out);
     return hipGetLastError();
 }
 

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = [
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats",
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
     "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
+    "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock",
 ]
 
 
@@ -115,6 +116,12 @@ def load() -> C.CDLL:
     L.gf_snapshot_get.argtypes = [p, p, p]
     L.gf_executor_fit.restype = i32
     L.gf_executor_fit.argtypes = [p, i32, u32, p, p, p, p]
+    L.gf_ctx_lock.restype = None
+    L.gf_ctx_lock.argtypes = [p]
+    L.gf_ctx_unlock.restype = None
+    L.gf_ctx_unlock.argtypes = [p]
+    L.gf_find_nodes.restype = i32
+    L.gf_find_nodes.argtypes = [p, i32, u32, p, p, p, p, u64, p]
     L.gf_shard_set.restype = i32
     L.gf_shard_set.argtypes = [p, u32, u32]
     L.gf_shard_partials_dev.restype = i32

@@ -59,7 +59,7 @@ def build_host(force: bool = False) -> str:
         subprocess.check_call(cmd)
     test_src = os.path.join(host_dir, "tests", "host_test.cpp")
     if os.path.exists(test_src) and (force or _stale(HOST_TEST_PATH, [test_src, HOST_LIB_PATH] + hdrs)):
-        cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-I", INCLUDE, "-I", host_dir, test_src, "-L", _PKG_ROOT,
+        cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-I", INCLUDE, "-I", host_dir, test_src, "-L", _PKG_ROOT,
                "-lgangfit_host", "-lgangfit", "-Wl,-rpath,$ORIGIN", "-o", HOST_TEST_PATH]
         subprocess.check_call(cmd)
     bench_src = os.path.join(host_dir, "tests", "host_bench.cpp")

@@ -203,6 +203,24 @@ class Context:
                                               N.ptr(bits), N.ptr(out)))
         return out
 
+    def find_nodes(self, exe, k, chained: bool = True, want_adds: bool = True):
+        """findNodes (failover.go:412-436) for n_req requests.  Returns (placed, last_node, exec_off, exec_nodes, adds):
+        placed / last_node per request, the concatenated partial placements, and the `reserved` map in units of exe."""
+        exe = np.ascontiguousarray(exe, dtype=np.int64).reshape(-1, 3)
+        k = np.ascontiguousarray(k, dtype=np.int32).reshape(-1)
+        assert len(exe) == len(k)
+        kk = np.clip(k.astype(np.int64), 0, None)
+        off = np.zeros(len(k), dtype=np.uint64)
+        if len(k) > 1:
+            off[1:] = np.cumsum(kk[:-1]).astype(np.uint64)
+        total = int(kk.sum())
+        res = np.zeros((len(k), 2), dtype=np.uint32)
+        out = np.zeros(total + 1, dtype=np.uint32)
+        adds = np.zeros((len(k), self.n_nodes), dtype=np.uint32) if want_adds else None
+        self._check(self._lib.gf_find_nodes(self._h, int(chained), len(k), N.ptr(exe), N.ptr(k), N.ptr(res), N.ptr(out), total,
+                                            N.ptr(adds)))
+        return res[:, 0].copy(), res[:, 1].copy(), off, out[:total], adds
+
     def residual(self) -> np.ndarray:
         out = np.zeros((self.n_nodes, 3), dtype=np.int64)
         self._check(self._lib.gf_residual_get(self._h, N.ptr(out)))

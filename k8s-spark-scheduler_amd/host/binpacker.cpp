@@ -84,6 +84,7 @@ PackingResult Binpacker::BinpackFunc(const Resources& driverResources, const Res
     FlatSnapshot snap;
     std::string err;
     if (!flatten(metadata, driverNodePriorityOrder, executorNodePriorityOrder, &snap, &err)) return not_served(err);
+    CtxSequence seq(ctx);  // snapshot + decision (+ efficiencies) are one sequence on the shared context
     if (!upload(ctx, snap, &err)) return not_served(err);
     gf_result res{};
     std::vector<uint32_t> exec((size_t)executorCount + 1);

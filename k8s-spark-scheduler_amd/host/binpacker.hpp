@@ -47,6 +47,16 @@ bool flatten(const NodeGroupSchedulingMetadata& metadata, const std::vector<std:
              const std::vector<std::string>& executorOrder, FlatSnapshot* out, std::string* err);
 bool upload(gf_ctx* ctx, const FlatSnapshot& snap, std::string* err);
 
+// Holds the context's sequence lock (gf_ctx_lock) for one "install a snapshot, then decide on it" sequence: Predicate and
+// the UnschedulablePodMarker call from different threads (cmd/server.go:230) and must not see each other's snapshot.
+struct CtxSequence {
+    explicit CtxSequence(gf_ctx* c) : ctx(c) { gf_ctx_lock(ctx); }
+    ~CtxSequence() { gf_ctx_unlock(ctx); }
+    CtxSequence(const CtxSequence&) = delete;
+    CtxSequence& operator=(const CtxSequence&) = delete;
+    gf_ctx* ctx;
+};
+
 struct Binpacker {
     std::string Name;
     gf_algo Algo;

@@ -85,6 +85,7 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNode(const std::string& ins
     cur.k = resources->MinExecutorCount;
     apps.push_back(cur);
     FlatSnapshot snap;
+    CtxSequence seq(binpacker_.ctx);
     if (!flatten(metadata, driverNodeNames, executorNodeNames, &snap, &err) || !upload(binpacker_.ctx, snap, &err)) {
         out.served = false;
         out.error = err;
@@ -148,6 +149,7 @@ SelectNodeResult SparkSchedulerExtender::rescheduleExecutor(const Pod& driver, c
     auto [driverOrder, executorNodeNames] = sorter_.PotentialNodes(metadata, nodeNames);
     (void)driverOrder;
     FlatSnapshot snap;
+    CtxSequence seq(binpacker_.ctx);
     if (!flatten(metadata, {}, executorNodeNames, &snap, &err) || !upload(binpacker_.ctx, snap, &err)) {
         out.served = false;
         out.error = err;
@@ -259,6 +261,7 @@ std::vector<std::pair<std::string, bool>> SparkSchedulerExtender::scanForUnsched
     for (const Node& n : availableNodes) names.push_back(n.Name);
     FlatSnapshot snap;
     std::string e;
+    CtxSequence seq(binpacker_.ctx);
     if (!flatten(metadata, names, names, &snap, &e) || !upload(binpacker_.ctx, snap, &e)) {
         if (served) *served = false;
         if (err) *err = e;
@@ -430,6 +433,7 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
     apps.push_back(cur);
     // ---- snapshot + orders on the device, then the chain
     gf_ctx* ctx = binpacker_.ctx;
+    CtxSequence seq(ctx);
     if (gf_snapshot_build(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(),
                           overhead.empty() ? nullptr : over[0].data(), overhead.empty() ? nullptr : over[1].data(),
                           overhead.empty() ? nullptr : over[2].data(), (uint32_t)rnode.size(), rnode.data(), rreq[0].data(),

@@ -4,16 +4,20 @@
 //   TestAZAwareNodeSorting(+IfZoneLabelIsMissing), TestLabelPrioritySorting   internal/sort/nodesorting_test.go:27-250
 //   TestScheduler, TestUnschedulablePodMarker, TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs
 //                                                               internal/extender/resource_test.go:27-71, unschedulablepods_test.go:24-80
+//   findNodes (no reference test exists: checked against the literal loop of failover.go:412-436 on the host types)
 // `host_test cpu` needs no GPU (parsing, sorting, snapshot, reservations); `host_test gpu` drives the device through
 // the C ABI exactly like the Go shim would.  Exit code 0 = all passed.
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
 #include <set>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "extender.hpp"
+#include "failover.hpp"
 
 using namespace gangfit::host;
 
@@ -632,6 +636,132 @@ static void TestDeviceSnapshotBuildAgainstHostMirror() {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ failover: findNodes
+// The loop of internal/extender/failover.go:412-436 on the host mirror's own types (Quantity arithmetic, string-keyed maps):
+// what the device-backed findNodes must reproduce, over-add included.
+static std::pair<std::vector<std::string>, NodeGroupResources> literalFindNodes(int executorCount, const Resources& executorResources,
+                                                                                 const NodeGroupResources& availableResources,
+                                                                                 const std::vector<Node>& orderedNodes) {
+    std::vector<std::string> executorNodeNames;
+    NodeGroupResources reserved;
+    for (const Node& n : orderedNodes) {
+        if (!reserved.count(n.Name)) reserved[n.Name] = Resources::Zero();
+        for (;;) {
+            reserved[n.Name].Add(executorResources);
+            if (reserved[n.Name].GreaterThan(availableResources.at(n.Name))) break;
+            executorNodeNames.push_back(n.Name);
+            if ((int)executorNodeNames.size() == executorCount) return {executorNodeNames, reserved};
+        }
+    }
+    return {executorNodeNames, reserved};
+}
+
+static bool sameReserved(const NodeGroupResources& a, const NodeGroupResources& b) {
+    if (a.size() != b.size()) return false;
+    for (const auto& [k, v] : a) {
+        auto it = b.find(k);
+        if (it == b.end() || !it->second.Eq(v)) return false;
+    }
+    return true;
+}
+
+static void TestFindNodes() {
+    std::vector<Node> ordered;
+    NodeGroupResources available;
+    const int64_t cpu[] = {4, 0, 9, 2, 16, 1, 7};
+    const int64_t memGi[] = {8, 4, 2, 64, 16, 1, 7};
+    const int64_t gpu[] = {0, 0, 1, 0, 2, 0, 0};
+    for (int i = 0; i < 7; ++i) {
+        Node n;
+        n.Name = "node-" + std::to_string(i);
+        n.Ready = true;
+        ordered.push_back(n);
+        available[n.Name] = Resources::Create(cpu[i], memGi[i] * Gi, gpu[i]);
+    }
+    available["node-5"].CPU.Sub(Quantity::FromInt(3));  // an overcommitted node: the first add already exceeds
+    struct Rq {
+        int count;
+        Resources exe;
+    };
+    const Rq rqs[] = {{5, Resources::Create(1, 2 * Gi, 0)},  {40, Resources::Create(2, 1 * Gi, 0)}, {2, Resources::Create(1, 1 * Gi, 1)},
+                      {3, Resources::Create(32, 1 * Gi, 0)}, {4, Resources::Create(0, 0, 0)},        {1, Resources::Create(4, 8 * Gi, 0)}};
+    for (const Rq& rq : rqs) {
+        auto want = literalFindNodes(rq.count, rq.exe, available, ordered);
+        FindNodesResult got = findNodes(g_ctx, rq.count, rq.exe, available, ordered);
+        CHECK(got.served);
+        CHECK(got.executorNodeNames == want.first);
+        CHECK(sameReserved(got.reserved, want.second));
+    }
+    // the reconcile loop over several stale applications: each sees availableResources after the previous `Sub` (:159)
+    std::vector<FindNodesRequest> chain;
+    for (const Rq& rq : rqs) chain.push_back({rq.count, rq.exe});
+    NodeGroupResources avail_dev = available, avail_ref = available;
+    std::vector<FindNodesResult> got = findNodesForStaleApplications(g_ctx, chain, &avail_dev, ordered);
+    for (size_t q = 0; q < chain.size(); ++q) {
+        auto want = literalFindNodes(chain[q].executorCount, chain[q].executorResources, avail_ref, ordered);
+        for (const auto& [node, r] : want.second) avail_ref[node].Sub(r);
+        CHECK(got[q].served);
+        CHECK(got[q].executorNodeNames == want.first);
+        CHECK(sameReserved(got[q].reserved, want.second));
+    }
+    CHECK(sameReserved(avail_dev, avail_ref));
+    // a quantity the canonical units cannot hold exactly must be refused, not rounded
+    Resources odd = Resources::Create(1, 1 * Gi, 0);
+    odd.CPU = Quantity::FromNano(1500);  // 1.5 micro-cores
+    CHECK(!findNodes(g_ctx, 1, odd, available, ordered).served);
+}
+
+// ------------------------------------------------------------------------------------------------ two threads, one context
+// cmd/server.go:230 starts the UnschedulablePodMarker next to the HTTP server: Predicate (a FIFO Filter) and the marker's
+// scan (an independent batch on a DIFFERENT snapshot: the empty cluster) reach the binpacker concurrently.  Both go through
+// one gf_ctx here; every answer must equal the single-threaded one.
+static void TestTwoThreadsOneContext() {
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone1");
+    auto filter = NewTestExtender("tightly-pack", {node1, node2});
+    Pod first = Driver("first", StaticAnnotations(6), 1), second = Driver("second", StaticAnnotations(8), 2);
+    filter.pods = {first, second};
+    std::vector<Node> big;
+    for (int i = 0; i < 150; ++i) big.push_back(NewNode(("big-" + std::to_string(i)).c_str(), i % 3 == 0 ? "zone1" : "zone2"));
+    auto marker = NewTestExtender("tightly-pack", big);
+    marker.nowNanos = 10000ll * 1000000000;
+    std::vector<Pod> pending;
+    for (int i = 0; i < 40; ++i) pending.push_back(Driver(("app-" + std::to_string(i)).c_str(), StaticAnnotations(1 + 37 * i), 1 + i));
+    bool served = true;
+    std::string err;
+    const SelectNodeResult want_filter = filter.selectDriverNode("batch-medium-priority", second, {"node1", "node2"}, filter.nodes);
+    const auto want_scan = marker.scanForUnschedulablePods(pending, 600ll * 1000000000, marker.nodes, {}, &served, &err);
+    CHECK(want_filter.served && want_filter.outcome == std::string(outcome::success));
+    CHECK(served && want_scan.size() == pending.size());
+    int n_exceed = 0;
+    for (const auto& kv : want_scan) n_exceed += kv.second ? 1 : 0;
+    CHECK(n_exceed > 0 && n_exceed < (int)want_scan.size());  // both answers occur: 150 nodes x 8 cpu hold 1 + 37 i up to i = 32
+    std::atomic<int> bad_filter{0}, bad_scan{0};
+    const int iters = 200;
+    std::thread t1([&] {
+        for (int i = 0; i < iters; ++i) {
+            SelectNodeResult r = filter.selectDriverNode("batch-medium-priority", second, {"node1", "node2"}, filter.nodes);
+            bool same = r.served && r.outcome == want_filter.outcome && r.node == want_filter.node && r.created.has_value();
+            if (same)
+                for (const auto& [name, res] : want_filter.created->Reservations)
+                    same = same && r.created->Reservations.count(name) && r.created->Reservations.at(name).Node == res.Node;
+            if (!same) ++bad_filter;
+        }
+    });
+    std::thread t2([&] {
+        for (int i = 0; i < iters; ++i) {
+            bool sv = true;
+            std::string e;
+            auto r = marker.scanForUnschedulablePods(pending, 600ll * 1000000000, marker.nodes, {}, &sv, &e);
+            if (!sv || r != want_scan) ++bad_scan;
+        }
+    });
+    t1.join();
+    t2.join();
+    CHECK(bad_filter.load() == 0);
+    CHECK(bad_scan.load() == 0);
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu" || mode == "all") {
@@ -658,6 +788,8 @@ int main(int argc, char** argv) {
         TestFifoAndBinpackers();
         TestMinimalFragmentationEdgeCase();
         TestDeviceSnapshotBuildAgainstHostMirror();
+        TestFindNodes();
+        TestTwoThreadsOneContext();
         gf_destroy(g_ctx);
     }
     std::printf("%s: %d checks, %d failed\n", mode.c_str(), g_checked, g_failed);

@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
         L.go_executor_first_fit_reserved.argtypes = [p, C.c_uint32, p, p, p, C.c_uint32]
         L.go_executor_min_frag.restype = C.c_uint32
         L.go_executor_min_frag.argtypes = [p, C.c_uint32, p, p, p, C.c_uint32, p]
+        L.go_find_nodes_chain.restype = None
+        L.go_find_nodes_chain.argtypes = [C.c_int, p, C.c_uint32, p, p, C.c_uint32, p, C.c_uint32, p, p, p, p]
         _lib = L
     return _lib
 
@@ -231,3 +233,39 @@ def executor_fit(avail, exe, exec_order, reserved=None, minimal_fragmentation=Fa
         h = None if hosts is None else np.ascontiguousarray(hosts, dtype=np.uint8)
         return int(lib().go_executor_min_frag(_ptr(avail), len(avail), _ptr(r), _ptr(e), _ptr(x), len(x), _ptr(h)))
     return int(lib().go_executor_first_fit_reserved(_ptr(avail), len(avail), _ptr(r), _ptr(e), _ptr(x), len(x)))
+
+
+@dataclass
+class FindNodesOut:
+    placed: np.ndarray      # uint32 per request: executors that found a node (<= k)
+    exec_off: np.ndarray    # uint64
+    exec_nodes: np.ndarray  # uint32, concatenated; request q owns [exec_off[q], exec_off[q] + placed[q])
+    adds: np.ndarray        # (n_req, n_nodes) uint32: `reserved[n].Add(exe)` calls = the returned map in units of exe
+    avail_after: np.ndarray
+
+    def placement(self, q: int) -> np.ndarray:
+        o = int(self.exec_off[q])
+        return self.exec_nodes[o:o + int(self.placed[q])]
+
+
+def find_nodes(avail, exe, k, ordered_nodes, closed_form: bool = False, chained: bool = True) -> FindNodesOut:
+    """findNodes (failover.go:412-436) for n_req requests; chained = each request's `reserved` map (over-adds included) is
+    subtracted from availableResources before the next one (failover.go:159), else every request sees the same table."""
+    avail = np.ascontiguousarray(avail, dtype=np.int64).reshape(-1, 3).copy()
+    exe = np.ascontiguousarray(exe, dtype=np.int64).reshape(-1, 3)
+    k = np.ascontiguousarray(k, dtype=np.int32).reshape(-1)
+    o = np.ascontiguousarray(ordered_nodes, dtype=np.uint32)
+    off = exec_offsets(np.maximum(k, 0))
+    out = np.zeros(int(np.maximum(k, 0).astype(np.int64).sum()) + 1, dtype=np.uint32)
+    placed = np.zeros(len(k), dtype=np.uint32)
+    adds = np.zeros((len(k), len(avail)), dtype=np.uint32)
+    if chained:
+        lib().go_find_nodes_chain(int(closed_form), _ptr(avail), len(avail), _ptr(exe), _ptr(k), len(k), _ptr(o), len(o),
+                                  _ptr(placed), _ptr(off), _ptr(out), _ptr(adds))
+    else:
+        for q in range(len(k)):
+            a = avail.copy()
+            lib().go_find_nodes_chain(int(closed_form), _ptr(a), len(a), _ptr(exe[q:q + 1]), _ptr(k[q:q + 1]), 1, _ptr(o),
+                                      len(o), _ptr(placed[q:q + 1]), _ptr(np.zeros(1, dtype=np.uint64)),
+                                      _ptr(out[int(off[q]):]), _ptr(adds[q:q + 1]))
+    return FindNodesOut(placed, off, out[:-1], adds, avail)

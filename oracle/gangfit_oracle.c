@@ -818,3 +818,82 @@ uint32_t go_executor_first_fit_reserved(const int64_t *avail, uint32_t n_nodes, 
     }
     return GO_NO_NODE;
 }
+
+/* ---------------------------------------------------------------- failover reconcile: findNodes */
+
+/* findNodes, internal/extender/failover.go:412-436, literal: tightly-pack with PARTIAL results and no driver.  Every
+ * visited node gets an entry in `reserved` (:419-421); the add that fails the comparison is NOT taken back before the
+ * `break` (:424-428), so a node that was filled up ends with (placed + 1) x executorResources in the map, while the node on
+ * which the count is reached returns at once (:430-432) and keeps exactly what was placed.  adds_out[n] = number of
+ * `reserved[n].Add(executorResources)` calls (0 = no entry).  availableResources[n.Name] exists for every ordered node
+ * (both derive from schedulableNodes, failover.go:286-322); an index >= n_nodes is skipped defensively.
+ * executor_count <= 0 never happens (guarded at :367); it is treated as "nothing to do". */
+uint32_t go_find_nodes(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t executor_count,
+                       const uint32_t *ordered_nodes, uint32_t n_o, uint32_t *exec_out, uint32_t *adds_out) {
+    uint32_t placed = 0;
+    if (adds_out) memset(adds_out, 0, (size_t)n_nodes * sizeof(uint32_t));
+    if (executor_count <= 0) return 0;
+    for (uint32_t i = 0; i < n_o; ++i) {
+        uint32_t n = ordered_nodes[i];
+        if (n >= n_nodes) continue;
+        int64_t reserved[3] = {0, 0, 0}; /* :419-421 (orderedNodes holds each node once) */
+        uint32_t adds = 0;
+        for (;;) {
+            res_add(reserved, exe); /* :424 */
+            ++adds;
+            if (res_greater_than(reserved, &avail[3 * n])) break; /* :425-427 */
+            exec_out[placed++] = n;                               /* :428 */
+            if (placed == (uint32_t)executor_count) {             /* :429-431 */
+                if (adds_out) adds_out[n] += adds;
+                return placed;
+            }
+        }
+        if (adds_out) adds_out[n] += adds;
+    }
+    return placed;
+}
+
+/* The same through capacities (cross-check): cap(n) = min over dims floor(avail / exe), 0 when any avail < 0. */
+uint32_t go_find_nodes_closed_form(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t executor_count,
+                                   const uint32_t *ordered_nodes, uint32_t n_o, uint32_t *exec_out, uint32_t *adds_out) {
+    static const int64_t zero[3] = {0, 0, 0};
+    uint32_t placed = 0;
+    if (adds_out) memset(adds_out, 0, (size_t)n_nodes * sizeof(uint32_t));
+    if (executor_count <= 0) return 0;
+    for (uint32_t i = 0; i < n_o; ++i) {
+        uint32_t n = ordered_nodes[i];
+        if (n >= n_nodes) continue;
+        int64_t left = (int64_t)executor_count - placed;
+        int64_t cap = cap_clamped(&avail[3 * n], zero, exe, left);
+        for (int64_t t = 0; t < cap; ++t) exec_out[placed++] = n;
+        if (cap == left) {
+            if (adds_out) adds_out[n] += (uint32_t)cap;
+            return placed;
+        }
+        if (adds_out) adds_out[n] += (uint32_t)cap + 1;
+    }
+    return placed;
+}
+
+/* The reconcile loop over stale applications of ONE instance group (failover.go:132-160): each request runs findNodes
+ * against the current availableResources, then `r.availableResources[instanceGroup].Sub(reservedResources)` (:159)
+ * subtracts the map findNodes returned — over-adds included.  avail is mutated; exec_out is the concatenation (request q
+ * at exec_off[q], room for k[q]); adds_out (nullable) n_req x n_nodes. */
+void go_find_nodes_chain(int closed_form, int64_t *avail, uint32_t n_nodes, const int64_t *exe, const int32_t *k,
+                         uint32_t n_req, const uint32_t *ordered_nodes, uint32_t n_o, uint32_t *placed_out,
+                         const uint64_t *exec_off, uint32_t *exec_out, uint32_t *adds_out) {
+    uint32_t *adds = (uint32_t *)malloc(((size_t)n_nodes + 1) * sizeof(uint32_t));
+    if (!adds) return;
+    for (uint32_t q = 0; q < n_req; ++q) {
+        const int64_t *e = &exe[3 * (size_t)q];
+        placed_out[q] = closed_form
+                            ? go_find_nodes_closed_form(avail, n_nodes, e, k[q], ordered_nodes, n_o, exec_out + exec_off[q], adds)
+                            : go_find_nodes(avail, n_nodes, e, k[q], ordered_nodes, n_o, exec_out + exec_off[q], adds);
+        for (uint32_t n = 0; n < n_nodes; ++n) {
+            if (!adds[n]) continue;
+            for (int j = 0; j < 3; ++j) avail[3 * (size_t)n + j] -= (int64_t)adds[n] * e[j]; /* NodeGroupResources.Sub */
+        }
+        if (adds_out) memcpy(adds_out + (size_t)q * n_nodes, adds, (size_t)n_nodes * sizeof(uint32_t));
+    }
+    free(adds);
+}

@@ -127,6 +127,20 @@ uint32_t go_executor_first_fit_reserved(const int64_t *avail, uint32_t n_nodes, 
 uint32_t go_executor_min_frag(const int64_t *avail, uint32_t n_nodes, const int64_t *reserved, const int64_t exe[3],
                               const uint32_t *exec_order, uint32_t n_x, const uint8_t *hosts);
 
+/* findNodes (internal/extender/failover.go:412-436): tightly-pack with partial results, no driver, and no `Sub` of the
+ * add that fails the comparison.  Returns the number of executors placed (<= executor_count); exec_out receives them;
+ * adds_out (nullable, n_nodes, zeroed here) = number of `reserved[n].Add(executorResources)` calls per node, i.e. the
+ * returned `reserved` map is adds_out[n] x exe (0 = the node has no entry). */
+uint32_t go_find_nodes(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t executor_count,
+                       const uint32_t *ordered_nodes, uint32_t n_o, uint32_t *exec_out, uint32_t *adds_out);
+uint32_t go_find_nodes_closed_form(const int64_t *avail, uint32_t n_nodes, const int64_t exe[3], int32_t executor_count,
+                                   const uint32_t *ordered_nodes, uint32_t n_o, uint32_t *exec_out, uint32_t *adds_out);
+/* n_req findNodes calls in sequence, each followed by availableResources.Sub(reservedResources) (failover.go:159):
+ * avail (n_nodes x 3) is mutated.  exe: n_req x 3; adds_out nullable, n_req x n_nodes. */
+void go_find_nodes_chain(int closed_form, int64_t *avail, uint32_t n_nodes, const int64_t *exe, const int32_t *k,
+                         uint32_t n_req, const uint32_t *ordered_nodes, uint32_t n_o, uint32_t *placed_out,
+                         const uint64_t *exec_off, uint32_t *exec_out, uint32_t *adds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,3 +247,36 @@ def fit_earlier_drivers_then_pack(binpack, apps, driver_order, exec_order, avail
     drv, exe, count, _ = apps[-1]
     results[-1] = binpack(drv, exe, count, driver_order, exec_order, avail)
     return results, -1
+
+
+def find_nodes(executor_count: int, exe: Sequence[int], available: Dict[str, Res], ordered_nodes: Sequence[str]):
+    """findNodes — internal/extender/failover.go:412-436, with the reference's dict-of-lists shapes.  Returns
+    (executorNodeNames, reserved); the add that fails the comparison stays in `reserved` (no Sub before the break)."""
+    names: List[str] = []
+    reserved: Dict[str, Res] = {}
+    for n in ordered_nodes:
+        if n not in reserved:
+            reserved[n] = [0, 0, 0]
+        while True:
+            _add(reserved[n], exe)
+            if greater_than(reserved[n], available[n]):
+                break
+            names.append(n)
+            if len(names) == executor_count:
+                return names, reserved
+    return names, reserved
+
+
+def find_nodes_chain(requests, available: Dict[str, Res], ordered_nodes: Sequence[str]):
+    """The reconciler's loop over stale applications of one instance group (failover.go:132-160): findNodes, then
+    availableResources.Sub(reservedResources) (:159; NodeGroupResources.Sub, LIB/resources/resources.go:119-126).
+    requests: [(executor_count, exe)].  Mutates `available`; returns [(names, reserved)]."""
+    out = []
+    for count, exe in requests:
+        names, reserved = find_nodes(count, exe, available, ordered_nodes) if count > 0 else ([], {})
+        for n, r in reserved.items():
+            if n not in available:
+                available[n] = [0, 0, 0]
+            _sub(available[n], r)
+        out.append((names, reserved))
+    return out
