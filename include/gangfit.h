@@ -307,10 +307,17 @@ int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[10]);
  * reference code on n_cases adversarial inputs per lane.  *mismatches == 0 means pass. */
 int gf_selftest(gf_ctx *ctx, uint64_t seed, uint32_t n_cases, uint32_t *mismatches);
 
-/* Stream-copy probe: copies `bytes` (a multiple of 16; use far more than the 256 MiB of last-level cache) `iters` times
- * between two scratch buffers and reports read + write bandwidth in GB/s — the achievable HBM peak the rooflines in
- * bench.py are set against, next to the spec figure. */
-int gf_hbm_probe(gf_ctx *ctx, uint64_t bytes, uint32_t iters, double *gb_per_s);
+/* Bandwidth probe: streams `bytes` (a multiple of 16; use far more than the 256 MiB of last-level cache) `iters` times and
+ * reports what this device delivers, in GB/s — the measured figures the rooflines in bench.py quote next to the spec peak:
+ *   *read_gb_per_s   read-only stream (the access pattern of the scans), bytes / time
+ *   *copy_gb_per_s   copy between two buffers, (read + write) bytes / time
+ * Either pointer may be NULL (that leg is skipped). */
+int gf_hbm_probe(gf_ctx *ctx, uint64_t bytes, uint32_t iters, double *read_gb_per_s, double *copy_gb_per_s);
+
+/* Launch-floor probe: `iters` back-to-back launches of an empty one-wavefront kernel on `stream` (NULL = the context's own
+ * stream) between two HIP events; *us_per_launch = what one dependent launch costs on this stream when there is nothing
+ * to compute — the floor a latency-bound batch kernel is measured against. */
+int gf_launch_floor(gf_ctx *ctx, void *stream, uint32_t iters, float *us_per_launch);
 
 /* Device properties the host uses to size launches (also lets a caller verify it is talking to a gfx950). */
 typedef struct gf_device_info {

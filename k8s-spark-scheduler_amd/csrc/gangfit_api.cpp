@@ -588,35 +588,65 @@ void gf_ctx_unlock(gf_ctx* ctx) {
 
 const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* gb_per_s) {
-    if (!ctx || !gb_per_s || bytes < 16 || iters == 0) return GF_ERR_INVALID;
+int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gb_per_s, double* copy_gb_per_s) {
+    if (!ctx || bytes < 16 || iters == 0) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
     bytes &= ~UINT64_C(15);
     void *src = nullptr, *dst = nullptr;
     GF_HIP(ctx, hipMalloc(&src, bytes));
-    if (hipMalloc(&dst, bytes) != hipSuccess) {
+    if (copy_gb_per_s && hipMalloc(&dst, bytes) != hipSuccess) {
         (void)hipFree(src);
         return fail(ctx, GF_ERR_HIP, "hipMalloc of the probe buffer failed");
     }
     int rc = GF_OK;
-    float ms = 0.0f;
+    float ms_read = 0.0f, ms_copy = 0.0f;
+    uint32_t* sink = reinterpret_cast<uint32_t*>(ctx->d_stats.ptr);  // never written (see stream_read_kernel)
     do {
         if (hipMemsetAsync(src, 1, bytes, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }
-        if (gangfit::launch_stream_copy(src, dst, bytes, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }  // warm-up
-        if (hipEventRecord(ctx->ev_begin, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }
-        for (uint32_t i = 0; i < iters && rc == GF_OK; ++i)
-            if (gangfit::launch_stream_copy(i & 1 ? dst : src, i & 1 ? src : dst, bytes, ctx->stream) != hipSuccess) rc = GF_ERR_HIP;
-        if (rc != GF_OK) break;
-        if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
-            hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end) != hipSuccess)
-            rc = GF_ERR_HIP;
+        if (read_gb_per_s) {
+            if (gangfit::launch_stream_read(src, bytes, sink, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }  // warm-up
+            if (hipEventRecord(ctx->ev_begin, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }
+            for (uint32_t i = 0; i < iters && rc == GF_OK; ++i)
+                if (gangfit::launch_stream_read(src, bytes, sink, ctx->stream) != hipSuccess) rc = GF_ERR_HIP;
+            if (rc != GF_OK) break;
+            if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+                hipEventElapsedTime(&ms_read, ctx->ev_begin, ctx->ev_end) != hipSuccess) { rc = GF_ERR_HIP; break; }
+        }
+        if (copy_gb_per_s) {
+            if (gangfit::launch_stream_copy(src, dst, bytes, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }  // warm-up
+            if (hipEventRecord(ctx->ev_begin, ctx->stream) != hipSuccess) { rc = GF_ERR_HIP; break; }
+            for (uint32_t i = 0; i < iters && rc == GF_OK; ++i)
+                if (gangfit::launch_stream_copy(i & 1 ? dst : src, i & 1 ? src : dst, bytes, ctx->stream) != hipSuccess) rc = GF_ERR_HIP;
+            if (rc != GF_OK) break;
+            if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+                hipEventElapsedTime(&ms_copy, ctx->ev_begin, ctx->ev_end) != hipSuccess)
+                rc = GF_ERR_HIP;
+        }
     } while (false);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(src);
-    (void)hipFree(dst);
-    if (rc != GF_OK) return fail(ctx, rc, "stream-copy probe failed");
-    *gb_per_s = ms > 0.0f ? 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9 : 0.0;
+    if (dst) (void)hipFree(dst);
+    if (rc != GF_OK) return fail(ctx, rc, "bandwidth probe failed");
+    if (read_gb_per_s) *read_gb_per_s = ms_read > 0.0f ? (double)bytes * iters / ((double)ms_read * 1e-3) / 1e9 : 0.0;
+    if (copy_gb_per_s) *copy_gb_per_s = ms_copy > 0.0f ? 2.0 * (double)bytes * iters / ((double)ms_copy * 1e-3) / 1e9 : 0.0;
+    return GF_OK;
+}
+
+int gf_launch_floor(gf_ctx* ctx, void* stream, uint32_t iters, float* us_per_launch) {
+    if (!ctx || !us_per_launch || iters == 0) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    for (int i = 0; i < 8; ++i) GF_HIP(ctx, gangfit::launch_empty(nullptr, st));
+    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
+    for (uint32_t i = 0; i < iters; ++i) GF_HIP(ctx, gangfit::launch_empty(nullptr, st));
+    GF_HIP(ctx, hipEventRecord(ctx->ev_end, st));
+    GF_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    float ms = 0.0f;
+    GF_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    *us_per_launch = ms * 1e3f / (float)iters;
     return GF_OK;
 }
 

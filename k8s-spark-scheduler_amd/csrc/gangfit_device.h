@@ -280,6 +280,8 @@ struct SnapshotFinalize {
 };
 hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t stream);
 hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream);
+hipError_t launch_stream_read(const void* src, size_t bytes, uint32_t* sink, hipStream_t stream);
+hipError_t launch_empty(uint32_t* sink, hipStream_t stream);
 size_t snapshot_sort_temp_bytes(uint32_t n_nodes);
 hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream);
 

@@ -316,9 +316,32 @@ hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t strea
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------- stream-copy probe
-// The achievable HBM bandwidth of THIS device, for the roofline next to the spec figure: a plain
-// grid-stride copy with 16-byte accesses, far larger than L2 + MALL.
+// ---------------------------------------------------------------------------------------------------- bandwidth / launch probes
+// What THIS device delivers, measured next to the spec figures the rooflines quote:
+//   stream_read_kernel  — read-only stream (the access pattern of the scans: loads, almost no stores), 16 bytes per lane,
+//                         eight independent loads in flight per lane, far larger than L2 + MALL;
+//   stream_copy_kernel  — read + write of the same size (a copy pays the write-allocate / turnaround traffic: lower);
+//   empty_kernel        — the floor of one dependent kernel launch on a stream (nothing to do, one wavefront).
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restrict__ src_, size_t n16, uint32_t* __restrict__ sink) {
+    const probe_u32x4* __restrict__ src = reinterpret_cast<const probe_u32x4*>(src_);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        probe_u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&src[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) {
+        const probe_u32x4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;  // never true for the probe's fill pattern; keeps the loads alive
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,9 +355,24 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4* __restric
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(64) void empty_kernel(uint32_t* __restrict__ sink) {
+    if (sink != nullptr && threadIdx.x == 1234567u) *sink = 0;
+}
+
 hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream) {
     const size_t n16 = bytes / 16;
     hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 32), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, n16);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_read(const void* src, size_t bytes, uint32_t* sink, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 16), dim3(256), 0, stream, (const uint4*)src, n16, sink);
+    return hipGetLastError();
+}
+
+hipError_t launch_empty(uint32_t* sink, hipStream_t stream) {
+    hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, stream, sink);
     return hipGetLastError();
 }
 

@@ -99,9 +99,10 @@ class Context:
         self.n_nodes = len(avail)
 
     def build_snapshot(self, alloc, node_flags, name_rank, overhead=None, res_node=None, res_req=None, zone=None,
-                       n_zones: int = 1, driver_label_rank=None, exec_label_rank=None):
+                       n_zones: int = 1, driver_label_rank=None, exec_label_rank=None, want_orders: bool = True):
         """gf_snapshot_build: reservation replay + available/schedulable + priority orders on the device, installed as
-        the current snapshot.  Returns (driver_order, exec_order)."""
+        the current snapshot.  Returns (driver_order, exec_order) — (None, None) with want_orders=False (nothing of size
+        O(n_nodes) then returns to the host)."""
         alloc = np.ascontiguousarray(alloc, dtype=np.int64).reshape(-1, 3)
         n = len(alloc)
         cols = [np.ascontiguousarray(alloc[:, j]) for j in range(3)]
@@ -117,6 +118,12 @@ class Context:
         z = None if zone is None else np.ascontiguousarray(zone, dtype=np.uint32)
         dl = None if driver_label_rank is None else np.ascontiguousarray(driver_label_rank, dtype=np.uint32)
         el = None if exec_label_rank is None else np.ascontiguousarray(exec_label_rank, dtype=np.uint32)
+        if not want_orders:
+            self._check(self._lib.gf_snapshot_build(self._h, n, *[N.ptr(c) for c in cols], *[N.ptr(c) for c in ocols], len(rn),
+                                                    N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(flags), N.ptr(z), n_zones,
+                                                    N.ptr(ranks), N.ptr(dl), N.ptr(el), None, None, None, None))
+            self.n_nodes = n
+            return None, None
         d_out, x_out = np.zeros(n + 1, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint32)
         nd, nx = C.c_uint32(0), C.c_uint32(0)
         self._check(self._lib.gf_snapshot_build(self._h, n, *[N.ptr(c) for c in cols], *[N.ptr(c) for c in ocols], len(rn),
@@ -249,11 +256,17 @@ class Context:
         self.last_fifo_phases = [int(v) for v in out[4:10]]  # stage, driver scan, executor scan, slow path, commit
         return int(out[0]), int(out[1])
 
-    def hbm_probe(self, nbytes: int = 2 << 30, iters: int = 10) -> float:
-        """Achievable HBM bandwidth (read + write GB/s) of a plain stream copy on this device."""
-        out = C.c_double(0.0)
-        self._check(self._lib.gf_hbm_probe(self._h, nbytes, iters, C.byref(out)))
-        return float(out.value)
+    def hbm_probe(self, nbytes: int = 2 << 30, iters: int = 10):
+        """(read-only stream GB/s, copy read + write GB/s) this device delivers on `nbytes` buffers."""
+        rd, cp = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._lib.gf_hbm_probe(self._h, nbytes, iters, C.byref(rd), C.byref(cp)))
+        return float(rd.value), float(cp.value)
+
+    def launch_floor(self, stream: int = 0, iters: int = 200) -> float:
+        """Microseconds per back-to-back launch of an empty kernel on `stream`."""
+        us = C.c_float(0.0)
+        self._check(self._lib.gf_launch_floor(self._h, C.c_void_p(stream) if stream else None, iters, C.byref(us)))
+        return float(us.value)
 
     def selftest(self, seed: int = 1, n_cases: int = 256) -> int:
         bad = C.c_uint32(0)

@@ -83,6 +83,9 @@ def lib() -> C.CDLL:
         L.go_executor_first_fit_reserved.argtypes = [p, C.c_uint32, p, p, p, C.c_uint32]
         L.go_executor_min_frag.restype = C.c_uint32
         L.go_executor_min_frag.argtypes = [p, C.c_uint32, p, p, p, C.c_uint32, p]
+        L.go_fit_fifo_chain_with_efficiencies.restype = C.c_int32
+        L.go_fit_fifo_chain_with_efficiencies.argtypes = [C.c_int, p, p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p,
+                                                          C.c_uint32, p, p, p]
         L.go_find_nodes_chain.restype = None
         L.go_find_nodes_chain.argtypes = [C.c_int, p, C.c_uint32, p, p, C.c_uint32, p, C.c_uint32, p, p, p, p]
         _lib = L
@@ -162,7 +165,9 @@ def fit_independent(algo: int, avail, apps: np.ndarray, driver_order, exec_order
 
 
 def fit_fifo_chain(algo: int, avail, apps: np.ndarray, driver_order, exec_order, closed_form: bool = False,
-                   sched=None, zone=None) -> BatchOut:
+                   sched=None, zone=None, with_efficiencies: bool = False) -> BatchOut:
+    """with_efficiencies: also build the PackingEfficiencies map of every successful pack like the reference's
+    SparkBinPack does (binpack.go:77) — same results, the reference's cost shape (needs sched; literal loops)."""
     avail, d, x = _prep(avail, driver_order, exec_order)
     sched, zone = _aux(avail, sched, zone)
     avail = avail.copy()
@@ -170,9 +175,15 @@ def fit_fifo_chain(algo: int, avail, apps: np.ndarray, driver_order, exec_order,
     res = np.zeros(len(apps), dtype=RESULT_DTYPE)
     off = exec_offsets(apps["k"])
     out = np.zeros(int(apps["k"].astype(np.int64).sum()) + 1, dtype=np.uint32)
-    failed = lib().go_fit_fifo_chain_ex(algo, int(closed_form), _ptr(avail), _ptr(sched), _ptr(zone), len(avail),
-                                        _ptr(apps), len(apps), _ptr(d), len(d), _ptr(x), len(x), _ptr(res), _ptr(off),
-                                        _ptr(out))
+    if with_efficiencies:
+        assert sched is not None and not closed_form
+        failed = lib().go_fit_fifo_chain_with_efficiencies(algo, _ptr(avail), _ptr(sched), _ptr(zone), len(avail), _ptr(apps),
+                                                           len(apps), _ptr(d), len(d), _ptr(x), len(x), _ptr(res),
+                                                           _ptr(off), _ptr(out))
+    else:
+        failed = lib().go_fit_fifo_chain_ex(algo, int(closed_form), _ptr(avail), _ptr(sched), _ptr(zone), len(avail),
+                                            _ptr(apps), len(apps), _ptr(d), len(d), _ptr(x), len(x), _ptr(res), _ptr(off),
+                                            _ptr(out))
     return BatchOut(res, off, out[:-1], int(failed), avail)
 
 

@@ -723,10 +723,10 @@ static void subtract_usage(int64_t *avail, uint32_t n_nodes, const go_app *app, 
     if (!driver_overwritten && driver_node < n_nodes) res_sub(&avail[3 * driver_node], app->drv);
 }
 
-int32_t go_fit_fifo_chain_ex(int algo, int closed_form, int64_t *avail, const int64_t *sched, const uint32_t *zone,
-                             uint32_t n_nodes, const go_app *apps, uint32_t n_apps, const uint32_t *driver_order,
-                             uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, go_result *results,
-                             const uint64_t *exec_off, uint32_t *exec_out) {
+static int32_t fifo_chain_impl(int algo, int closed_form, int64_t *avail, const int64_t *sched, const uint32_t *zone,
+                               uint32_t n_nodes, const go_app *apps, uint32_t n_apps, const uint32_t *driver_order,
+                               uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                               const uint64_t *exec_off, uint32_t *exec_out, double *eff_scratch) {
     reserved_map rm;
     cluster_aux aux = {sched, zone};
     int have_rm = rm_init(&rm, n_nodes);
@@ -747,6 +747,10 @@ int32_t go_fit_fifo_chain_ex(int algo, int closed_form, int64_t *avail, const in
         results[a].has_capacity = ok;
         results[a].driver_node = ok ? d : GO_NO_NODE;
         results[a].exec_len = ok ? (uint32_t)apps[a].k : 0;
+        if (ok && eff_scratch && sched) { /* binpack.go:77: PackingEfficiencies of EVERY successful pack, replayed ones included */
+            double avg[4];
+            go_packing_efficiency(avail, sched, n_nodes, &apps[a], d, exec_out + exec_off[a], (uint32_t)apps[a].k, eff_scratch, avg);
+        }
         if (a + 1 == n_apps) break; /* the driver being filtered: no subtraction afterwards */
         if (!ok) {
             if (apps[a].flags & GO_APP_SKIPPABLE) continue; /* resource.go:244-248 */
@@ -759,6 +763,28 @@ done:
     free(mark);
     rm_free(&rm);
     return failed_at;
+}
+
+int32_t go_fit_fifo_chain_ex(int algo, int closed_form, int64_t *avail, const int64_t *sched, const uint32_t *zone,
+                             uint32_t n_nodes, const go_app *apps, uint32_t n_apps, const uint32_t *driver_order,
+                             uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, go_result *results,
+                             const uint64_t *exec_off, uint32_t *exec_out) {
+    return fifo_chain_impl(algo, closed_form, avail, sched, zone, n_nodes, apps, n_apps, driver_order, n_d, exec_order, n_x,
+                           results, exec_off, exec_out, NULL);
+}
+
+/* The chain as the reference's SparkBinPack really runs it: every successful pack also builds the per-node
+ * PackingEfficiencies map over ALL nodes (binpack.go:77 -> efficiency.go:66-103), which fitEarlierDrivers then discards
+ * (SURVEY.md section 8a row 9).  Same decisions; used by bench.py as the "reference-shaped" CPU baseline. */
+int32_t go_fit_fifo_chain_with_efficiencies(int algo, int64_t *avail, const int64_t *sched, const uint32_t *zone,
+                                            uint32_t n_nodes, const go_app *apps, uint32_t n_apps,
+                                            const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                                            uint32_t n_x, go_result *results, const uint64_t *exec_off, uint32_t *exec_out) {
+    double *eff = (double *)malloc(((size_t)n_nodes * 3 + 3) * sizeof(double));
+    int32_t r = fifo_chain_impl(algo, 0, avail, sched, zone, n_nodes, apps, n_apps, driver_order, n_d, exec_order, n_x,
+                                results, exec_off, exec_out, eff);
+    free(eff);
+    return r;
 }
 
 int32_t go_fit_fifo_chain(int algo, int closed_form, int64_t *avail, uint32_t n_nodes, const go_app *apps,

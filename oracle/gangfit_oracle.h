@@ -95,6 +95,13 @@ int32_t go_fit_fifo_chain_ex(int algo, int closed_form, int64_t *avail, const in
                              uint32_t n_d, const uint32_t *exec_order, uint32_t n_x, go_result *results,
                              const uint64_t *exec_off, uint32_t *exec_out);
 
+/* go_fit_fifo_chain_ex (literal) plus what the reference's SparkBinPack also does on every successful pack: the per-node
+ * PackingEfficiencies map over all nodes (binpack.go:77), discarded by fitEarlierDrivers.  Same results. */
+int32_t go_fit_fifo_chain_with_efficiencies(int algo, int64_t *avail, const int64_t *sched, const uint32_t *zone,
+                                            uint32_t n_nodes, const go_app *apps, uint32_t n_apps,
+                                            const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
+                                            uint32_t n_x, go_result *results, const uint64_t *exec_off, uint32_t *exec_out);
+
 /* ComputeAvgPackingEfficiency (efficiency.go:114-156) over nodeNames = [driver] ++ exec_nodes, duplicates counted,
  * summed in slice order.  reserved_includes_executors = 0 reproduces minimalFragmentation, which never writes its
  * placements into the `reserved` map (minimal_fragmentation.go:59-91): only the driver entry exists there. */

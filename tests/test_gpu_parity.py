@@ -38,7 +38,9 @@ def test_device_is_gfx950(gf_ctx):
 
 def test_hbm_stream_copy_probe(gf_ctx):
     """The roofline's measured companion of the 8 TB/s spec figure: a plain copy must move terabytes per second."""
-    assert gf_ctx.hbm_probe(1 << 30, 4) > 1000.0
+    rd, cp = gf_ctx.hbm_probe(1 << 30, 4)
+    assert rd > 1000.0 and cp > 1000.0
+    assert 0.5 < gf_ctx.launch_floor(0, 100) < 100.0
 
 
 def test_wave_primitives_selftest(gf_ctx):
