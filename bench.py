@@ -421,6 +421,27 @@ def main():
                         "requests": int(len(extra)), "requests_per_s": len(extra) / (time.perf_counter() - t0),
                         "note": "host entry point incl. H2D/D2H"}
             ctx4.close()
+            # ---- the same split INSIDE the library: one gf_ctx over several devices (gf_init with n_dev > 1, exchanges by peer
+            #      access).  One GPU: N shards on this device (what the path itself costs).  N GPUs: rank 0 drives all N devices
+            #      from one process while the other ranks wait at the barrier below; a subprocess, so that a fault in this
+            #      optional leg cannot take the contract line down.
+            if rank == 0:
+                import subprocess
+
+                grp = {}
+                for cfgname in ("headline", "config4"):
+                    devs = ",".join(str(i) for i in range(world)) if world > 1 else "0,0,0,0,0,0,0,0"
+                    try:
+                        env = dict(os.environ)
+                        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                            env.pop(k, None)
+                        p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "group_bench.py"), "--devices", devs,
+                                            "--config", cfgname, "--steps", "20"], capture_output=True, text=True, timeout=100, env=env)
+                        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                        grp[cfgname] = json.loads(line[-1]) if line else {"error": (p.stderr or p.stdout)[-400:]}
+                    except Exception as e:
+                        grp[cfgname] = {"error": f"{type(e).__name__}: {e}"}
+                node_sharded["in_library_multi_device_context"] = grp
             out["node_sharded"] = node_sharded
         except Exception as e:  # the headline number above must survive a failure of this optional leg
             out["node_sharded"] = {"error": f"{type(e).__name__}: {e}"}

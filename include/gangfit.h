@@ -106,8 +106,18 @@ typedef struct gf_ctx gf_ctx;
 
 int gf_version(void);
 
-/* Create a context on one device (n_dev must be 1 in this version; device_ids NULL = device 0).
- * Replaces nothing in the reference; the shim calls it right after SelectBinpacker (cmd/server.go:145). */
+/* Create a context.  Replaces nothing in the reference; the shim calls it right after SelectBinpacker (cmd/server.go:145).
+ *   n_dev == 1 (or device_ids NULL, n_dev 0 = device 0): everything runs on that device.
+ *   n_dev  > 1 (<= 16): ONE context over several devices of the box — the node table shards by range of the priority order
+ *     (SURVEY.md section 8e).  gf_snapshot_set / gf_zones_set / gf_orders_set / gf_snapshot_build install the snapshot on
+ *     every device; gf_fit_batch(GF_MODE_INDEPENDENT) with tightly-pack or distribute-evenly then evaluates every
+ *     application on every device's range (four device steps per device) and stitches the result with three exchanges
+ *     done by peer access over xGMI inside the call: two all-gathers of 16 B per application (written straight into the
+ *     peers' tables) and one reduction of the placement buffer onto the first device.  Same gf_result / ExecutorNodes as on
+ *     one device, bit for bit.  Everything else (FIFO chains — each commit must be visible to the next scan —, zone-aware
+ *     and minimal-fragmentation packers, orders that do not merge into one, single executors, findNodes, efficiencies, the
+ *     *_dev entry points) runs on the first device.  A device id may repeat (several shards on one GPU): that is how the
+ *     path is tested on a one-GPU box; GF_ERR_UNSUPPORTED when two distinct devices cannot access each other's memory. */
 int gf_init(const int *device_ids, int n_dev, gf_ctx **out);
 void gf_destroy(gf_ctx *ctx);
 

@@ -157,6 +157,14 @@ struct gf_ctx {
     DeviceBuf<int64_t> d_xexe, d_xreserved;
     DeviceBuf<uint32_t> d_xhosts, d_xout;
 
+    // ---- multi-device context (gf_init with n_dev > 1): this object only routes; one sub-context per device id does the
+    //      work and owns shard `shard` of `n_shards` of the priority order.  The g_* members live in the sub-contexts.
+    std::vector<gf_ctx*> group;
+    DeviceBuf<gf_shard_partial> g_part_loc, g_part_all;  // this shard's records | [n_shards][n_apps] gathered
+    DeviceBuf<gf_shard_driver> g_drv_loc, g_drv_all;
+    DeviceBuf<uint32_t> g_exec2;                         // 2 * half: placements (node + 1) | capacities
+    hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};    // behind partials+push | drivers+push | emit
+
     // findNodes requests (gf_find_nodes)
     DeviceBuf<int32_t> d_fk;
     DeviceBuf<uint64_t> d_foff;
@@ -194,6 +202,38 @@ int fail(gf_ctx* ctx, int code, const char* fmt, ...) {
         hipError_t e__ = (call);                                                                             \
         if (e__ != hipSuccess) return fail((ctx), GF_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
+
+// Entry points that have no multi-device form run on the first sub-context of a group (gf_init with n_dev > 1).
+#define GF_DELEGATE(ctx, expr)                                   \
+    do {                                                         \
+        if ((ctx) != nullptr && !(ctx)->group.empty()) {         \
+            gf_ctx* const group__ = (ctx);                       \
+            (ctx) = group__->group[0];                           \
+            const int rc__ = (expr);                             \
+            if (rc__ != GF_OK) group__->err = (ctx)->err;        \
+            return rc__;                                         \
+        }                                                        \
+    } while (0)
+// The same call on every sub-context (snapshot / zones / orders are replicated: each device scans only its range).
+#define GF_EACH(ctx, expr)                                                 \
+    do {                                                                   \
+        if ((ctx) != nullptr && !(ctx)->group.empty()) {                   \
+            gf_ctx* const group__ = (ctx);                                 \
+            std::lock_guard<std::recursive_mutex> glock__(group__->mu);    \
+            for (gf_ctx* sub__ : group__->group) {                         \
+                (ctx) = sub__;                                             \
+                const int rc__ = (expr);                                   \
+                if (rc__ != GF_OK) {                                       \
+                    group__->err = sub__->err;                             \
+                    return rc__;                                           \
+                }                                                          \
+            }                                                              \
+            return GF_OK;                                                  \
+        }                                                                  \
+    } while (0)
+
+int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results,
+                    uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at);
 
 NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     NodeTable t;
@@ -451,7 +491,51 @@ int gf_version(void) { return GF_VERSION; }
 int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (!out) return GF_ERR_INVALID;
     *out = nullptr;
-    if (n_dev != 1 && !(n_dev == 0 && device_ids == nullptr)) return GF_ERR_UNSUPPORTED;
+    if (n_dev > 1) {
+        // One context over several devices: sub-context i owns range i of n_dev of the priority order.  A device id may
+        // repeat (several shards on one GPU: how the path is exercised on a one-GPU box).
+        if (!device_ids || n_dev > (int)gangfit::kMaxGroupDevices) return GF_ERR_INVALID;
+        gf_ctx* g = new (std::nothrow) gf_ctx();
+        if (!g) return GF_ERR_HIP;
+        g->device = device_ids[0];
+        for (int i = 0; i < n_dev; ++i) {
+            gf_ctx* sub = nullptr;
+            const int rc = gf_init(&device_ids[i], 1, &sub);
+            if (rc != GF_OK) {
+                gf_destroy(g);
+                return rc;
+            }
+            sub->shard = (uint32_t)i;
+            sub->n_shards = (uint32_t)n_dev;
+            g->group.push_back(sub);
+            bool ok = hipSetDevice(sub->device) == hipSuccess;
+            for (hipEvent_t& e : sub->g_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                gf_destroy(g);
+                return GF_ERR_HIP;
+            }
+        }
+        for (int i = 0; i < n_dev; ++i)  // every shard's kernels write into / read from every other shard's buffers
+            for (int j = 0; j < n_dev; ++j) {
+                if (device_ids[i] == device_ids[j]) continue;
+                int can = 0;
+                if (hipSetDevice(device_ids[i]) != hipSuccess ||
+                    hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) != hipSuccess || !can) {
+                    gf_destroy(g);
+                    return GF_ERR_UNSUPPORTED;
+                }
+                const hipError_t e = hipDeviceEnablePeerAccess(device_ids[j], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    gf_destroy(g);
+                    return GF_ERR_HIP;
+                }
+                (void)hipGetLastError();
+            }
+        g->info = g->group[0]->info;
+        *out = g;
+        return GF_OK;
+    }
+    if (n_dev != 1 && !(n_dev == 0 && device_ids == nullptr)) return GF_ERR_INVALID;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GF_ERR_NO_DEVICE;
     const int dev = device_ids ? device_ids[0] : 0;
@@ -507,6 +591,16 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
 
 void gf_destroy(gf_ctx* ctx) {
     if (!ctx) return;
+    if (!ctx->group.empty()) {
+        for (gf_ctx* s : ctx->group) gf_destroy(s);
+        ctx->group.clear();
+        (void)hipSetDevice(ctx->device);
+        ctx->h_apps.release();
+        ctx->h_results.release();
+        ctx->h_exec.release();
+        delete ctx;
+        return;
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_snap.release();
@@ -547,6 +641,13 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_xreserved.release();
     ctx->d_xhosts.release();
     ctx->d_xout.release();
+    ctx->g_part_loc.release();
+    ctx->g_part_all.release();
+    ctx->g_drv_loc.release();
+    ctx->g_drv_all.release();
+    ctx->g_exec2.release();
+    for (hipEvent_t& e : ctx->g_ev)
+        if (e) (void)hipEventDestroy(e);
     ctx->d_fk.release();
     ctx->d_foff.release();
     ctx->d_fres.release();
@@ -589,6 +690,7 @@ void gf_ctx_unlock(gf_ctx* ctx) {
 const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gb_per_s, double* copy_gb_per_s) {
+    GF_DELEGATE(ctx, gf_hbm_probe(ctx, bytes, iters, read_gb_per_s, copy_gb_per_s));
     if (!ctx || bytes < 16 || iters == 0) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -634,6 +736,7 @@ int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gb_pe
 }
 
 int gf_launch_floor(gf_ctx* ctx, void* stream, uint32_t iters, float* us_per_launch) {
+    GF_DELEGATE(ctx, gf_launch_floor(ctx, stream, iters, us_per_launch));
     if (!ctx || !us_per_launch || iters == 0) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -682,6 +785,7 @@ int materialize_host(gf_ctx* ctx) {
 int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_milli, const int64_t* avail_mem_bytes,
                     const int64_t* avail_gpu, const int64_t* sched_cpu_milli, const int64_t* sched_mem_bytes,
                     const int64_t* sched_gpu) {
+    GF_EACH(ctx, gf_snapshot_set(ctx, n_nodes, avail_cpu_milli, avail_mem_bytes, avail_gpu, sched_cpu_milli, sched_mem_bytes, sched_gpu));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_nodes > 0 && (!avail_cpu_milli || !avail_mem_bytes || !avail_gpu))
@@ -727,6 +831,7 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
 }
 
 int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
+    GF_EACH(ctx, gf_zones_set(ctx, zone_of_node));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_zones_set");
@@ -737,6 +842,7 @@ int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
 }
 
 int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const uint32_t* exec_order, uint32_t n_x) {
+    GF_EACH(ctx, gf_orders_set(ctx, driver_order, n_d, exec_order, n_x));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_orders_set");
@@ -1029,6 +1135,8 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
 
 int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results,
                  uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at) {
+    if (ctx != nullptr && !ctx->group.empty())
+        return group_fit_batch(ctx, mode, algo, n_apps, apps, results, exec_nodes, exec_nodes_cap, chain_failed_at);
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_apps > 0 && (!apps || !results)) return fail(ctx, GF_ERR_INVALID, "apps/results must not be NULL");
@@ -1076,6 +1184,7 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
 int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
                      gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_chain_failed_at,
                      void* stream) {
+    GF_DELEGATE(ctx, gf_fit_batch_dev(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, stream));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);  // launch() grows buffers and flips state flags
     if (n_apps > 0 && (!d_apps || !d_results)) return fail(ctx, GF_ERR_INVALID, "device apps/results must not be NULL");
@@ -1096,6 +1205,23 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
                       const uint32_t* zone_of_node, uint32_t n_zones, const uint32_t* name_rank,
                       const uint32_t* driver_label_rank, const uint32_t* exec_label_rank, uint32_t* driver_order_out,
                       uint32_t* n_d_out, uint32_t* exec_order_out, uint32_t* n_x_out) {
+    if (ctx != nullptr && !ctx->group.empty()) {  // the caller's order lists come from the first device only
+        gf_ctx* const g = ctx;
+        std::lock_guard<std::recursive_mutex> glock(g->mu);
+        for (size_t i = 0; i < g->group.size(); ++i) {
+            const bool first = i == 0;
+            const int rc = gf_snapshot_build(g->group[i], n_nodes, alloc_cpu_milli, alloc_mem_bytes, alloc_gpu, over_cpu_milli,
+                                             over_mem_bytes, over_gpu, n_res, res_node, res_cpu_milli, res_mem_bytes, res_gpu,
+                                             node_flags, zone_of_node, n_zones, name_rank, driver_label_rank, exec_label_rank,
+                                             first ? driver_order_out : nullptr, first ? n_d_out : nullptr,
+                                             first ? exec_order_out : nullptr, first ? n_x_out : nullptr);
+            if (rc != GF_OK) {
+                g->err = g->group[i]->err;
+                return rc;
+            }
+        }
+        return GF_OK;
+    }
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     const uint32_t n = n_nodes;
@@ -1335,6 +1461,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
 }
 
 int gf_snapshot_get(gf_ctx* ctx, int64_t* avail_out, int64_t* sched_out) {
+    GF_DELEGATE(ctx, gf_snapshot_get(ctx, avail_out, sched_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "no snapshot");
@@ -1349,6 +1476,7 @@ int gf_snapshot_get(gf_ctx* ctx, int64_t* avail_out, int64_t* sched_out) {
 
 int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, const int64_t* exe, const int64_t* reserved,
                     const uint32_t* hosts_app, uint32_t* node_out) {
+    GF_DELEGATE(ctx, gf_executor_fit(ctx, minimal_fragmentation, n_req, exe, reserved, hosts_app, node_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_req == 0) return GF_OK;
@@ -1386,6 +1514,7 @@ int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, cons
 
 int gf_find_nodes(gf_ctx* ctx, int chained, uint32_t n_req, const int64_t* exe, const int32_t* k, gf_find_result* results,
                   uint32_t* exec_nodes, uint64_t exec_nodes_cap, uint32_t* reserved_adds) {
+    GF_DELEGATE(ctx, gf_find_nodes(ctx, chained, n_req, exe, k, results, exec_nodes, exec_nodes_cap, reserved_adds));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_req == 0) return GF_OK;
@@ -1456,6 +1585,8 @@ int shard_ready(gf_ctx* ctx, gf_algo algo, gangfit::ShardRange* r) {
 }  // namespace
 
 int gf_shard_set(gf_ctx* ctx, uint32_t shard, uint32_t n_shards) {
+    if (ctx != nullptr && !ctx->group.empty())
+        return fail(ctx, GF_ERR_UNSUPPORTED, "a multi-device context runs the shard steps and their exchanges itself (gf_fit_batch)");
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_shards == 0 || shard >= n_shards || n_shards > 1024)
@@ -1467,6 +1598,8 @@ int gf_shard_set(gf_ctx* ctx, uint32_t shard, uint32_t n_shards) {
 
 int gf_shard_partials_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_shard_partial* d_out,
                           void* stream) {
+    if (ctx != nullptr && !ctx->group.empty())
+        return fail(ctx, GF_ERR_UNSUPPORTED, "a multi-device context runs the shard steps and their exchanges itself (gf_fit_batch)");
     if (!ctx) return GF_ERR_INVALID;
     if (n_apps > 0 && (!d_apps || !d_out)) return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
     gangfit::ShardRange r{};
@@ -1479,6 +1612,8 @@ int gf_shard_partials_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_a
 
 int gf_shard_drivers_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
                          const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, void* stream) {
+    if (ctx != nullptr && !ctx->group.empty())
+        return fail(ctx, GF_ERR_UNSUPPORTED, "a multi-device context runs the shard steps and their exchanges itself (gf_fit_batch)");
     if (!ctx) return GF_ERR_INVALID;
     if (n_apps > 0 && (!d_apps || !d_all_partials || !d_out))
         return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
@@ -1493,6 +1628,8 @@ int gf_shard_drivers_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_ap
 int gf_shard_emit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
                       const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers, gf_result* d_results,
                       uint32_t* d_exec2, uint64_t half, void* stream) {
+    if (ctx != nullptr && !ctx->group.empty())
+        return fail(ctx, GF_ERR_UNSUPPORTED, "a multi-device context runs the shard steps and their exchanges itself (gf_fit_batch)");
     if (!ctx) return GF_ERR_INVALID;
     if (n_apps > 0 && (!d_apps || !d_all_partials || !d_all_drivers || !d_results || !d_exec2 || half == 0))
         return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
@@ -1508,6 +1645,8 @@ int gf_shard_emit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* 
 int gf_shard_finish_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
                         const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
                         const gf_result* d_results, uint32_t* d_exec2, uint64_t half, void* stream) {
+    if (ctx != nullptr && !ctx->group.empty())
+        return fail(ctx, GF_ERR_UNSUPPORTED, "a multi-device context runs the shard steps and their exchanges itself (gf_fit_batch)");
     if (!ctx) return GF_ERR_INVALID;
     if (n_apps > 0 && (!d_apps || !d_all_partials || !d_all_drivers || !d_results || !d_exec2 || half == 0))
         return fail(ctx, GF_ERR_INVALID, "device pointers must not be NULL");
@@ -1522,6 +1661,7 @@ int gf_shard_finish_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app
 
 int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps, const gf_result* results,
                               const uint32_t* exec_nodes, uint64_t exec_nodes_len, gf_avg_efficiency* out) {
+    GF_DELEGATE(ctx, gf_avg_packing_efficiency(ctx, algo, n_apps, apps, results, exec_nodes, exec_nodes_len, out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_apps > 0 && (!apps || !results || !out)) return fail(ctx, GF_ERR_INVALID, "apps/results/out must not be NULL");
@@ -1579,6 +1719,7 @@ int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const 
 
 int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const gf_result* result,
                             const uint32_t* exec_nodes, double* eff_out) {
+    GF_DELEGATE(ctx, gf_packing_efficiencies(ctx, algo, app, result, exec_nodes, eff_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!app || !result || !eff_out) return fail(ctx, GF_ERR_INVALID, "app/result/eff_out must not be NULL");
@@ -1616,6 +1757,7 @@ int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const 
 }
 
 int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
+    GF_DELEGATE(ctx, gf_residual_get(ctx, avail_out));
     if (!ctx || !avail_out) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_orders || !ctx->work_valid) return fail(ctx, GF_ERR_STATE, "no FIFO chain has run on the current orders");
@@ -1635,6 +1777,7 @@ int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
 }
 
 int gf_timer_begin(gf_ctx* ctx, void* stream) {
+    GF_DELEGATE(ctx, gf_timer_begin(ctx, stream));
     if (!ctx) return GF_ERR_INVALID;
     ctx->timer_stream = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     GF_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->timer_stream));
@@ -1642,6 +1785,7 @@ int gf_timer_begin(gf_ctx* ctx, void* stream) {
 }
 
 int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
+    GF_DELEGATE(ctx, gf_timer_end(ctx, elapsed_ms));
     if (!ctx || !elapsed_ms) return GF_ERR_INVALID;
     GF_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->timer_stream ? ctx->timer_stream : ctx->stream));
     GF_HIP(ctx, hipEventSynchronize(ctx->ev_end));
@@ -1650,6 +1794,7 @@ int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
 }
 
 int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
+    GF_DELEGATE(ctx, gf_scan_stats(ctx, enable, reset, out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -1672,6 +1817,7 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
 }
 
 int gf_selftest(gf_ctx* ctx, uint64_t seed, uint32_t n_cases, uint32_t* mismatches) {
+    GF_DELEGATE(ctx, gf_selftest(ctx, seed, n_cases, mismatches));
     if (!ctx || !mismatches) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
@@ -1687,3 +1833,120 @@ int gf_selftest(gf_ctx* ctx, uint64_t seed, uint32_t n_cases, uint32_t* mismatch
 }
 
 }  // extern "C"
+
+namespace {
+
+// gf_fit_batch on a multi-device context.  Independent batches of the two plain packers are node-range sharded across the
+// sub-contexts (the four steps of gangfit_shard.inc with the three exchanges done by peer access,
+// see shard_push_kernel / shard_reduce_pull_kernel); everything else — FIFO chains (each commit must be visible to the next
+// scan), the zone-aware and minimal-fragmentation packers, orders that do not merge — runs on the first device.
+int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results,
+                    uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at) {
+    std::lock_guard<std::recursive_mutex> glock(g->mu);
+    gf_ctx* const first = g->group[0];
+    bool sharded = mode == GF_MODE_INDEPENDENT && (algo == GF_ALGO_TIGHTLY_PACK || algo == GF_ALGO_DISTRIBUTE_EVENLY) && n_apps > 0;
+    for (gf_ctx* s : g->group) sharded = sharded && s->have_orders && s->merged;
+    if (!sharded) {
+        const int rc = gf_fit_batch(first, mode, algo, n_apps, apps, results, exec_nodes, exec_nodes_cap, chain_failed_at);
+        if (rc != GF_OK) g->err = first->err;
+        return rc;
+    }
+    if (!apps || !results) return fail(g, GF_ERR_INVALID, "apps/results must not be NULL");
+    if (chain_failed_at) *chain_failed_at = -1;
+    const uint32_t S = (uint32_t)g->group.size();
+    GF_HIP(g, hipSetDevice(first->device));
+    GF_HIP(g, g->h_apps.reserve(n_apps));
+    uint64_t total_k = 0;
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        const gf_app& in = apps[a];
+        if (in.k < 0 || in.k > GF_MAX_K) return fail(g, GF_ERR_INVALID, "apps[%u].k = %d outside [0, %d]", a, in.k, GF_MAX_K);
+        for (int j = 0; j < 3; ++j)
+            if (in.drv[j] < 0 || in.drv[j] >= GF_MAX_ABS_QUANTITY || in.exe[j] < 0 || in.exe[j] >= GF_MAX_ABS_QUANTITY)
+                return fail(g, GF_ERR_INVALID, "apps[%u] request outside [0, 2^62)", a);
+        gf_app& o = g->h_apps.ptr[a];
+        o = in;
+        o.exec_off = total_k;
+        total_k += (uint64_t)in.k;
+    }
+    if (total_k > exec_nodes_cap || (total_k > 0 && !exec_nodes))
+        return fail(g, GF_ERR_CAPACITY, "exec_nodes holds %llu entries, %llu needed", (unsigned long long)exec_nodes_cap,
+                    (unsigned long long)total_k);
+    const uint64_t half = total_k + 1;
+    GF_HIP(g, g->h_results.reserve(n_apps));
+    GF_HIP(g, g->h_exec.reserve(total_k + 1));
+    // ---- buffers and the app table on every device
+    gangfit::ShardRange range[gangfit::kMaxGroupDevices];
+    gangfit::PeerPtrs part_all{}, drv_all{}, exec_others{};
+    for (uint32_t s = 0; s < S; ++s) {
+        gf_ctx* c = g->group[s];
+        GF_HIP(g, hipSetDevice(c->device));
+        if (const int rc = shard_ready(c, algo, &range[s]); rc != GF_OK) {
+            g->err = c->err;
+            return rc;
+        }
+        GF_HIP(g, c->d_apps.reserve(n_apps));
+        GF_HIP(g, c->d_results.reserve(n_apps));
+        GF_HIP(g, c->g_part_loc.reserve(n_apps));
+        GF_HIP(g, c->g_drv_loc.reserve(n_apps));
+        GF_HIP(g, c->g_part_all.reserve((size_t)S * n_apps));
+        GF_HIP(g, c->g_drv_all.reserve((size_t)S * n_apps));
+        GF_HIP(g, c->g_exec2.reserve(2 * half));
+        GF_HIP(g, hipMemcpyAsync(c->d_apps.ptr, g->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, c->stream));
+        part_all.p[s] = c->g_part_all.ptr;
+        drv_all.p[s] = c->g_drv_all.ptr;
+        if (s > 0) exec_others.p[exec_others.n++] = c->g_exec2.ptr;
+    }
+    part_all.n = drv_all.n = S;
+    auto everyone_waits = [&](int which) -> hipError_t {  // stream t continues only behind event `which` of every other shard
+        for (uint32_t t = 0; t < S; ++t) {
+            hipError_t e = hipSetDevice(g->group[t]->device);
+            for (uint32_t s = 0; s < S && e == hipSuccess; ++s)
+                if (s != t) e = hipStreamWaitEvent(g->group[t]->stream, g->group[s]->g_ev[which], 0);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    // ---- step 1: per-range capacity sums, gathered everywhere
+    for (uint32_t s = 0; s < S; ++s) {
+        gf_ctx* c = g->group[s];
+        GF_HIP(g, hipSetDevice(c->device));
+        GF_HIP(g, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_loc.ptr, c->stream));
+        GF_HIP(g, gangfit::launch_shard_push(c->g_part_loc.ptr, part_all, (size_t)s * n_apps * sizeof(gf_shard_partial),
+                                             (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
+        GF_HIP(g, hipEventRecord(c->g_ev[0], c->stream));
+    }
+    GF_HIP(g, everyone_waits(0));
+    // ---- step 2: first feasible driver of each range, gathered everywhere
+    for (uint32_t s = 0; s < S; ++s) {
+        gf_ctx* c = g->group[s];
+        GF_HIP(g, hipSetDevice(c->device));
+        GF_HIP(g, gangfit::launch_shard_drivers(make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr, c->g_drv_loc.ptr, c->stream));
+        GF_HIP(g, gangfit::launch_shard_push(c->g_drv_loc.ptr, drv_all, (size_t)s * n_apps * sizeof(gf_shard_driver),
+                                             (size_t)n_apps * sizeof(gf_shard_driver), c->stream));
+        GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
+    }
+    GF_HIP(g, everyone_waits(1));
+    // ---- step 3: every shard emits its slice of the placements
+    for (uint32_t s = 0; s < S; ++s) {
+        gf_ctx* c = g->group[s];
+        GF_HIP(g, hipSetDevice(c->device));
+        GF_HIP(g, gangfit::launch_shard_emit(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
+                                             c->g_drv_all.ptr, c->d_results.ptr, c->g_exec2.ptr, half, c->stream));
+        GF_HIP(g, hipEventRecord(c->g_ev[2], c->stream));
+    }
+    // ---- step 4 on the first device only: sum of the slices (each entry written by exactly one shard), finish, D2H
+    GF_HIP(g, hipSetDevice(first->device));
+    for (uint32_t s = 1; s < S; ++s) GF_HIP(g, hipStreamWaitEvent(first->stream, g->group[s]->g_ev[2], 0));
+    GF_HIP(g, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream));
+    GF_HIP(g, gangfit::launch_shard_finish(algo, S, n_apps, first->d_apps.ptr, first->g_part_all.ptr, first->g_drv_all.ptr,
+                                           first->d_results.ptr, first->g_exec2.ptr, half, first->stream));
+    GF_HIP(g, hipMemcpyAsync(g->h_results.ptr, first->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, first->stream));
+    if (total_k)
+        GF_HIP(g, hipMemcpyAsync(g->h_exec.ptr, first->g_exec2.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, first->stream));
+    GF_HIP(g, hipStreamSynchronize(first->stream));
+    std::memcpy(results, g->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
+    if (total_k) std::memcpy(exec_nodes, g->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
+    return GF_OK;
+}
+
+}  // namespace

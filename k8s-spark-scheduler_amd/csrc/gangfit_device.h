@@ -213,6 +213,17 @@ hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps,
                                const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
                                const gf_result* d_results, uint32_t* d_exec2, uint64_t half, hipStream_t stream);
 
+// Exchanges of the in-process multi-device context (gangfit_shard.inc): up to 16 peer pointers by value.
+constexpr uint32_t kMaxGroupDevices = 16;
+struct PeerPtrs {
+    void* p[kMaxGroupDevices];
+    uint32_t n;
+};
+// every shard's `bytes` (multiple of 16) at src -> byte offset dst_offset of each pointer in dsts
+hipError_t launch_shard_push(const void* d_src, const PeerPtrs& dsts, size_t dst_offset, size_t bytes, hipStream_t stream);
+// d_dst[i] += sum over srcs of src[i], n uint32 entries
+hipError_t launch_shard_reduce_pull(const PeerPtrs& srcs, uint32_t* d_dst, size_t n, hipStream_t stream);
+
 // Placing one executor per request (gangfit_executor.inc): first fit or the minimal-fragmentation choice.
 // d_reserved: 3 x n_nodes int64 by node index (row-major, nullable); d_hosts: per request a bit set over node indices.
 hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& table, const int64_t* d_reserved, uint32_t n_req,

@@ -1997,6 +1997,21 @@ hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps,
     return hipGetLastError();
 }
 
+hipError_t launch_shard_push(const void* d_src, const PeerPtrs& dsts, size_t dst_offset, size_t bytes, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0 || dsts.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(shard_push_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)d_src, dsts, dst_offset / 16, n16);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_reduce_pull(const PeerPtrs& srcs, uint32_t* d_dst, size_t n, hipStream_t stream) {
+    if (n == 0 || srcs.n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(shard_reduce_pull_kernel, dim3(blocks), dim3(256), 0, stream, srcs, d_dst, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& table, const int64_t* d_reserved, uint32_t n_req,
                                const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
                                hipStream_t stream) {

@@ -53,11 +53,14 @@ class BatchOut:
 class Context:
     """gf_ctx wrapper. Raises GangfitError on any negative return code — no silent fallback."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None):
+        """devices: a list of device ids makes ONE context over several devices (gf_init with n_dev > 1: independent batches
+        of the plain packers are node-range sharded across them inside the library; an id may repeat)."""
         self._lib = N.load()
         h = C.c_void_p()
-        ids = (C.c_int * 1)(device)
-        rc = self._lib.gf_init(ids, 1, C.byref(h))
+        devs = [device] if devices is None else [int(d) for d in devices]
+        ids = (C.c_int * len(devs))(*devs)
+        rc = self._lib.gf_init(ids, len(devs), C.byref(h))
         if rc != N.GF_OK:
             raise N.GangfitError(rc, "gf_init failed (no gfx950 device visible?)")
         self._h = h

@@ -762,6 +762,82 @@ static void TestTwoThreadsOneContext() {
     CHECK(bad_scan.load() == 0);
 }
 
+// ------------------------------------------------------------------------------------------------ one context, several devices
+// gf_init with n_dev > 1 (include/gangfit.h): the Go shim reaches node-range sharding by passing more device ids, nothing
+// else changes.  Driven here through gangfit.h only (no torch, no Python): the sharded batch must equal the one-device one.
+static void TestMultiDeviceContext() {
+    const uint32_t n = 3000, n_apps = 500;
+    std::vector<int64_t> col[3];
+    std::vector<uint32_t> order(n);
+    uint64_t x = 88172645463325252ull;
+    auto rnd = [&x]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        col[0].push_back((int64_t)(rnd() % 64) * 500 - 1000);
+        col[1].push_back((int64_t)(rnd() % 128) * (Gi / 2));
+        col[2].push_back(rnd() % 10 == 0 ? (int64_t)(rnd() % 8) : 0);
+        order[i] = i;
+    }
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return col[1][a] != col[1][b] ? col[1][a] < col[1][b] : (col[0][a] != col[0][b] ? col[0][a] < col[0][b] : a < b);
+    });
+    std::vector<gf_app> apps(n_apps);
+    uint64_t total_k = 0;
+    for (gf_app& a : apps) {
+        a = gf_app{};
+        a.drv[0] = 1000 * (1 + (int64_t)(rnd() % 3));
+        a.drv[1] = Gi * (1 + (int64_t)(rnd() % 4));
+        a.exe[0] = 500 * (1 + (int64_t)(rnd() % 8));
+        a.exe[1] = Gi * (1 + (int64_t)(rnd() % 16));
+        a.exe[2] = rnd() % 20 == 0 ? 1 : 0;
+        a.k = (int32_t)(1 + rnd() % 90);
+        total_k += (uint64_t)a.k;
+    }
+    auto run = [&](gf_ctx* c, gf_algo algo, std::vector<gf_result>* res, std::vector<uint32_t>* exec) {
+        res->assign(n_apps, gf_result{});
+        exec->assign(total_k + 1, 0u);
+        return gf_snapshot_set(c, n, col[0].data(), col[1].data(), col[2].data(), nullptr, nullptr, nullptr) == GF_OK &&
+               gf_orders_set(c, order.data(), n, order.data(), n) == GF_OK &&
+               gf_fit_batch(c, GF_MODE_INDEPENDENT, algo, n_apps, apps.data(), res->data(), exec->data(), total_k, nullptr) == GF_OK;
+    };
+    for (int n_dev : {2, 5, 8}) {
+        std::vector<int> ids((size_t)n_dev, 0);  // every shard on device 0: the one-GPU form of the eight-GPU context
+        gf_ctx* g = nullptr;
+        CHECK(gf_init(ids.data(), n_dev, &g) == GF_OK);
+        if (!g) continue;
+        for (gf_algo algo : {GF_ALGO_TIGHTLY_PACK, GF_ALGO_DISTRIBUTE_EVENLY}) {
+            std::vector<gf_result> r1, rg;
+            std::vector<uint32_t> e1, eg;
+            CHECK(run(g_ctx, algo, &r1, &e1));
+            CHECK(run(g, algo, &rg, &eg));
+            bool same = true;
+            int feasible = 0;
+            uint64_t off = 0;
+            for (uint32_t a = 0; a < n_apps; ++a) {
+                same = same && r1[a].has_capacity == rg[a].has_capacity && r1[a].driver_node == rg[a].driver_node &&
+                       r1[a].exec_len == rg[a].exec_len;
+                if (r1[a].has_capacity) {
+                    ++feasible;
+                    for (uint32_t i = 0; i < r1[a].exec_len; ++i) same = same && e1[off + i] == eg[off + i];
+                }
+                off += (uint64_t)apps[a].k;
+            }
+            CHECK(same);
+            CHECK(feasible > 0 && feasible < (int)n_apps);
+        }
+        // a FIFO chain on the group runs on its first device and still answers
+        std::vector<gf_result> rc(n_apps);
+        std::vector<uint32_t> ec(total_k + 1);
+        int32_t failed = 0;
+        CHECK(gf_fit_batch(g, GF_MODE_FIFO_CHAIN, GF_ALGO_TIGHTLY_PACK, n_apps, apps.data(), rc.data(), ec.data(), total_k, &failed) == GF_OK);
+        gf_destroy(g);
+    }
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu" || mode == "all") {
@@ -790,6 +866,7 @@ int main(int argc, char** argv) {
         TestDeviceSnapshotBuildAgainstHostMirror();
         TestFindNodes();
         TestTwoThreadsOneContext();
+        TestMultiDeviceContext();
         gf_destroy(g_ctx);
     }
     std::printf("%s: %d checks, %d failed\n", mode.c_str(), g_checked, g_failed);

@@ -167,4 +167,6 @@ def test_config5_replay_then_fifo_999_plus_1(gf_ctx, algo):
         assert np.array_equal(residual, avail - usage)
         if variant != "as specified":
             assert not gpu.results["evaluated"][801:].any() and gpu.results["evaluated"][:801].all()
-            assert not gpu.results["has_capacity"][[100, 400, 401, 800]].any()
+            # the plain packers can still host the first such gangs on the gpu nodes the replay left empty; the one that
+            # aborts the chain cannot be hosted by any packer
+            assert not gpu.results["has_capacity"][800] and not gpu.results["has_capacity"][401]

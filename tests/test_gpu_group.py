@@ -1,0 +1,97 @@
+"""One gf_ctx over several devices (gf_init with n_dev > 1, include/gangfit.h): an independent batch of a plain packer is
+node-range sharded INSIDE the library — four device steps per shard, exchanges by peer access — and must return exactly
+what one device returns.  The one-GPU box exercises it with a repeated device id (N shards on cuda:0); everything else a
+multi-device context is asked for (FIFO chains, zone-aware packers, single executors, findNodes) runs on its first device."""
+import numpy as np
+import pytest
+
+import gangfit
+from gangfit import workloads as wl
+from oracle import binding as ob
+from test_gpu_parity import _assert_same, _random_problem
+
+pytestmark = pytest.mark.gpu
+IND, FIFO = gangfit.GF_MODE_INDEPENDENT, gangfit.GF_MODE_FIFO_CHAIN
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("n_dev", [2, 3, 8, 16])
+@pytest.mark.parametrize("n", [5, 64, 130, 1000])
+def test_group_matches_oracle(algo, n_dev, n):
+    rng = np.random.default_rng(4321 + 17 * n_dev + algo + n)
+    with gangfit.Context(devices=[0] * n_dev) as g:
+        for layout in ("merged", "identical"):
+            for tight_cluster in (True, False):
+                avail, D, X, drv, exe, k = _random_problem(rng, n, 150, tight_cluster, layout)
+                g.set_snapshot(avail)
+                g.set_orders(D, X)
+                apps = gangfit.make_apps(drv, exe, k)
+                ref = ob.fit_independent(algo, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True)
+                _assert_same(g.fit_batch(IND, algo, apps), ref, apps)
+
+
+def test_group_general_layout_and_other_modes_run_on_the_first_device():
+    rng = np.random.default_rng(99)
+    avail, D, X, drv, exe, k = _random_problem(rng, 300, 60, True, "general")
+    sched = np.abs(avail) + 5
+    zone = rng.integers(0, 3, size=len(avail)).astype(np.uint32)
+    apps = gangfit.make_apps(drv, exe, k, np.ones(len(k), dtype=np.uint32))
+    oapps = ob.make_apps(drv, exe, k, np.ones(len(k), dtype=np.uint32))
+    with gangfit.Context(devices=[0, 0, 0]) as g:
+        g.set_snapshot(avail, sched)
+        g.set_zones(zone)
+        g.set_orders(D, X)
+        for algo in (0, 1, 2, 4):
+            ref = ob.fit_independent(algo, avail, oapps, D, X, sched=sched, zone=zone)
+            _assert_same(g.fit_batch(IND, algo, apps), ref, apps)
+            ref = ob.fit_fifo_chain(algo, avail, oapps, D, X, sched=sched, zone=zone)
+            out = g.fit_batch(FIFO, algo, apps)
+            assert out.failed_at == ref.failed_at and np.array_equal(out.results, ref.results)
+            assert np.array_equal(g.residual(), ref.avail_after)
+        Xk = X[X < len(avail)]
+        assert g.executor_fit(exe[:8]).tolist() == [ob.executor_fit(avail, e, X) for e in exe[:8]]
+        placed, _, _, _, adds = g.find_nodes(exe[:5], k[:5], chained=True)
+        want = ob.find_nodes(avail, exe[:5], k[:5], Xk)
+        assert np.array_equal(placed, want.placed) and np.array_equal(adds, want.adds)
+        assert g.device_info()["arch"].startswith("gfx950") and g.selftest(3, 32) == 0
+        with pytest.raises(gangfit.GangfitError):  # the shard steps of a group are not the caller's to drive
+            g._check(g._lib.gf_shard_set(g._h, 0, 2))
+
+
+def test_group_device_built_snapshot_and_headline_size():
+    w = wl.headline(10000, 1000)
+    s = w.snapshot
+    apps = gangfit.make_apps(w.drv, w.exe, w.k)
+    oapps = ob.make_apps(w.drv, w.exe, w.k)
+    with gangfit.Context(devices=[0] * 8) as g:
+        g.set_snapshot(s.avail, s.sched)
+        g.set_orders(s.driver_order, s.exec_order)
+        for algo in (0, 1):
+            ref = ob.fit_independent(algo, s.avail, oapps, s.driver_order, s.exec_order, closed_form=False)
+            _assert_same(g.fit_batch(IND, algo, apps), ref, apps)
+        # a snapshot built on the device installs itself on every sub-context
+        rng = np.random.default_rng(12)
+        n = 5000
+        alloc = np.stack([rng.choice([16, 32, 64], size=n) * 1000, rng.choice([64, 128, 256], size=n) * (1 << 30),
+                          np.zeros(n, dtype=np.int64)], axis=1).astype(np.int64)
+        rnode = rng.integers(0, n, size=30000).astype(np.uint32)
+        rreq = np.stack([rng.choice([1000, 2000, 4000], size=30000), rng.choice([4, 8, 16], size=30000) * (1 << 30),
+                         np.zeros(30000, dtype=np.int64)], axis=1).astype(np.int64)
+        D, X = g.build_snapshot(alloc, np.full(n, 6, dtype=np.uint32), rng.permutation(n).astype(np.uint32), res_node=rnode,
+                                res_req=rreq)
+        avail, _ = g.snapshot()
+        ref = ob.fit_independent(0, avail, oapps, D, X, closed_form=True)
+        out = g.fit_batch(IND, 0, apps)
+        assert 0 < ref.results["has_capacity"].sum()
+        _assert_same(out, ref, apps)
+
+
+def test_group_argument_errors():
+    lib = gangfit._native.load()
+    import ctypes as C
+
+    h = C.c_void_p()
+    ids = (C.c_int * 17)(*([0] * 17))
+    assert lib.gf_init(ids, 17, C.byref(h)) == gangfit._native.GF_ERR_INVALID  # more than 16 devices
+    ids = (C.c_int * 2)(0, 999)
+    assert lib.gf_init(ids, 2, C.byref(h)) == gangfit._native.GF_ERR_NO_DEVICE
