@@ -21,7 +21,6 @@ import (
 	"context"
 	"errors"
 	"fmt"
-	"math"
 	"sync"
 	"unsafe"
 
@@ -64,21 +63,34 @@ func canonical(r *resources.Resources) (out [3]int64, err error) {
 	return
 }
 
-// Context owns one gf_ctx (one MI355X).  Created right after SelectBinpacker (cmd/server.go:145), destroyed in the
-// server's cleanup func.
+// Context owns one gf_ctx.  Created right after SelectBinpacker (cmd/server.go:145), destroyed in the server's cleanup
+// func.  One device id = one MI355X; several ids = ONE context over several GPUs of the box: independent batches of the
+// plain packers are then node-range sharded inside the library (SURVEY.md 8e), nothing else changes for the caller.
 type Context struct {
-	mu  sync.Mutex // snapshot+orders+fit must not interleave between goroutines (Predicate vs UnschedulablePodMarker)
+	mu  sync.Mutex // snapshot+zones+orders+fit must not interleave between goroutines (Predicate vs UnschedulablePodMarker)
 	ctx *C.gf_ctx
 }
 
-func New(device int) (*Context, error) {
+func New(devices ...int) (*Context, error) {
+	if len(devices) == 0 {
+		devices = []int{0}
+	}
+	ids := make([]C.int, len(devices))
+	for i, d := range devices {
+		ids[i] = C.int(d)
+	}
 	var h *C.gf_ctx
-	id := C.int(device)
-	if rc := C.gf_init(&id, 1, &h); rc != C.GF_OK {
+	if rc := C.gf_init(&ids[0], C.int(len(ids)), &h); rc != C.GF_OK {
 		return nil, fmt.Errorf("gf_init: %d", int(rc))
 	}
 	return &Context{ctx: h}, nil
 }
+
+// zone-aware packers compare packing efficiencies per zone (single_az.go:75-97): they need the zone ids and exact
+// schedulable columns; minimal-fragmentation packers never write executor placements into `reserved`
+// (minimal_fragmentation.go:59-91).
+func zoneAware(algo int) bool { return algo == 3 || algo == 4 || algo == 5 }
+func reservesExecutors(algo int) bool { return algo != 2 && algo != 5 }
 
 func (c *Context) Close() {
 	if c.ctx != nil {
@@ -111,25 +123,38 @@ type table struct {
 	names        []string
 	index        map[string]uint32
 	avail, sched [3][]int64
+	schedOK      bool // every SchedulableResources is an exact canonical value >= 0
+	zone         []uint32
 	dOrder       []uint32
 	xOrder       []uint32
 }
 
 func flatten(meta resources.NodeGroupSchedulingMetadata, driverOrder, execOrder []string) (*table, error) {
-	t := &table{index: make(map[string]uint32, len(meta))}
+	t := &table{index: make(map[string]uint32, len(meta)), schedOK: true}
+	zoneID := map[string]uint32{} // dense id per distinct NodeSchedulingMetadata.ZoneLabel (resources.go:78-81)
 	for name, m := range meta {
 		a, err := canonical(m.AvailableResources)
 		if err != nil {
 			return nil, err
 		}
-		s := [3]int64{math.MaxInt64 >> 2, math.MaxInt64 >> 2, math.MaxInt64 >> 2}
-		if m.SchedulableResources != nil {
-			if s2, err := canonical(m.SchedulableResources); err == nil {
-				s = s2
-			}
+		var s [3]int64
+		if m.SchedulableResources == nil {
+			t.schedOK = false
+		} else if s2, err := canonical(m.SchedulableResources); err != nil || s2[0] < 0 || s2[1] < 0 || s2[2] < 0 {
+			// e.g. CreateSchedulingMetadata's math.MaxInt64 (resources.go:260-266): not below 2^62.  The plain packers do
+			// not need the column (it is then passed as NULL); the zone-aware ones fall back to Go (FitBatch).
+			t.schedOK = false
+		} else {
+			s = s2
+		}
+		z, ok := zoneID[m.ZoneLabel]
+		if !ok {
+			z = uint32(len(zoneID))
+			zoneID[m.ZoneLabel] = z
 		}
 		t.index[name] = uint32(len(t.names))
 		t.names = append(t.names, name)
+		t.zone = append(t.zone, z)
 		for j := 0; j < 3; j++ {
 			t.avail[j] = append(t.avail[j], a[j])
 			t.sched[j] = append(t.sched[j], s[j])
@@ -174,6 +199,9 @@ func (c *Context) FitBatch(fifo bool, algo int, apps []App, driverOrder, execOrd
 	if err != nil {
 		return nil, -1, err
 	}
+	if zoneAware(algo) && !t.schedOK {
+		return nil, -1, ErrNotRepresentable // chooseBestResult compares efficiencies: they must be exact, so Go decides
+	}
 	capps := make([]C.gf_app, len(apps))
 	total := 0
 	for i, a := range apps {
@@ -207,9 +235,20 @@ func (c *Context) FitBatch(fifo bool, algo int, apps []App, driverOrder, execOrd
 
 	c.mu.Lock()
 	defer c.mu.Unlock()
+	var s0, s1, s2 *C.int64_t // NULL schedulable columns: only the efficiencies need them
+	if t.schedOK {
+		s0, s1, s2 = p64(t.sched[0]), p64(t.sched[1]), p64(t.sched[2])
+	}
 	if rc := C.gf_snapshot_set(c.ctx, C.uint32_t(len(t.names)), p64(t.avail[0]), p64(t.avail[1]), p64(t.avail[2]),
-		p64(t.sched[0]), p64(t.sched[1]), p64(t.sched[2])); rc != C.GF_OK {
+		s0, s1, s2); rc != C.GF_OK {
 		return nil, -1, c.err(rc)
+	}
+	// NodeSchedulingMetadata.ZoneLabel as dense ids: without them every node would sit in ONE zone and the single-AZ /
+	// AZ-aware packers would silently answer for a one-zone cluster (after gf_snapshot_set, before gf_orders_set)
+	if len(t.zone) > 0 {
+		if rc := C.gf_zones_set(c.ctx, p32(t.zone)); rc != C.GF_OK {
+			return nil, -1, c.err(rc)
+		}
 	}
 	if rc := C.gf_orders_set(c.ctx, p32(t.dOrder), C.uint32_t(len(t.dOrder)), p32(t.xOrder), C.uint32_t(len(t.xOrder))); rc != C.GF_OK {
 		return nil, -1, c.err(rc)
@@ -259,11 +298,13 @@ func (c *Context) SparkBinPackFunction(algo int, fallback binpack.SparkBinPackFu
 		}
 		reserved := make(resources.NodeGroupResources, len(res[0].ExecutorNodes)+1)
 		reserved[res[0].DriverNode] = driverResources.Copy()
-		for _, n := range res[0].ExecutorNodes {
-			if reserved[n] == nil {
-				reserved[n] = resources.Zero()
+		if reservesExecutors(algo) { // minimalFragmentation leaves `reserved` with the driver only
+			for _, n := range res[0].ExecutorNodes {
+				if reserved[n] == nil {
+					reserved[n] = resources.Zero()
+				}
+				reserved[n].Add(executorResources)
 			}
-			reserved[n].Add(executorResources)
 		}
 		return &binpack.PackingResult{
 			DriverNode:          res[0].DriverNode,
@@ -272,4 +313,91 @@ func (c *Context) SparkBinPackFunction(algo int, fallback binpack.SparkBinPackFu
 			PackingEfficiencies: binpack.ComputePackingEfficiencies(nodesSchedulingMetadata, reserved),
 		}
 	}
+}
+
+// FindNodes is findNodes of the failover reconciler (internal/extender/failover.go:412-436) for the stale applications of
+// ONE instance group, chained like the reconciler's loop: request i sees availableResources after
+// `availableResources.Sub(reservedResources)` of the requests before it (:159).  Returns, per request, the executor node
+// names (possibly fewer than asked for) and the `reserved` map — with the reference's over-add: a node that was filled up
+// carries one executor request more than it hosts (:424-427).  available is NOT modified; the caller applies Sub itself.
+func (c *Context) FindNodes(counts []int, executor []*resources.Resources, available resources.NodeGroupResources,
+	orderedNodes []string) (nodes [][]string, reserved []resources.NodeGroupResources, err error) {
+	n := len(orderedNodes)
+	var cols [3][]int64
+	order := make([]uint32, n)
+	for i, name := range orderedNodes {
+		r, ok := available[name]
+		if !ok {
+			return nil, nil, fmt.Errorf("gangfit: node %s has no availableResources entry", name)
+		}
+		a, err := canonical(r)
+		if err != nil {
+			return nil, nil, err
+		}
+		for j := 0; j < 3; j++ {
+			cols[j] = append(cols[j], a[j])
+		}
+		order[i] = uint32(i)
+	}
+	exe := make([]int64, 0, 3*len(counts))
+	ks := make([]C.int32_t, len(counts))
+	total := 0
+	for q, k := range counts {
+		e, err := canonical(executor[q])
+		if err != nil {
+			return nil, nil, err
+		}
+		if k <= 0 || k > C.GF_MAX_K {
+			return nil, nil, ErrNotRepresentable
+		}
+		exe = append(exe, e[0], e[1], e[2])
+		ks[q] = C.int32_t(k)
+		total += k
+	}
+	res := make([]C.gf_find_result, len(counts))
+	placed := make([]uint32, total+1)
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	if rc := C.gf_snapshot_set(c.ctx, C.uint32_t(n), p64(cols[0]), p64(cols[1]), p64(cols[2]), nil, nil, nil); rc != C.GF_OK {
+		return nil, nil, c.err(rc)
+	}
+	if rc := C.gf_orders_set(c.ctx, nil, 0, p32(order), C.uint32_t(n)); rc != C.GF_OK {
+		return nil, nil, c.err(rc)
+	}
+	if len(counts) == 0 {
+		return nil, nil, nil
+	}
+	if rc := C.gf_find_nodes(c.ctx, 1, C.uint32_t(len(counts)), p64(exe), &ks[0], &res[0], p32(placed), C.uint64_t(total), nil); rc != C.GF_OK {
+		return nil, nil, c.err(rc)
+	}
+	off := 0
+	for q, k := range counts {
+		got := placed[off : off+int(res[q].placed)]
+		names := make([]string, len(got))
+		mult := map[uint32]int64{}
+		for i, ix := range got {
+			names[i] = orderedNodes[ix]
+			mult[ix]++
+		}
+		// the `reserved` map as include/gangfit.h documents it: every node up to last_node was reached and carries one
+		// failing add on top of its placements, except last_node itself when the count was reached there
+		rmap := resources.NodeGroupResources{}
+		if res[q].last_node != C.GF_NO_NODE {
+			for ix := uint32(0); ix <= uint32(res[q].last_node); ix++ {
+				adds := mult[ix] + 1
+				if ix == uint32(res[q].last_node) && int(res[q].placed) == k {
+					adds--
+				}
+				r := resources.Zero()
+				for i := int64(0); i < adds; i++ {
+					r.Add(executor[q])
+				}
+				rmap[orderedNodes[ix]] = r
+			}
+		}
+		nodes = append(nodes, names)
+		reserved = append(reserved, rmap)
+		off += k
+	}
+	return nodes, reserved, nil
 }

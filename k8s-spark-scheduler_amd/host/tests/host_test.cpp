@@ -795,6 +795,7 @@ static void TestMultiDeviceContext() {
         a.exe[1] = Gi * (1 + (int64_t)(rnd() % 16));
         a.exe[2] = rnd() % 20 == 0 ? 1 : 0;
         a.k = (int32_t)(1 + rnd() % 90);
+        if (rnd() % 9 == 0) a.k = 4000;  // gangs the cluster cannot host: both answers must occur
         total_k += (uint64_t)a.k;
     }
     auto run = [&](gf_ctx* c, gf_algo algo, std::vector<gf_result>* res, std::vector<uint32_t>* exec) {

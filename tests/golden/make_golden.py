@@ -55,6 +55,92 @@ def problem(seed, n, a, tight):
                 flags=flags)
 
 
+def answers_for(p, case):
+    """Literal-oracle answers of one problem for every packer, both batch shapes, plus the findNodes chain."""
+    a = len(p["k"])
+    apps = ob.make_apps(p["drv"], p["exe"], p["k"], p["flags"])
+    kf = np.asarray(p.get("fifo_k", np.minimum(p["k"], 25)), dtype=np.int32)
+    fexe = np.asarray(p.get("fifo_exe", np.maximum(p["exe"], 1)), dtype=np.int64)
+    case["answers"] = {}
+    for name, algo in ALGOS.items():
+        ind = ob.fit_independent(algo, p["avail"], apps, p["D"], p["X"], sched=p["sched"], zone=p["zone"])
+        fapps = ob.make_apps(p["drv"], fexe, kf, p["flags"])
+        fifo = ob.fit_fifo_chain(algo, p["avail"], fapps, p["D"], p["X"], sched=p["sched"], zone=p["zone"])
+        case["answers"][name] = {
+            "independent": {"has_capacity": ind.results["has_capacity"].tolist(),
+                            "driver_node": ind.results["driver_node"].tolist(),
+                            "exec_nodes": [ind.placement(i)[2].tolist() for i in range(a)]},
+            "fifo": {"k": kf.tolist(), "exe": fexe.tolist(), "failed_at": int(fifo.failed_at),
+                     "has_capacity": fifo.results["has_capacity"].tolist(),
+                     "evaluated": fifo.results["evaluated"].tolist(),
+                     "driver_node": fifo.results["driver_node"].tolist(),
+                     "exec_nodes": [fifo.placement(i)[2].tolist() for i in range(a)],
+                     "avail_after": fifo.avail_after.tolist()},
+        }
+    # findNodes (failover.go:412-436) over the known nodes of the executor order, requests chained like the reconciler's loop
+    order = np.asarray([x for x in p["X"] if x < len(p["avail"])], dtype=np.uint32)
+    fk = np.maximum(np.minimum(p["k"], 12), 1).astype(np.int32)
+    fn = ob.find_nodes(p["avail"], p["exe"], fk, order, chained=True)
+    case["find_nodes"] = {"order": order.tolist(), "k": fk.tolist(), "exe": np.asarray(p["exe"]).tolist(),
+                          "placed": fn.placed.tolist(), "exec_nodes": [fn.placement(q).tolist() for q in range(len(fk))],
+                          "adds": fn.adds.tolist(), "avail_after": fn.avail_after.tolist()}
+
+
+def targeted_cases():
+    """Hand-built problems that isolate what the random ones only hit by chance (cpu in milli, memory / gpu in units)."""
+    out = []
+    # (1) distribute-evenly over several passes with nodes dropping out pass by pass (distribute_evenly.go:49-71):
+    #     capacities for exe (250 m, 1, 0) are 1, 5, 3, 0 (overcommitted) and 9
+    avail = np.array([[250, 9, 0], [1250, 9, 0], [750, 3, 0], [-250, 9, 0], [2250, 9, 1]], dtype=np.int64)
+    n = len(avail)
+    ks = [4, 7, 14, 18, 19, 3, 9]
+    out.append(dict(name="distribute-evenly multi-pass", avail=avail, sched=np.maximum(avail, 0) * 2 + 1,
+                    zone=np.array([0, 1, 0, 1, 0], dtype=np.uint32), D=np.array([3, 1, 4, 0], dtype=np.uint32),
+                    X=np.array([0, 1, 2, 3, 4], dtype=np.uint32),
+                    drv=np.array([[250, 1, 0]] * 5 + [[1000, 2, 0], [0, 0, 1]], dtype=np.int64),
+                    exe=np.array([[250, 1, 0]] * 7, dtype=np.int64), k=np.array(ks, dtype=np.int32),
+                    flags=np.array([1, 1, 0, 1, 0, 1, 1], dtype=np.uint32), fifo_k=np.array([2, 3, 2, 1, 30, 2, 1], dtype=np.int32),
+                    fifo_exe=np.array([[250, 1, 0]] * 7, dtype=np.int64)))
+    # (2) the sparkResourceUsage quirk (sparkpods.go:139-146) where the driver shares its node with executors, at the 63 | 64
+    #     boundary of the 64-slot chunks the kernels scan: the first 63 nodes are full, node 63 is the last lane of chunk 0,
+    #     node 64 the first lane of chunk 1 (absent in the 64-node variant: the table ends at the boundary)
+    for n in (64, 65, 130):
+        avail = np.zeros((n, 3), dtype=np.int64)
+        avail[63:] = [4000, 8, 0]
+        if n > 100:
+            avail[100] = [4000, 8, 2]
+        order = np.arange(n, dtype=np.uint32)
+        drv = np.array([[1000, 1, 0], [1000, 1, 0], [2000, 2, 0], [500, 0, 0], [1000, 1, 0], [250, 1, 0], [1000, 1, 1], [0, 0, 0]], dtype=np.int64)
+        exe = np.array([[1000, 2, 0], [1000, 2, 0], [1000, 1, 0], [250, 1, 0], [4000, 8, 0], [500, 1, 0], [500, 1, 1], [250, 1, 0]], dtype=np.int64)
+        k = np.array([5, 0, 2, 3, 1, 6, 2, 9], dtype=np.int32)  # K = 0: the driver's request is subtracted (no executor overwrites it)
+        out.append(dict(name=f"fifo usage quirk at the chunk boundary, {n} nodes", avail=avail, sched=np.maximum(avail, 0) + 1000,
+                        zone=(order % 2).astype(np.uint32), D=order, X=order, drv=drv, exe=exe, k=k,
+                        flags=np.array([0, 0, 1, 0, 1, 0, 1, 0], dtype=np.uint32), fifo_k=k, fifo_exe=exe))
+    return out
+
+
+def main_v2():
+    cases = []
+    for p in targeted_cases():
+        case = {key: np.asarray(v).tolist() for key, v in p.items() if key != "name"}
+        case.update(name=p["name"], seed=0, n_nodes=len(p["avail"]))
+        answers_for(p, case)
+        cases.append(case)
+    for seed, n, a, tight in [(11, 9, 10, True), (12, 64, 20, True), (13, 65, 20, False), (14, 200, 16, True)]:
+        p = problem(seed, n, a, tight)
+        case = {key: np.asarray(v).tolist() for key, v in p.items()}
+        case.update(name=f"random seed {seed}", seed=seed, n_nodes=n)
+        answers_for(p, case)
+        cases.append(case)
+    out = os.path.join(HERE, "gangfit_golden_v2.json")
+    with open(out, "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py (main_v2)", "oracle": "oracle/gangfit_oracle.c (literal loops)",
+                   "units": "cpu milli-cores, memory and gpu in whole units; node i is named n%05d, zone z is named z%d, an order "
+                            "entry >= n_nodes is a name that is not a key of the metadata map",
+                   "algos": ALGOS, "cases": cases}, f, separators=(",", ":"))
+    print(out, os.path.getsize(out), "bytes")
+
+
 def main():
     cases = []
     for seed, n, a, tight in [(1, 6, 12, True), (2, 70, 24, True), (3, 130, 24, False), (4, 64, 16, True)]:
@@ -88,3 +174,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_v2()
