@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -25,6 +26,43 @@ using gangfit::ScanStats;
 namespace {
 
 constexpr int64_t kSentinelAvail = -(INT64_C(1) << 62);  // "node is not in nodesSchedulingMetadata"
+
+// Completion waits.  hipStreamSynchronize / hipEventSynchronize park the calling thread and pay an interrupt + wake-up
+// (tens of microseconds) per call — more than a whole 1 000-application batch takes on the device, and a visible part of
+// every Filter.  The entry points of this library are short blocking calls, so they poll instead (hipStreamQuery /
+// hipEventQuery, sub-microsecond per probe) and only fall back to the blocking wait when the device takes long (50 ms) or
+// when GANGFIT_WAIT=block asks for it (a host that cannot spare the core for the duration of a call).
+inline bool wait_blocking() {
+    static const bool block = [] {
+        const char* e = std::getenv("GANGFIT_WAIT");
+        return e != nullptr && std::strcmp(e, "block") == 0;
+    }();
+    return block;
+}
+template <class Query, class Block>
+inline hipError_t poll_then_block(Query query, Block block) {
+    if (wait_blocking()) return block();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0;; ++i) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+        if ((i & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            (void)hipGetLastError();
+            return block();
+        }
+    }
+}
+inline hipError_t gf_wait_stream(hipStream_t st) {
+    const hipError_t e = poll_then_block([st] { return hipStreamQuery(st); }, [st] { return hipStreamSynchronize(st); });
+    if (e == hipSuccess) (void)hipGetLastError();  // hipErrorNotReady of the probes is not an error
+    return e;
+}
+inline hipError_t gf_wait_event(hipEvent_t ev) {
+    const hipError_t e = poll_then_block([ev] { return hipEventQuery(ev); }, [ev] { return hipEventSynchronize(ev); });
+    if (e == hipSuccess) (void)hipGetLastError();
+    return e;
+}
 
 template <typename T>
 struct DeviceBuf {
@@ -117,7 +155,8 @@ struct gf_ctx {
     // narrow (scaled int32) form of the table: value = scaled * unit[dim]; exists when every |value / unit| < 2^30
     bool narrow_ok = false;
     int64_t unit[3] = {1, 1, 1};
-    DeviceBuf<int32_t> d_nsnap, d_nwork, d_ncmax;
+    int64_t nmax[3] = {0, 0, 0};  // largest |scaled value| per dimension: how far the units may still be refined per batch
+    DeviceBuf<int32_t> d_nsnap, d_nwork, d_ncmax, d_ncmax_w;
     PinnedBuf<int32_t> h_ntable;
     // GANGFIT_FIFO_KERNEL: "narrow" (default: narrow first, v2 as its wide fallback), "fused" (wide fused only),
     // "v2" (general-layout kernel only), "narrow+fused" (narrow first, wide fused as the fallback)
@@ -281,7 +320,7 @@ int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
     if (rows < 1) rows = 1;
     if (rows <= ctx->cnt_rows && ctx->cnt_slots == ctx->n_slots) return GF_OK;
     if (rows < ctx->cnt_rows) rows = ctx->cnt_rows;
-    GF_HIP(ctx, hipStreamSynchronize(stream));
+    GF_HIP(ctx, gf_wait_stream(stream));
     GF_HIP(ctx, ctx->d_cnt.reserve(rows * ctx->n_slots));
     GF_HIP(ctx, hipMemsetAsync(ctx->d_cnt.ptr, 0, rows * ctx->n_slots * sizeof(uint32_t), stream));
     ctx->cnt_rows = (uint32_t)rows;
@@ -289,9 +328,63 @@ int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
     return GF_OK;
 }
 
+
+// The narrow (scaled int32) working table of one FIFO chain.  The table's units are the gcds of its own columns; a batch
+// whose requests are finer than that (a 2 GiB driver on a cluster whose free memory happens to be a multiple of 4 GiB)
+// would have no scaled form and fall to the wide kernels.  When the host sees the batch (h_apps; gf_fit_batch) the units are
+// therefore refined to gcd(table unit, every request of the batch) and the working copy is multiplied up by the ratio —
+// as long as every scaled magnitude stays below 2^30; comparisons, subtractions and floor divisions are invariant under a
+// common factor, so the chain is bit-identical.  Device-resident batches (gf_fit_batch_dev) keep the table's units.
+int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t stream, gangfit::NarrowTable* nt) {
+    int64_t eff[3] = {ctx->unit[0], ctx->unit[1], ctx->unit[2]};
+    int32_t factor[3] = {1, 1, 1};
+    if (h_apps != nullptr) {
+        for (uint32_t a = 0; a < n_apps; ++a)
+            for (int j = 0; j < 3; ++j)
+                for (const int64_t v : {h_apps[a].drv[j], h_apps[a].exe[j]})
+                    if (v > 0 && v % eff[j] != 0) {
+                        int64_t x = eff[j], y = v;
+                        while (y) {
+                            const int64_t t = x % y;
+                            x = y;
+                            y = t;
+                        }
+                        eff[j] = x;
+                    }
+        bool ok = true;
+        for (int j = 0; j < 3; ++j) {
+            const int64_t f = ctx->unit[j] / eff[j];
+            const int64_t room = ctx->nmax[j] > 0 ? ((INT64_C(1) << 30) - 1) / ctx->nmax[j] : (INT64_C(1) << 30) - 1;
+            ok = ok && f <= room;
+            factor[j] = ok ? (int32_t)f : 1;
+        }
+        if (!ok)
+            for (int j = 0; j < 3; ++j) {
+                eff[j] = ctx->unit[j];
+                factor[j] = 1;
+            }
+    }
+    nt->cpu = ctx->d_nwork.ptr;
+    nt->mem = nt->cpu + ctx->n_slots;
+    nt->gpu = nt->mem + ctx->n_slots;
+    for (int j = 0; j < 3; ++j) nt->unit[j] = eff[j];
+    if (factor[0] == 1 && factor[1] == 1 && factor[2] == 1) {
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
+                                   hipMemcpyDeviceToDevice, stream));
+        nt->cmax = ctx->d_ncmax.ptr;
+        return GF_OK;
+    }
+    GF_HIP(ctx, ctx->d_ncmax_w.reserve(3 * (size_t)ctx->n_chunks));
+    GF_HIP(ctx, gangfit::launch_narrow_rescale(ctx->d_nsnap.ptr, ctx->d_nwork.ptr, ctx->n_slots, ctx->d_ncmax.ptr,
+                                               ctx->d_ncmax_w.ptr, ctx->n_chunks, factor, stream));
+    nt->cmax = ctx->d_ncmax_w.ptr;
+    return GF_OK;
+}
+
 // The LDS-resident minimal-fragmentation chain when the layout is merged, the table has a narrow form and the tables fit;
 // *run_if is then set to the flag the generic kernel must test (it only runs when a request had no scaled form).
-int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint32_t nz, uint32_t n_apps, const gf_app* d_apps,
+int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint32_t nz, uint32_t n_apps, const gf_app* h_apps,
+                    const gf_app* d_apps,
                     gf_result* d_results, uint32_t* d_exec_nodes, uint64_t half, int32_t* d_failed, hipStream_t stream,
                     const int32_t** run_if) {
     *run_if = nullptr;
@@ -305,14 +398,8 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
     GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
     GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
-    GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
-                               hipMemcpyDeviceToDevice, stream));
     gangfit::NarrowTable nt{};
-    nt.cpu = ctx->d_nwork.ptr;
-    nt.mem = nt.cpu + ctx->n_slots;
-    nt.gpu = nt.mem + ctx->n_slots;
-    nt.cmax = ctx->d_ncmax.ptr;
-    for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+    if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt); nrc != GF_OK) return nrc;
     // capacity matrix: one int32 per (request shape, slot); skipped (capacities recomputed per pass) beyond 1 GiB
     int32_t* capmat = nullptr;
     if ((uint64_t)n_shapes * ctx->n_slots * sizeof(int32_t) <= (UINT64_C(1) << 30) && ctx->fifo_minfrag_matrix) {
@@ -326,7 +413,8 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     return GF_OK;
 }
 
-int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
+int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, const gf_app* d_apps,
+                 gf_result* d_results,
                  uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
     if (!ctx->have_sched)
         return fail(ctx, GF_ERR_STATE, "zone-aware packers compare packing efficiencies: gf_snapshot_set needs the schedulable columns");
@@ -363,14 +451,8 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
                 lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
                 GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
                 GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
-                GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
-                                           hipMemcpyDeviceToDevice, stream));
                 gangfit::NarrowTable nt{};
-                nt.cpu = ctx->d_nwork.ptr;
-                nt.mem = nt.cpu + ctx->n_slots;
-                nt.gpu = nt.mem + ctx->n_slots;
-                nt.cmax = ctx->d_ncmax.ptr;
-                for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+                if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt); nrc != GF_OK) return nrc;
                 GF_HIP(ctx, gangfit::launch_fit_fifo_zoned_lds(az_aware, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr,
                                                                lds_slots, n_shapes, n_apps, d_apps, ctx->d_napps.ptr,
                                                                ctx->d_wide_needed.ptr, d_results, d_exec_nodes,
@@ -381,8 +463,8 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
             }
         }
         if (inner == GF_ALGO_MINIMAL_FRAGMENTATION) {
-            const int rc2 = try_minfrag_lds(ctx, true, zt, nz, n_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream,
-                                            &run_if);
+            const int rc2 = try_minfrag_lds(ctx, true, zt, nz, n_apps, h_apps, d_apps, d_results, d_exec_nodes, half, d_failed,
+                                            stream, &run_if);
             if (rc2 != GF_OK) return rc2;
             if (run_if) zb.zexec = ctx->d_zexec.ptr;
         }
@@ -399,15 +481,16 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     return GF_OK;
 }
 
-int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
-           uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
+// h_apps: the same records on the host when the caller has them (gf_fit_batch), nullptr for device-resident batches.
+int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, const gf_app* d_apps,
+           gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
     const uint64_t half = exec_nodes_len + 1;
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
     if (is_zone_algo(algo)) {
         if (mode != GF_MODE_INDEPENDENT && mode != GF_MODE_FIFO_CHAIN)
             return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
-        return launch_zoned(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_failed, stream);
+        return launch_zoned(ctx, mode, algo, n_apps, h_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_failed, stream);
     }
     if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY && algo != GF_ALGO_MINIMAL_FRAGMENTATION)
         return fail(ctx, GF_ERR_UNSUPPORTED, "gf_algo %d is not served by the device path", (int)algo);
@@ -419,7 +502,8 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         ctx->work_valid = true;
         gangfit::ZoneTable zt{nullptr, nullptr, 0, 0};
         const int32_t* run_if = nullptr;
-        const int rc2 = try_minfrag_lds(ctx, false, zt, 0, n_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream, &run_if);
+        const int rc2 = try_minfrag_lds(ctx, false, zt, 0, n_apps, h_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream,
+                                        &run_if);
         if (rc2 != GF_OK) return rc2;
         gangfit::ZoneBuffers zb{nullptr, ctx->d_zexec.ptr, half, nullptr, nullptr, 0, nullptr};
         GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_MINIMAL_FRAGMENTATION, false, false, false,
@@ -464,13 +548,7 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         gangfit::NarrowTable nt{};
         if (plan.narrow) {
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
-            GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
-                                       hipMemcpyDeviceToDevice, stream));
-            nt.cpu = ctx->d_nwork.ptr;
-            nt.mem = nt.cpu + ctx->n_slots;
-            nt.gpu = nt.mem + ctx->n_slots;
-            nt.cmax = ctx->d_ncmax.ptr;
-            for (int j = 0; j < 3; ++j) nt.unit[j] = ctx->unit[j];
+            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt); nrc != GF_OK) return nrc;
         }
         if (plan.wide_fused) GF_HIP(ctx, ctx->d_dev_apps.reserve(n_apps));
         GF_HIP(ctx, gangfit::launch_fit_fifo(algo, plan, make_table(ctx, ctx->d_work.ptr), nt, n_apps, d_apps,
@@ -602,7 +680,7 @@ void gf_destroy(gf_ctx* ctx) {
         return;
     }
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)gf_wait_stream(ctx->stream);
     ctx->d_snap.release();
     ctx->d_work.release();
     ctx->d_slot_node.release();
@@ -618,6 +696,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_nsnap.release();
     ctx->d_nwork.release();
     ctx->d_ncmax.release();
+    ctx->d_ncmax_w.release();
     ctx->h_ntable.release();
     ctx->h_cmax.release();
     ctx->d_sched.release();
@@ -712,7 +791,7 @@ int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gb_pe
             for (uint32_t i = 0; i < iters && rc == GF_OK; ++i)
                 if (gangfit::launch_stream_read(src, bytes, sink, ctx->stream) != hipSuccess) rc = GF_ERR_HIP;
             if (rc != GF_OK) break;
-            if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+            if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || gf_wait_event(ctx->ev_end) != hipSuccess ||
                 hipEventElapsedTime(&ms_read, ctx->ev_begin, ctx->ev_end) != hipSuccess) { rc = GF_ERR_HIP; break; }
         }
         if (copy_gb_per_s) {
@@ -721,12 +800,12 @@ int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gb_pe
             for (uint32_t i = 0; i < iters && rc == GF_OK; ++i)
                 if (gangfit::launch_stream_copy(i & 1 ? dst : src, i & 1 ? src : dst, bytes, ctx->stream) != hipSuccess) rc = GF_ERR_HIP;
             if (rc != GF_OK) break;
-            if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev_end) != hipSuccess ||
+            if (hipEventRecord(ctx->ev_end, ctx->stream) != hipSuccess || gf_wait_event(ctx->ev_end) != hipSuccess ||
                 hipEventElapsedTime(&ms_copy, ctx->ev_begin, ctx->ev_end) != hipSuccess)
                 rc = GF_ERR_HIP;
         }
     } while (false);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)gf_wait_stream(ctx->stream);
     (void)hipFree(src);
     if (dst) (void)hipFree(dst);
     if (rc != GF_OK) return fail(ctx, rc, "bandwidth probe failed");
@@ -742,11 +821,11 @@ int gf_launch_floor(gf_ctx* ctx, void* stream, uint32_t iters, float* us_per_lau
     GF_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     for (int i = 0; i < 8; ++i) GF_HIP(ctx, gangfit::launch_empty(nullptr, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     GF_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     for (uint32_t i = 0; i < iters; ++i) GF_HIP(ctx, gangfit::launch_empty(nullptr, st));
     GF_HIP(ctx, hipEventRecord(ctx->ev_end, st));
-    GF_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    GF_HIP(ctx, gf_wait_event(ctx->ev_end));
     float ms = 0.0f;
     GF_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     *us_per_launch = ms * 1e3f / (float)iters;
@@ -771,7 +850,7 @@ int materialize_host(gf_ctx* ctx) {
         GF_HIP(ctx, hipMemcpyAsync(ctx->h_bcols.ptr, ctx->d_node_tab.ptr, 6 * N * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, ctx->d_node_slot.ptr, N * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));
     for (int j = 0; j < 3; ++j) {
         ctx->avail[j].assign(ctx->h_bcols.ptr + (size_t)j * N, ctx->h_bcols.ptr + (size_t)(j + 1) * N);
         ctx->sched[j].assign(ctx->h_bcols.ptr + (size_t)(3 + j) * N, ctx->h_bcols.ptr + (size_t)(4 + j) * N);
@@ -818,7 +897,7 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
     ctx->work_valid = false;
     // node-indexed copy for the per-node efficiency map (gf_packing_efficiencies)
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));
     GF_HIP(ctx, ctx->d_node_tab.reserve(6 * (size_t)n_nodes + 1));
     for (int j = 0; j < 3 && n_nodes; ++j) {
         GF_HIP(ctx, hipMemcpy(ctx->d_node_tab.ptr + (size_t)j * n_nodes, av[j], (size_t)n_nodes * sizeof(int64_t),
@@ -1007,6 +1086,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         int32_t* nt = ctx->h_ntable.ptr;
         int32_t* ncm = nt + 3 * (size_t)n_slots;
         for (int j = 0; j < 3 && ok; ++j) {
+            ctx->nmax[j] = 0;
             for (uint32_t c = 0; c < n_chunks; ++c) ncm[(size_t)j * n_chunks + c] = INT32_MIN;
             for (uint32_t s2 = 0; s2 < n_slots; ++s2) {
                 int32_t v32 = INT32_MIN / 2;  // sentinel / empty slot: never fits, never hosts
@@ -1017,6 +1097,8 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
                         break;
                     }
                     v32 = (int32_t)q;
+                    const int64_t mag = q < 0 ? -q : q;
+                    if (mag > ctx->nmax[j]) ctx->nmax[j] = mag;
                 }
                 nt[(size_t)j * n_slots + s2] = v32;
                 int32_t& m = ncm[(size_t)j * n_chunks + (s2 >> 6)];
@@ -1025,7 +1107,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         }
         ctx->narrow_ok = ok;
     }
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // nothing in flight may still read the old tables
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));  // nothing in flight may still read the old tables
     if (ctx->narrow_ok) {
         GF_HIP(ctx, ctx->d_nsnap.reserve(3 * (size_t)n_slots));
         GF_HIP(ctx, ctx->d_nwork.reserve(3 * (size_t)n_slots));
@@ -1061,7 +1143,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     GF_HIP(ctx, ctx->d_sched.reserve(3 * (size_t)n_slots));
     if (ctx->have_sched) {
         // h_table is free again only after the snapshot copy above has completed
-        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GF_HIP(ctx, gf_wait_stream(ctx->stream));
         for (int j = 0; j < 3; ++j)
             for (uint32_t s2 = 0; s2 < n_slots; ++s2)
                 ctx->h_table.ptr[(size_t)j * n_slots + s2] = slot_node[s2] == GF_NO_NODE ? 0 : ctx->sched[j][slot_node[s2]];
@@ -1123,7 +1205,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         ctx->zstride = zstride;
         ctx->zd_row0 = nz;
     }
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));
     ctx->n_x = n_x_slots;
     ctx->n_d = n_d_pos;
     ctx->n_slots = n_slots;
@@ -1166,15 +1248,15 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     GF_HIP(ctx, ctx->h_exec.reserve(total_k + 1));
     hipStream_t st = ctx->stream;
     GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
-    const int rc = launch(ctx, mode, algo, n_apps, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr, total_k,
-                          ctx->d_failed.ptr, st);
+    const int rc = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr,
+                          total_k, ctx->d_failed.ptr, st);
     if (rc != GF_OK) return rc;
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, st));
     if (total_k)
         GF_HIP(ctx, hipMemcpyAsync(ctx->h_exec.ptr, ctx->d_exec.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (mode == GF_MODE_FIFO_CHAIN)
         GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_failed.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
     if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
     if (mode == GF_MODE_FIFO_CHAIN && chain_failed_at) *chain_failed_at = ctx->h_failed.ptr[0];
@@ -1190,7 +1272,7 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
     if (n_apps > 0 && (!d_apps || !d_results)) return fail(ctx, GF_ERR_INVALID, "device apps/results must not be NULL");
     if (mode == GF_MODE_FIFO_CHAIN && !d_chain_failed_at) d_chain_failed_at = ctx->d_failed.ptr;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    return launch(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, st);
+    return launch(ctx, mode, algo, n_apps, nullptr, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, st);
 }
 
 int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
@@ -1269,7 +1351,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     // ---- device buffers
     const size_t N = n, R = n_res, Z = n_zones;
     const size_t NCH = (N + 1 + 63) / 64;  // chunks of the slot space (nodes + sentinel)
-    GF_HIP(ctx, hipStreamSynchronize(st));  // nothing in flight may still read buffers that are about to grow
+    GF_HIP(ctx, gf_wait_stream(st));  // nothing in flight may still read buffers that are about to grow
     GF_HIP(ctx, ctx->d_bi64.reserve(15 * N + 2 * N + 3 * R + 3 * Z + 3 * NCH + 16));
     GF_HIP(ctx, ctx->d_bu32.reserve(5 * N + R + 5 * Z + 16));
     const size_t temp = gangfit::snapshot_sort_temp_bytes(n);
@@ -1379,13 +1461,16 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
         GF_HIP(ctx, gangfit::launch_snapshot_finalize(f, st));
         GF_HIP(ctx, ctx->h_bcols.reserve(6 * N + 8));
         GF_HIP(ctx, ctx->h_border.reserve(N + 8));
-        long long* h_units = reinterpret_cast<long long*>(ctx->h_bcols.ptr);  // 3 values, then the scalars
+        long long* h_units = reinterpret_cast<long long*>(ctx->h_bcols.ptr);  // 3 units, then the 3 largest scaled magnitudes
         uint32_t* h_scalars = ctx->h_border.ptr;
-        GF_HIP(ctx, hipMemcpyAsync(h_units, d_units, 3 * sizeof(long long), hipMemcpyDeviceToHost, st));
+        GF_HIP(ctx, hipMemcpyAsync(h_units, d_units, 6 * sizeof(long long), hipMemcpyDeviceToHost, st));
         GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        GF_HIP(ctx, hipStreamSynchronize(st));
+        GF_HIP(ctx, gf_wait_stream(st));
         const uint32_t nz = h_scalars[0];
-        for (int j = 0; j < 3; ++j) ctx->unit[j] = (int64_t)h_units[j];
+        for (int j = 0; j < 3; ++j) {
+            ctx->unit[j] = (int64_t)h_units[j];
+            ctx->nmax[j] = (int64_t)h_units[3 + j];
+        }
         ctx->narrow_ok = h_scalars[1] == 0;
         ctx->have_sched = h_scalars[2] == 0;  // a negative schedulable value (overhead above allocatable) disables the efficiencies
         ctx->n_nodes = n;
@@ -1405,7 +1490,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
         ctx->host_stale = true;
         if (driver_order_out || exec_order_out || n_d_out || n_x_out) {  // the two lists, for callers that want them
             GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            GF_HIP(ctx, hipStreamSynchronize(st));
+            GF_HIP(ctx, gf_wait_stream(st));
             uint32_t nd = 0, nx = 0;
             for (size_t i = 0; i < N; ++i) {
                 const uint32_t node = ctx->h_border.ptr[i];
@@ -1428,7 +1513,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     GF_HIP(ctx, ctx->h_border.reserve(N));
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_bcols.ptr, d_avail, 6 * N * sizeof(int64_t), hipMemcpyDeviceToHost, st));  // avail | sched
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     // ---- the two candidate lists (nodesorting.go:47-63) and the optional stable label re-sorts (:161-199)
     const int64_t* h_avail = ctx->h_bcols.ptr;
     const int64_t* h_sched = ctx->h_bcols.ptr + 3 * N;
@@ -1508,7 +1593,7 @@ int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, cons
                                              reserved ? ctx->d_xreserved.ptr : nullptr, n_req, ctx->d_xexe.ptr,
                                              with_hosts ? ctx->d_xhosts.ptr : nullptr, words, ctx->d_xout.ptr, st));
     GF_HIP(ctx, hipMemcpyAsync(node_out, ctx->d_xout.ptr, (size_t)n_req * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     return GF_OK;
 }
 
@@ -1562,7 +1647,7 @@ int gf_find_nodes(gf_ctx* ctx, int chained, uint32_t n_req, const int64_t* exe, 
         GF_HIP(ctx, hipMemcpyAsync(exec_nodes, ctx->d_exec.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (d_adds)
         GF_HIP(ctx, hipMemcpyAsync(reserved_adds, d_adds, (size_t)n_req * n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     return GF_OK;
 }
 
@@ -1711,7 +1796,7 @@ int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const 
                                                n_apps, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr,
                                                ctx->d_avg.ptr, st));
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_avg.ptr, ctx->d_avg.ptr, 4 * (size_t)n_apps * sizeof(double), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     static_assert(sizeof(gf_avg_efficiency) == 4 * sizeof(double), "gf_avg_efficiency layout");
     std::memcpy(out, ctx->h_avg.ptr, 4 * (size_t)n_apps * sizeof(double));
     return GF_OK;
@@ -1752,7 +1837,7 @@ int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const 
                                                   ctx->d_results.ptr, ctx->d_exec.ptr, ctx->d_reserved.ptr,
                                                   ctx->d_eff.ptr, st));
     GF_HIP(ctx, hipMemcpyAsync(eff_out, ctx->d_eff.ptr, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, hipStreamSynchronize(st));
+    GF_HIP(ctx, gf_wait_stream(st));
     return GF_OK;
 }
 
@@ -1766,7 +1851,7 @@ int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
     GF_HIP(ctx, ctx->h_table.reserve(3 * (size_t)ctx->n_slots));
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_table.ptr, ctx->d_work.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));
     const int64_t* t = ctx->h_table.ptr;
     for (uint32_t n = 0; n < ctx->n_nodes; ++n) {
         const uint32_t s = ctx->h_node_slot[n];
@@ -1788,7 +1873,7 @@ int gf_timer_end(gf_ctx* ctx, float* elapsed_ms) {
     GF_DELEGATE(ctx, gf_timer_end(ctx, elapsed_ms));
     if (!ctx || !elapsed_ms) return GF_ERR_INVALID;
     GF_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->timer_stream ? ctx->timer_stream : ctx->stream));
-    GF_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    GF_HIP(ctx, gf_wait_event(ctx->ev_end));
     GF_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
     return GF_OK;
 }
@@ -1798,7 +1883,7 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));
     if (out) {
         ScanStats s;
         GF_HIP(ctx, hipMemcpy(&s, ctx->d_stats.ptr, sizeof s, hipMemcpyDeviceToHost));
@@ -1810,7 +1895,7 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
     }
     if (reset) {  // on the context's stream: a null-stream memset is not ordered against a non-blocking stream
         GF_HIP(ctx, hipMemsetAsync(ctx->d_stats.ptr, 0, sizeof(ScanStats), ctx->stream));
-        GF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GF_HIP(ctx, gf_wait_stream(ctx->stream));
     }
     ctx->stats_on = enable != 0;
     return GF_OK;
@@ -1826,7 +1911,7 @@ int gf_selftest(gf_ctx* ctx, uint64_t seed, uint32_t n_cases, uint32_t* mismatch
     hipError_t e = hipMemsetAsync(d.ptr, 0, sizeof(uint32_t), ctx->stream);
     if (e == hipSuccess) e = gangfit::launch_selftest(seed, n_cases, d.ptr, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = gf_wait_stream(ctx->stream);
     d.release();
     if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "selftest failed: %s", hipGetErrorString(e));
     return GF_OK;
@@ -1943,7 +2028,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
     GF_HIP(g, hipMemcpyAsync(g->h_results.ptr, first->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, first->stream));
     if (total_k)
         GF_HIP(g, hipMemcpyAsync(g->h_exec.ptr, first->g_exec2.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, first->stream));
-    GF_HIP(g, hipStreamSynchronize(first->stream));
+    GF_HIP(g, gf_wait_stream(first->stream));
     std::memcpy(results, g->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
     if (total_k) std::memcpy(exec_nodes, g->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
     return GF_OK;

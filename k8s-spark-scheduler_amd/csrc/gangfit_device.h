@@ -84,6 +84,11 @@ struct NApp {  // 64 bytes, produced by prepare_apps_kernel: requests divided by
 };
 static_assert(sizeof(NApp) == 64, "NApp must be 64 bytes");
 
+// d_dst = d_src * factor[dimension] for the 3 * n_slots table values and the 3 * n_chunks chunk maxima; sentinel values
+// (<= INT32_MIN / 2: empty slots) are kept.
+hipError_t launch_narrow_rescale(const int32_t* d_src, int32_t* d_dst, uint32_t n_slots, const int32_t* d_cmax_src,
+                                 int32_t* d_cmax_dst, uint32_t n_chunks, const int32_t factor[3], hipStream_t stream);
+
 struct NarrowTable {  // value = scaled value * unit[dimension]
     int32_t* cpu;  // [n_slots] working copy, scaled
     int32_t* mem;

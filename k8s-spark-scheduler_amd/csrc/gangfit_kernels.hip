@@ -1997,6 +1997,36 @@ hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps,
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void narrow_rescale_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst,
+                                                             uint32_t n_slots, const int32_t* __restrict__ cm_src,
+                                                             int32_t* __restrict__ cm_dst, uint32_t n_chunks, int32_t f0,
+                                                             int32_t f1, int32_t f2) {
+    const size_t n_tab = 3 * (size_t)n_slots, n_all = n_tab + 3 * (size_t)n_chunks;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += stride) {
+        const bool tab = i < n_tab;
+        const size_t k = tab ? i : i - n_tab;
+        const uint32_t dim = (uint32_t)(k / (tab ? n_slots : n_chunks));
+        const int32_t f = dim == 0 ? f0 : (dim == 1 ? f1 : f2);
+        const int32_t v = tab ? src[k] : cm_src[k];
+        const int32_t o = v <= INT32_MIN / 2 ? v : v * f;  // empty slots / all-empty chunks keep their sentinel
+        if (tab)
+            dst[k] = o;
+        else
+            cm_dst[k] = o;
+    }
+}
+
+hipError_t launch_narrow_rescale(const int32_t* d_src, int32_t* d_dst, uint32_t n_slots, const int32_t* d_cmax_src,
+                                 int32_t* d_cmax_dst, uint32_t n_chunks, const int32_t factor[3], hipStream_t stream) {
+    const size_t n_all = 3 * ((size_t)n_slots + n_chunks);
+    if (n_all == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n_all + 255) / 256 < 2048 ? (n_all + 255) / 256 : 2048);
+    hipLaunchKernelGGL(narrow_rescale_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, n_slots, d_cmax_src, d_cmax_dst,
+                       n_chunks, factor[0], factor[1], factor[2]);
+    return hipGetLastError();
+}
+
 hipError_t launch_shard_push(const void* d_src, const PeerPtrs& dsts, size_t dst_offset, size_t bytes, hipStream_t stream) {
     const size_t n16 = bytes / 16;
     if (n16 == 0 || dsts.n == 0) return hipSuccess;

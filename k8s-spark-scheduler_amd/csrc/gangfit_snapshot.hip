@@ -280,11 +280,17 @@ __global__ __launch_bounds__(256) void finalize_narrow_zones_kernel(SnapshotFina
     for (int j = 0; j < 3; ++j) {
         if (s < ns) f.d_nsnap[(size_t)j * ns + s] = v[j];
         int32_t m = s < ns ? v[j] : INT32_MIN;
+        int32_t mag = real ? (v[j] < 0 ? -v[j] : v[j]) : 0;  // largest |scaled value|: how far a batch may refine the units
         for (int d = 1; d < 64; d <<= 1) {
             const int32_t o = __shfl_xor(m, d, 64);
             m = o > m ? o : m;
+            const int32_t g = __shfl_xor(mag, d, 64);
+            mag = g > mag ? g : mag;
         }
-        if (lane == 0 && c < f.n_chunks) f.d_ncmax[(size_t)j * f.n_chunks + c] = m;
+        if (lane == 0 && c < f.n_chunks) {
+            f.d_ncmax[(size_t)j * f.n_chunks + c] = m;
+            atomicMax(reinterpret_cast<unsigned long long*>(f.d_units) + 3 + j, (unsigned long long)mag);
+        }
     }
     uint32_t ei = GF_NO_NODE;
     bool xbit = false, dbit = false;
@@ -309,6 +315,7 @@ hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t strea
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(f.d_zhasx, 0, (size_t)f.n_zones * sizeof(uint32_t), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(f.d_scalars, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(f.d_units + 3, 0, 3 * sizeof(long long), stream)) != hipSuccess) return e;  // largest scaled magnitudes
     const dim3 block(256), grid((unsigned)(((size_t)f.n_chunks * 64 + 255) / 256));
     hipLaunchKernelGGL(finalize_slots_kernel, grid, block, 0, stream, f);
     hipLaunchKernelGGL(finalize_reduce_kernel, dim3(1), block, 0, stream, f);
