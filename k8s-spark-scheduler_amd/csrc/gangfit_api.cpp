@@ -146,6 +146,14 @@ struct gf_ctx {
     bool merged = false;       // slot space is the merged order (see NodeTable)
     uint32_t shard = 0, n_shards = 1;  // node-range sharding (gf_shard_set)
     DeviceBuf<uint64_t> d_masks;  // xmask | dmask, n_chunks each
+    // sparse gpu view of the executor order (gangfit::SparseTable): compact table | node ids + slot map | maxima | masks
+    DeviceBuf<int64_t> d_gtab, d_gcmax;
+    DeviceBuf<uint32_t> d_gidx;   // slot_node of the sub-slots (n_gpad), then sub_of_slot (n_slots)
+    DeviceBuf<uint64_t> d_gmask;
+    PinnedBuf<int64_t> h_gtab;
+    PinnedBuf<uint32_t> h_gidx;
+    uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
+    bool sparse_gpu = true;        // GANGFIT_SPARSE_GPU=0 disables the view
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::DevApp> d_dev_apps;  // FIFO chain: app records with reciprocals (prepare_apps_kernel)
     DeviceBuf<gangfit::NApp> d_napps;       // the same in the narrow domain
@@ -292,6 +300,21 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     t.xmask = ctx->d_masks.ptr;
     t.dmask = ctx->d_masks.ptr + ctx->n_chunks;
     return t;
+}
+
+gangfit::SparseTable make_sparse(gf_ctx* ctx) {
+    gangfit::SparseTable g{};
+    if (ctx->n_g == 0) return g;
+    g.cpu = ctx->d_gtab.ptr;
+    g.mem = g.cpu + ctx->n_gpad;
+    g.gpu = g.mem + ctx->n_gpad;
+    g.slot_node = ctx->d_gidx.ptr;
+    g.sub_of_slot = ctx->d_gidx.ptr + ctx->n_gpad;
+    g.cmax = ctx->d_gcmax.ptr;
+    g.xmask = ctx->d_gmask.ptr;
+    g.n_x = ctx->n_g;
+    g.n_chunks = ctx->n_gpad / 64;
+    return g;
 }
 
 gangfit::EffTables slot_eff_tables(gf_ctx* ctx, const int64_t* avail_base) {
@@ -514,8 +537,8 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     }
     ScanStats* stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
     if (mode == GF_MODE_INDEPENDENT) {
-        GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), n_apps, d_apps, d_results,
-                                                    d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
+        GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps,
+                                                    d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
     } else if (mode == GF_MODE_FIFO_CHAIN) {
         // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303)
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
@@ -645,6 +668,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (const char* z = std::getenv("GANGFIT_FIFO_SOLO")) ctx->fifo_solo = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
     if (const char* z = std::getenv("GANGFIT_MINFRAG_MATRIX")) ctx->fifo_minfrag_matrix = std::strcmp(z, "0") != 0;
+    if (const char* z = std::getenv("GANGFIT_SPARSE_GPU")) ctx->sparse_gpu = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;
     if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
         const long v = std::atol(l);
@@ -689,6 +713,12 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_cmax.release();
     ctx->d_masks.release();
     ctx->h_masks.release();
+    ctx->d_gtab.release();
+    ctx->d_gcmax.release();
+    ctx->d_gidx.release();
+    ctx->d_gmask.release();
+    ctx->h_gtab.release();
+    ctx->h_gidx.release();
     ctx->d_dev_apps.release();
     ctx->d_napps.release();
     ctx->d_wide_needed.release();
@@ -1139,6 +1169,55 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     if (n_nodes)
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_node_slot.ptr, nslot, (size_t)n_nodes * sizeof(uint32_t),
                                    hipMemcpyHostToDevice, ctx->stream));
+    // ---- sparse gpu view (gangfit::SparseTable): the executor candidates with a free gpu as a compact table of their own,
+    //      when they are a minority of the order (merged layout only: the independent kernel's fast path)
+    ctx->n_g = ctx->n_gpad = 0;
+    if (mergeable && ctx->sparse_gpu) {
+        uint32_t n_g = 0;
+        for (uint32_t s2 = 0; s2 < merged.size(); ++s2)
+            if ((mflags[s2] & 1) && tgpu[s2] > 0) ++n_g;
+        if (n_g > 0 && (uint64_t)n_g * 4 <= merged.size()) {
+            const uint32_t n_gpad = (n_g + 63u) / 64u * 64u, gch = n_gpad / 64u;
+            GF_HIP(ctx, ctx->h_gtab.reserve(3 * (size_t)n_gpad + 3 * (size_t)gch));
+            GF_HIP(ctx, ctx->h_gidx.reserve((size_t)n_gpad + n_slots));
+            int64_t* g0 = ctx->h_gtab.ptr;
+            int64_t* gmax = g0 + 3 * (size_t)n_gpad;
+            uint32_t* gnode = ctx->h_gidx.ptr;
+            uint32_t* gsub = gnode + n_gpad;
+            for (uint32_t i = 0; i < 3 * n_gpad; ++i) g0[i] = kSentinelAvail;
+            for (uint32_t i = 0; i < n_gpad; ++i) gnode[i] = GF_NO_NODE;
+            for (uint32_t s2 = 0; s2 < n_slots; ++s2) gsub[s2] = GF_NO_NODE;
+            uint32_t k = 0;
+            for (uint32_t s2 = 0; s2 < merged.size(); ++s2)
+                if ((mflags[s2] & 1) && tgpu[s2] > 0) {
+                    g0[k] = tcpu[s2];
+                    g0[n_gpad + k] = tmem[s2];
+                    g0[2 * (size_t)n_gpad + k] = tgpu[s2];
+                    gnode[k] = slot_node[s2];
+                    gsub[s2] = k++;
+                }
+            for (int j = 0; j < 3; ++j)
+                for (uint32_t c = 0; c < gch; ++c) {
+                    int64_t m = INT64_MIN;
+                    for (uint32_t i = c * 64; i < (c + 1) * 64; ++i) m = g0[(size_t)j * n_gpad + i] > m ? g0[(size_t)j * n_gpad + i] : m;
+                    gmax[(size_t)j * gch + c] = m;
+                }
+            GF_HIP(ctx, ctx->d_gtab.reserve(3 * (size_t)n_gpad));
+            GF_HIP(ctx, ctx->d_gcmax.reserve(3 * (size_t)gch));
+            GF_HIP(ctx, ctx->d_gidx.reserve((size_t)n_gpad + n_slots));
+            GF_HIP(ctx, ctx->d_gmask.reserve(gch));
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gtab.ptr, g0, 3 * (size_t)n_gpad * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gcmax.ptr, gmax, 3 * (size_t)gch * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gidx.ptr, gnode, ((size_t)n_gpad + n_slots) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                       ctx->stream));
+            std::vector<uint64_t> gm(gch, 0);
+            for (uint32_t i = 0; i < n_g; ++i) gm[i >> 6] |= 1ull << (i & 63);
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gmask.ptr, gm.data(), gch * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+            GF_HIP(ctx, gf_wait_stream(ctx->stream));  // gm is a local
+            ctx->n_g = n_g;
+            ctx->n_gpad = n_gpad;
+        }
+    }
     // ---- SchedulableResources in slot order (efficiencies); empty slots read 0
     GF_HIP(ctx, ctx->d_sched.reserve(3 * (size_t)n_slots));
     if (ctx->have_sched) {
@@ -1478,6 +1557,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
         ctx->zone.clear();
         if (zone_of_node) ctx->zone.assign(zone_of_node, zone_of_node + N);
         ctx->n_x = ctx->n_d = n;
+        ctx->n_g = ctx->n_gpad = 0;  // the sparse gpu view is built by gf_orders_set only; the full order serves here
         ctx->n_slots = n_slots;
         ctx->n_chunks = n_chunks;
         ctx->d_identity = true;

@@ -40,6 +40,23 @@ struct NodeTable {
     uint32_t d_identity;        // 1: driver position == slot (merged layout)
 };
 
+// Sparse-dimension view of the executor order for the independent batch (merged layout): the executor candidates that have
+// at least one free gpu, in priority order, as a compact table of their own ("sub-slots").  gpu nodes are a minority of a
+// cluster, so a gang whose executors need a gpu collects them from a few slots of MANY 64-slot chunks of the full order —
+// a chain of dependent round trips that makes it the slowest wavefront of a launch.  Every node left out has capacity 0 for
+// such a request (available gpu <= 0 < request), so scanning the compact table instead gives the same placements.
+struct SparseTable {
+    const int64_t* cpu;  // [n_sub + pad] values of the sub-slots (the padding slots never fit)
+    const int64_t* mem;
+    const int64_t* gpu;
+    const uint32_t* slot_node;    // sub-slot -> caller's node index
+    const int64_t* cmax;          // [3][n_chunks] chunk maxima of the compact table
+    const uint64_t* xmask;        // [n_chunks] all sub-slots are executor candidates
+    const uint32_t* sub_of_slot;  // [n_slots of the full table] slot -> sub-slot, GF_NO_NODE when the slot is not in the view
+    uint32_t n_x;                 // sub-slots (0 = no sparse view: the kernel uses the full table)
+    uint32_t n_chunks;
+};
+
 // Zone view of the two candidate orders for the single-AZ packers (LIB/binpack/single_az.go:23-72): zone zi of the
 // evaluation list keeps only its own nodes of driverNodePriorityOrder / executorNodePriorityOrder, order preserved —
 // i.e. the same slot table scanned through per-zone candidate bit masks.  The evaluation list is driverZonesInOrder
@@ -109,8 +126,8 @@ struct ScanStats {
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).
-hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t n_apps, const gf_app* d_apps,
-                                  gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
+                                  const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
 
 // FIFO chain (fitEarlierDrivers + final pack).  One workgroup walks the chain; three kernels:

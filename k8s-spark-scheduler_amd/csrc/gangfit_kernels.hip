@@ -19,6 +19,8 @@
 // loads) and fit_fifo_chain_kernel (one workgroup walks the chain, table front resident in LDS).
 // No MFMA (nothing here is a contraction) — see DESIGN.md for the roofline discussion.
 
+#include <type_traits>
+
 #include "gangfit_device.h"
 
 namespace gangfit {
@@ -858,7 +860,8 @@ template <int ALGO, class View, bool SLOTS>
 __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, const App& app,
                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
                                                 uint32_t* __restrict__ scratch_b, int lane, unsigned long long& xvis,
-                                                unsigned long long& dvis, const Group0* g0p = nullptr) {
+                                                unsigned long long& dvis, const Group0* g0p = nullptr,
+                                                const SparseTable* gpu_view = nullptr) {
     Decision dec;
     dec.feasible = false;
     dec.ds = 0;
@@ -867,6 +870,10 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
     int64_t p0 = -1;
     uint32_t p0_node = GF_NO_NODE;
     ScanPre pre;
+    // executors that need a gpu are packed from the compact table of gpu nodes (SparseTable); wave-uniform
+    const bool sparse = gpu_view != nullptr && gpu_view->n_x != 0 && app.exe2 > 0 && K > 0 && O.d_identity &&
+                        (ALGO == GF_ALGO_TIGHTLY_PACK || ALGO == GF_ALGO_DISTRIBUTE_EVENLY);
+    uint32_t p0_sub = GF_NO_NODE;
     if (O.d_identity && ALGO != GF_ALGO_MINIMAL_FRAGMENTATION) {
         // Merged layout (driver position == slot): the chunk masks of group 0 for BOTH roles in one round trip (the
         // maxima are the same words), then the first candidate chunk of both roles — and the node ids — in one more.
@@ -875,20 +882,21 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
         const uint64_t dcand = g0.dcand;
         pre.cand = g0.xcand;
         const bool okd = g0.ind & (g0.m0 >= app.drv0) & (g0.m1 >= app.drv1) & (g0.m2 >= app.drv2) & (dcand != 0);
-        const bool okx = g0.inx & (g0.m0 >= app.exe0) & (g0.m1 >= app.exe1) & (g0.m2 >= app.exe2) & (pre.cand != 0);
+        const bool okx = !sparse & g0.inx & (g0.m0 >= app.exe0) & (g0.m1 >= app.exe1) & (g0.m2 >= app.exe2) & (pre.cand != 0);
         const uint64_t md = __ballot(okd);
         pre.m = __ballot(okx);
-        pre.on = true;
+        pre.on = !sparse;
         dvis += kWave;
         const int bd = md ? __ffsll((unsigned long long)md) - 1 : -1;
         pre.c = (K > 0 && pre.m) ? __ffsll((unsigned long long)pre.m) - 1 : -1;
         const uint32_t limit = O.n_d > O.n_x ? O.n_d : O.n_x;
         int64_t d0 = 0, d1 = 0, d2 = 0;
         const uint32_t id = (uint32_t)(bd < 0 ? 0 : bd) * kWave + lane, ix = (uint32_t)(pre.c < 0 ? 0 : pre.c) * kWave + lane;
-        uint32_t dnode = GF_NO_NODE;
+        uint32_t dnode = GF_NO_NODE, dsub = GF_NO_NODE;
         if (bd >= 0 && id < limit) {
             V.load(id, d0, d1, d2);
             if (!SLOTS) dnode = O.slot_node[id];  // the result needs the driver's node id: not one more round trip at the end
+            if (sparse) dsub = gpu_view->sub_of_slot[id];  // where the driver's reservation lands in the compact table
         }
         if (pre.c >= 0 && ix < limit) {
             if (pre.c != bd) V.load(ix, pre.a0, pre.a1, pre.a2);
@@ -909,6 +917,7 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
                 const int fl = __ffsll((unsigned long long)fm) - 1;
                 p0 = (int64_t)bd * kWave + fl;
                 p0_node = read_lane(dnode, fl);
+                p0_sub = read_lane(dsub, fl);
             }
             from = ((uint32_t)bd + 1) * kWave;
         }
@@ -926,8 +935,38 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
         dec.feasible = true;
         return dec;
     }
-    // (2) executors with the driver reserved on that candidate — the common case ends here
     int64_t pass1 = 0;
+    if constexpr (std::is_same<View, GlobalView>::value && !SLOTS) {
+        if (sparse) {
+            // (2s) the same pack over the compact table of gpu nodes.  S_s = the capacity total with the driver reserved,
+            //      exactly what the full order would give (every node left out has capacity 0 for this request).
+            if (p0_node == GF_NO_NODE) p0_sub = gpu_view->sub_of_slot[ds];  // the driver came from the generic search
+            const GlobalView VS{const_cast<int64_t*>(gpu_view->cpu), const_cast<int64_t*>(gpu_view->mem),
+                                const_cast<int64_t*>(gpu_view->gpu), gpu_view->cmax, gpu_view->cmax + gpu_view->n_chunks,
+                                gpu_view->cmax + 2 * (size_t)gpu_view->n_chunks, gpu_view->xmask, gpu_view->xmask,
+                                gpu_view->n_chunks};
+            const Orders OS{gpu_view->slot_node, nullptr, gpu_view->n_x, 0u, true};
+            const int64_t S_s = wave_pack<ALGO, GlobalView, false>(VS, OS, app, p0_sub, out, scratch_a, scratch_b, lane, pass1,
+                                                                   xvis, ScanPre());
+            if (S_s >= K) {
+                dec.feasible = true;
+                dec.pass1 = pass1;
+                return dec;
+            }
+            // short: without the driver's reservation the total is S = S_s + cap(ds, 0) - cap(ds, drv) (exact below K: every
+            // term is).  Below K no other driver candidate can help (binpack.go:67-85 tries them all against the same
+            // nodes); otherwise — rare — the decision is redone on the full order below.
+            int64_t S = S_s;
+            if (p0_sub != GF_NO_NODE) {
+                int64_t a0, a1, a2;
+                VS.load(p0_sub, a0, a1, a2);
+                S += cap3(a0, a1, a2, app) - cap3(a0 - app.drv0, a1 - app.drv1, a2 - app.drv2, app);
+            }
+            if (S < K) return dec;
+        }
+    }
+    // (2) executors with the driver reserved on that candidate — the common case ends here
+    pass1 = 0;
     const int64_t S_d = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis, pre);
     if (S_d >= K) {
         dec.feasible = true;
@@ -974,7 +1013,7 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // One wave per app, 4 apps per workgroup.  Grid = ceil(n_apps / 4) >> 256 CUs at the target sizes.
 template <int ALGO>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
-    NodeTable T, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
+    NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
     uint32_t* __restrict__ exec_nodes, uint32_t* __restrict__ scratch, uint64_t scratch_half,
     ScanStats* __restrict__ stats) {
     const int lane = lane_id();
@@ -993,7 +1032,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     unsigned long long xvis = 0, dvis = 0;
     Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
                                                         scratch + scratch_half + app.exec_off, lane, xvis, dvis,
-                                                        merged ? &g0 : nullptr);
+                                                        merged ? &g0 : nullptr, &G);
     if (lane == 0) {
         gf_result r;
         r.has_capacity = dec.feasible ? 1 : 0;
@@ -1543,20 +1582,20 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
 
 // ------------------------------------------------------------------------------------------------ launchers
 
-hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, uint32_t n_apps, const gf_app* d_apps,
-                                  gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
+                                  const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_TIGHTLY_PACK>, grid, block, 0, stream, table, n_apps,
+        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_TIGHTLY_PACK>, grid, block, 0, stream, table, gpu_view, n_apps,
                            d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
     else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
-        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, grid, block, 0, stream, table, n_apps,
-                           d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
+        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, grid, block, 0, stream, table, gpu_view,
+                           n_apps, d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
     else
-        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, grid, block, 0, stream, table, n_apps,
+        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, grid, block, 0, stream, table, gpu_view, n_apps,
                            d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
     return hipGetLastError();
 }
@@ -1745,8 +1784,8 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
     const dim3 app_grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
     hipError_t e = hipSuccess;
     if (az_aware) {  // the plain TightlyPack answer first; the select kernel overwrites it where a zone wins
-        e = launch_fit_independent(GF_ALGO_TIGHTLY_PACK, table, n_apps, d_apps, d_results, d_exec_nodes, d_scratch,
-                                   scratch_half, nullptr, stream);
+        e = launch_fit_independent(GF_ALGO_TIGHTLY_PACK, table, SparseTable{}, n_apps, d_apps, d_results, d_exec_nodes,
+                                   d_scratch, scratch_half, nullptr, stream);
         if (e != hipSuccess) return e;
         if (buf.avg_out != nullptr) {
             e = launch_avg_efficiency(true, table, eff, buf.cnt, buf.n_cnt_waves, n_apps, d_apps, d_results,
