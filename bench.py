@@ -6,7 +6,7 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line o
                 pending-app table of the headline workload (10 000 nodes x 1 000 pending apps, SURVEY.md 8d
                 distributions), inputs already resident in HBM.
   * timing    = W warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides,
-                wall time = max over ranks.  A K-step window is 0.1-0.2 ms at the driver's K = 20, where one scheduler
+                wall time = max over ranks of (rank's clock from the opening barrier to its own synchronize after step K).  A K-step window is 0.1-0.2 ms at the driver's K = 20, where one scheduler
                 hiccup moves the figure by tens of percent, so `--windows` (default 9) such windows are timed and the
                 MEDIAN is reported; every window is listed under `timing`.
   * value     = decisions/sec of the whole job = n_gpus * apps_per_batch * K / median window.
@@ -220,9 +220,10 @@ def main():
         ctx.timer_begin(stream)
         for _ in range(steps):
             fn()
-        ev_ms = ctx.timer_end()  # HIP events on the launch stream; blocks until the last kernel is done
-        barrier()
-        wall = time.perf_counter() - t0
+        ev_ms = ctx.timer_end()  # HIP events on the launch stream; returns when the last kernel is done
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0  # this rank's K steps, device idle again; the slowest rank defines the window (MAX below)
+        barrier()                        # closes the bracket; its own latency (an RCCL barrier on N > 1) is not work of the K steps
         if dist is not None:
             t = torch.tensor([wall], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -319,16 +320,33 @@ def main():
         return lat, o
 
     if rank == 0 and world == 1:
-        # ---- the same batch through the host entry point: H2D of the app records + kernel + D2H of results and placements
+        # ---- the same batch through the host entry point (what a cgo caller pays): app records in host memory in, results and
+        #      placements in host memory out.  Called through the raw ctypes symbol with preallocated buffers — the numpy
+        #      marshalling of gangfit.Context.fit_batch costs more than the call itself and is not part of the library.
         try:
-            happs = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
-            e2e_wall, _, e2e_walls = timed(lambda: ctx.fit_batch(IND, TIGHT, happs), max(20, min(args.steps, 200)), 5,
-                                           min(args.windows, 5))
+            import ctypes as C
+
+            from gangfit import _native as N
+
+            happs, htotal = gangfit.with_offsets(gangfit.make_apps(w.drv, w.exe, w.k, w.flags))
+            hres = np.zeros(len(happs), dtype=N.RESULT_DTYPE)
+            hexec = np.zeros(htotal + 1, dtype=np.uint32)
+            lib, h = ctx._lib, ctx._h
+            pa, pr, pe = N.ptr(happs), N.ptr(hres), N.ptr(hexec)
+
+            def host_batch():
+                rc = lib.gf_fit_batch(h, IND, TIGHT, len(happs), pa, pr, pe, htotal, None)
+                if rc != 0:
+                    raise RuntimeError(f"gf_fit_batch: {rc}")
+
             e2e_steps = max(20, min(args.steps, 200))
+            e2e_wall, _, e2e_walls = timed(host_batch, e2e_steps, 5, min(args.windows, 5))
+            dres = d_res.cpu().numpy().view(N.RESULT_DTYPE)
             out["end_to_end"] = {
                 "decisions_per_s": len(happs) * e2e_steps / e2e_wall, "ms_per_batch": e2e_wall / e2e_steps * 1e3,
-                "entry_point": "gf_fit_batch: pageable host buffers in, results + placements out (H2D 64 KB + D2H ~64 KB per batch), "
-                               "snapshot resident", "windows": len(e2e_walls)}
+                "entry_point": "gf_fit_batch: app records in host memory in, results + placements in host memory out (64 KB + ~64 KB "
+                               "per batch, read / written by the kernel through pinned staging buffers), snapshot resident; blocking",
+                "windows": len(e2e_walls), "results_equal_device_resident_path": bool(np.array_equal(hres, dres)) if rank == 0 and world == 1 else None}
         except Exception as e:
             out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
         # ---- the latency half of the metric: FIFO Filter = chain of (apps-1) earlier drivers + the filtered one

@@ -154,6 +154,7 @@ struct gf_ctx {
     PinnedBuf<uint32_t> h_gidx;
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
     bool sparse_gpu = true;        // GANGFIT_SPARSE_GPU=0 disables the view
+    bool zero_copy = true;         // GANGFIT_ZEROCOPY=0: gf_fit_batch always stages through device buffers
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::DevApp> d_dev_apps;  // FIFO chain: app records with reciprocals (prepare_apps_kernel)
     DeviceBuf<gangfit::NApp> d_napps;       // the same in the narrow domain
@@ -669,6 +670,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
     if (const char* z = std::getenv("GANGFIT_MINFRAG_MATRIX")) ctx->fifo_minfrag_matrix = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SPARSE_GPU")) ctx->sparse_gpu = std::strcmp(z, "0") != 0;
+    if (const char* z = std::getenv("GANGFIT_ZEROCOPY")) ctx->zero_copy = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;
     if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
         const long v = std::atol(l);
@@ -1326,6 +1328,25 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     GF_HIP(ctx, ctx->h_results.reserve(n_apps));
     GF_HIP(ctx, ctx->h_exec.reserve(total_k + 1));
     hipStream_t st = ctx->stream;
+    // Small independent batches of the plain packers skip the three staging copies: the kernel reads the app records from
+    // the pinned staging buffer and writes results and placements straight into pinned host memory (posted PCIe writes,
+    // visible when the kernel has completed).  A copy engine round trip costs more than the whole kernel at these sizes.
+    if (ctx->zero_copy && mode == GF_MODE_INDEPENDENT && !is_zone_algo(algo) && ctx->have_orders &&
+        (uint64_t)n_apps * sizeof(gf_app) + total_k * sizeof(uint32_t) <= (UINT64_C(4) << 20)) {
+        void *da = nullptr, *dr = nullptr, *de = nullptr;
+        if (hipHostGetDevicePointer(&da, ctx->h_apps.ptr, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&dr, ctx->h_results.ptr, 0) == hipSuccess &&
+            hipHostGetDevicePointer(&de, ctx->h_exec.ptr, 0) == hipSuccess) {
+            const int rc0 = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
+                                   static_cast<gf_result*>(dr), static_cast<uint32_t*>(de), total_k, ctx->d_failed.ptr, st);
+            if (rc0 != GF_OK) return rc0;
+            GF_HIP(ctx, gf_wait_stream(st));
+            std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
+            if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
+            return GF_OK;
+        }
+        (void)hipGetLastError();
+    }
     GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
     const int rc = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr,
                           total_k, ctx->d_failed.ptr, st);
