@@ -195,6 +195,19 @@ int gf_fit_batch_dev(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
                      gf_result *d_results, uint32_t *d_exec_nodes, uint64_t exec_nodes_len,
                      int32_t *d_chain_failed_at, void *stream);
 
+/* Replayable launch sequences.  A 1 000-application batch occupies the device for a few microseconds — about what the
+ * host needs to submit one kernel — so a caller that evaluates the same device-resident tables over and over (bench.py; a
+ * host that re-checks its pending queue on every event) is bound by its own launch rate.  gf_graph_begin starts recording
+ * the device work of every *_dev call made on `stream` by the calling thread (nothing executes), gf_graph_end turns the
+ * recording into a graph; gf_graph_launch replays it — same kernels, same arguments, one submission.  `stream` must not be
+ * the NULL stream (NULL = the context's own stream, which is fine).  Snapshot, orders and every buffer the recorded calls
+ * named must stay as they are until the graph is destroyed; buffers must have reached their final size before recording
+ * (run the sequence once eagerly first).  The statistics counters of gf_scan_stats must be off while recording. */
+int gf_graph_begin(gf_ctx *ctx, void *stream);
+int gf_graph_end(gf_ctx *ctx, void *stream, void **graph_out);
+int gf_graph_launch(gf_ctx *ctx, void *graph, void *stream);
+void gf_graph_destroy(gf_ctx *ctx, void *graph);
+
 /* One decision through the batched path: the literal shape of binpack.SparkBinPackFunction
  * (LIB/binpack/binpack.go:43-48) for registry entries "gpu-tightly-pack" / "gpu-distribute-evenly". */
 int gf_spark_binpack(gf_ctx *ctx, gf_algo algo, const gf_app *app, gf_result *result, uint32_t *exec_nodes,

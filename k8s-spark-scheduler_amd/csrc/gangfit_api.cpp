@@ -1375,6 +1375,46 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
     return launch(ctx, mode, algo, n_apps, nullptr, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, st);
 }
 
+int gf_graph_begin(gf_ctx* ctx, void* stream) {
+    GF_DELEGATE(ctx, gf_graph_begin(ctx, stream));
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, gf_wait_stream(st));
+    GF_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    return GF_OK;
+}
+
+int gf_graph_end(gf_ctx* ctx, void* stream, void** graph_out) {
+    GF_DELEGATE(ctx, gf_graph_end(ctx, stream, graph_out));
+    if (!ctx || !graph_out) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    *graph_out = nullptr;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipGraph_t graph = nullptr;
+    GF_HIP(ctx, hipStreamEndCapture(st, &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    *graph_out = exec;
+    return GF_OK;
+}
+
+int gf_graph_launch(gf_ctx* ctx, void* graph, void* stream) {
+    GF_DELEGATE(ctx, gf_graph_launch(ctx, graph, stream));
+    if (!ctx || !graph) return GF_ERR_INVALID;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    GF_HIP(ctx, hipGraphLaunch(static_cast<hipGraphExec_t>(graph), st));
+    return GF_OK;
+}
+
+void gf_graph_destroy(gf_ctx* ctx, void* graph) {
+    (void)ctx;
+    if (graph) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph));
+}
+
 int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
                      uint64_t exec_nodes_cap) {
     return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);

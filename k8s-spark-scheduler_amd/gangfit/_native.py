@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = [
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
     "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
+    "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy",
 ]
 
 
@@ -110,6 +111,14 @@ def load() -> C.CDLL:
     L.gf_packing_efficiencies.argtypes = [p, i32, p, p, p, p]
     L.gf_hbm_probe.restype = i32
     L.gf_hbm_probe.argtypes = [p, u64, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.gf_graph_begin.restype = i32
+    L.gf_graph_begin.argtypes = [p, p]
+    L.gf_graph_end.restype = i32
+    L.gf_graph_end.argtypes = [p, p, C.POINTER(p)]
+    L.gf_graph_launch.restype = i32
+    L.gf_graph_launch.argtypes = [p, p, p]
+    L.gf_graph_destroy.restype = None
+    L.gf_graph_destroy.argtypes = [p, p]
     L.gf_launch_floor.restype = i32
     L.gf_launch_floor.argtypes = [p, p, u32, C.POINTER(C.c_float)]
     L.gf_snapshot_build.restype = i32

@@ -244,6 +244,21 @@ class Context:
                                                C.c_void_p(d_failed_at) if d_failed_at else None,
                                                C.c_void_p(stream) if stream else None))
 
+    # -- replayable launch sequences (gf_graph_*)
+    def graph_begin(self, stream: int = 0):
+        self._check(self._lib.gf_graph_begin(self._h, C.c_void_p(stream) if stream else None))
+
+    def graph_end(self, stream: int = 0) -> int:
+        g = C.c_void_p()
+        self._check(self._lib.gf_graph_end(self._h, C.c_void_p(stream) if stream else None, C.byref(g)))
+        return g.value
+
+    def graph_launch(self, graph: int, stream: int = 0):
+        self._check(self._lib.gf_graph_launch(self._h, C.c_void_p(graph), C.c_void_p(stream) if stream else None))
+
+    def graph_destroy(self, graph: int):
+        self._lib.gf_graph_destroy(self._h, C.c_void_p(graph))
+
     def timer_begin(self, stream: int = 0):
         self._check(self._lib.gf_timer_begin(self._h, C.c_void_p(stream) if stream else None))
 

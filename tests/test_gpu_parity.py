@@ -400,3 +400,41 @@ def test_argument_errors(gf_ctx):
         gf_ctx.fit_batch(IND, 7, _gpu_apps([[0, 0, 0]], [[1, 1, 0]], [1]))
     with pytest.raises(gangfit.GangfitError):
         gf_ctx.set_snapshot([[1 << 62, 1, 0]])
+
+
+def test_recorded_graph_replays_the_same_batches(gf_ctx):
+    """gf_graph_begin / end / launch: the recorded *_dev calls replay with the same results as the eager calls."""
+    import torch
+
+    from gangfit import workloads as wl
+
+    w = wl.headline(3000, 300)
+    s = w.snapshot
+    gf_ctx.set_snapshot(s.avail, s.sched)
+    gf_ctx.set_orders(s.driver_order, s.exec_order)
+    apps, total_k = gangfit.with_offsets(gangfit.make_apps(w.drv, w.exe, w.k))
+    dev = torch.device("cuda:0")
+    d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
+    outs = []
+    for algo in (TIGHT, EVEN):
+        d_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
+        d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+        gf_ctx.fit_batch_dev(IND, algo, len(apps), d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k)
+        torch.cuda.synchronize()
+        want_res, want_exec = d_res.clone(), d_exec.clone()
+        gf_ctx.graph_begin()
+        for _ in range(4):
+            gf_ctx.fit_batch_dev(IND, algo, len(apps), d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k)
+        g = gf_ctx.graph_end()
+        for _ in range(3):
+            d_res.zero_()
+            d_exec.zero_()
+            torch.cuda.synchronize()
+            gf_ctx.graph_launch(g)
+            gf_ctx.timer_begin()
+            gf_ctx.timer_end()  # waits for the context's stream
+            assert torch.equal(d_res, want_res) and torch.equal(d_exec, want_exec)
+        gf_ctx.graph_destroy(g)
+        outs.append(want_res)
+    ref = ob.fit_independent(TIGHT, s.avail, ob.make_apps(w.drv, w.exe, w.k), s.driver_order, s.exec_order, closed_form=True)
+    assert np.array_equal(outs[0].cpu().numpy().view(gangfit._native.RESULT_DTYPE), ref.results)
