@@ -212,6 +212,8 @@ struct gf_ctx {
     DeviceBuf<gf_shard_driver> g_drv_loc, g_drv_all;
     DeviceBuf<uint32_t> g_exec2;                         // 2 * half: placements (node + 1) | capacities
     hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};    // behind partials+push | drivers+push | emit
+    hipStream_t join_stream = nullptr;                   // group object only: where the shards' events are joined
+    hipEvent_t join_ev[2] = {nullptr, nullptr};
 
     // findNodes requests (gf_find_nodes)
     DeviceBuf<int32_t> d_fk;
@@ -634,6 +636,12 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
                 (void)hipGetLastError();
             }
         g->info = g->group[0]->info;
+        if (hipSetDevice(g->device) != hipSuccess || hipStreamCreateWithFlags(&g->join_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&g->join_ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->join_ev[1], hipEventDisableTiming) != hipSuccess) {
+            gf_destroy(g);
+            return GF_ERR_HIP;
+        }
         *out = g;
         return GF_OK;
     }
@@ -699,6 +707,9 @@ void gf_destroy(gf_ctx* ctx) {
         for (gf_ctx* s : ctx->group) gf_destroy(s);
         ctx->group.clear();
         (void)hipSetDevice(ctx->device);
+        for (hipEvent_t& e : ctx->join_ev)
+            if (e) (void)hipEventDestroy(e);
+        if (ctx->join_stream) (void)hipStreamDestroy(ctx->join_stream);
         ctx->h_apps.release();
         ctx->h_results.release();
         ctx->h_exec.release();
@@ -1470,15 +1481,36 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     const int64_t* cols[3] = {alloc_cpu_milli, alloc_mem_bytes, alloc_gpu};
     const int64_t* ocols[3] = {over_cpu_milli, over_mem_bytes, over_gpu};
     const int64_t* rcols[3] = {res_cpu_milli, res_mem_bytes, res_gpu};
-    const int64_t lim = GF_MAX_ABS_QUANTITY >> 12;  // headroom for the sums: 4096 full-size terms still fit
+    const int64_t lim = GF_MAX_ABS_QUANTITY >> 1;
+    int64_t max_res[3] = {0, 0, 0}, max_over[3] = {0, 0, 0};
     for (int j = 0; j < 3; ++j) {
-        for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t i = 0; i < n; ++i) {
             if (cols[j][i] < 0 || cols[j][i] >= GF_MAX_ABS_QUANTITY || (with_over && (ocols[j][i] < 0 || ocols[j][i] >= lim)))
                 return fail(ctx, GF_ERR_INVALID, "allocatable / overhead value out of range at node %u", i);
-        for (uint32_t i = 0; i < n_res; ++i)
+            if (with_over && ocols[j][i] > max_over[j]) max_over[j] = ocols[j][i];
+        }
+        for (uint32_t i = 0; i < n_res; ++i) {
             if (rcols[j][i] < 0 || rcols[j][i] >= lim) return fail(ctx, GF_ERR_INVALID, "reservation %u out of range", i);
+            if (rcols[j][i] > max_res[j]) max_res[j] = rcols[j][i];
+        }
     }
     if ((uint64_t)n_res >= (1ull << 32) - 1) return fail(ctx, GF_ERR_INVALID, "too many reservations");
+    {  // the per-node sums (usage + overhead) must stay below 2^62: the device accumulates in 64 bits and would wrap silently.
+        // Coarse bound first (every entry on one node); only when that fails, the real per-node entry counts.
+        auto fits = [&](uint64_t count) {
+            for (int j = 0; j < 3; ++j)
+                if ((unsigned __int128)count * (uint64_t)max_res[j] + (uint64_t)max_over[j] >= (unsigned __int128)GF_MAX_ABS_QUANTITY) return false;
+            return true;
+        };
+        if (!fits(n_res)) {
+            std::vector<uint32_t> cnt(n, 0);
+            uint32_t most = 0;
+            for (uint32_t i = 0; i < n_res; ++i)
+                if (res_node[i] < n && ++cnt[res_node[i]] > most) most = cnt[res_node[i]];
+            if (!fits(most))
+                return fail(ctx, GF_ERR_INVALID, "the reservations of one node (%u entries) can sum past 2^62: not representable", most);
+        }
+    }
     if (n == 0) {
         int rc = gf_snapshot_set(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         if (rc != GF_OK) return rc;
@@ -2123,14 +2155,17 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         if (s > 0) exec_others.p[exec_others.n++] = c->g_exec2.ptr;
     }
     part_all.n = drv_all.n = S;
-    auto everyone_waits = [&](int which) -> hipError_t {  // stream t continues only behind event `which` of every other shard
-        for (uint32_t t = 0; t < S; ++t) {
-            hipError_t e = hipSetDevice(g->group[t]->device);
-            for (uint32_t s = 0; s < S && e == hipSuccess; ++s)
-                if (s != t) e = hipStreamWaitEvent(g->group[t]->stream, g->group[s]->g_ev[which], 0);
-            if (e != hipSuccess) return e;
+    // Every stream continues only behind event `which` of every shard: the first device's join stream waits for the S events
+    // and records one join event all streams wait for — 2 S + 1 runtime calls per exchange instead of S (S - 1).
+    auto everyone_waits = [&](int which) -> hipError_t {
+        hipError_t e = hipSetDevice(first->device);
+        for (uint32_t s = 0; s < S && e == hipSuccess; ++s) e = hipStreamWaitEvent(g->join_stream, g->group[s]->g_ev[which], 0);
+        if (e == hipSuccess) e = hipEventRecord(g->join_ev[which], g->join_stream);
+        for (uint32_t t = 0; t < S && e == hipSuccess; ++t) {
+            e = hipSetDevice(g->group[t]->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(g->group[t]->stream, g->join_ev[which], 0);
         }
-        return hipSuccess;
+        return e;
     };
     // ---- step 1: per-range capacity sums, gathered everywhere
     for (uint32_t s = 0; s < S; ++s) {

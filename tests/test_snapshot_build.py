@@ -96,3 +96,23 @@ def test_config5_size_and_argument_errors(gf_ctx):
     bad["zone"] = np.full(100000, 7, dtype=np.uint32)
     with pytest.raises(gangfit.GangfitError):
         gf_ctx.build_snapshot(**bad)
+
+
+@pytest.mark.gpu
+def test_sums_that_could_wrap_are_refused(gf_ctx):
+    """The replay accumulates in 64 bits on the device: a node whose reservations can sum past 2^62 must be refused (the shim
+    then falls back to Go), never wrapped.  Large values spread over many nodes are fine."""
+    n = 8
+    alloc = np.tile(np.array([[64000, 256 * GIB, 0]], dtype=np.int64), (n, 1))
+    flags = np.full(n, ps.READY | ps.DRIVER_CANDIDATE, dtype=np.uint32)
+    ranks = np.arange(n, dtype=np.uint32)
+    big = np.int64(1) << 58
+    req = np.tile(np.array([[1000, big, 0]], dtype=np.int64), (20, 1))
+    with pytest.raises(gangfit.GangfitError) as e:  # 20 x 2^58 on one node > 2^62
+        gf_ctx.build_snapshot(alloc, flags, ranks, res_node=np.zeros(20, dtype=np.uint32), res_req=req)
+    assert e.value.code == gangfit._native.GF_ERR_INVALID
+    node = (np.arange(20) % n).astype(np.uint32)  # at most 3 per node: 3 x 2^58 < 2^62
+    D, X = gf_ctx.build_snapshot(alloc, flags, ranks, res_node=node, res_req=req)
+    avail, _, _, _ = ps.build(alloc, flags, ranks, res_node=node, res_req=req)
+    got, _ = gf_ctx.snapshot()
+    assert np.array_equal(got, avail)
