@@ -99,6 +99,21 @@ def cpu_baseline_variants(n_nodes, n_apps, budget_s: float = 3.0):
 
     n_done, dt = _cpu_worker((n_nodes, n_apps, budget_s, True))
     out = {"closed_form_1_core": {"value": n_done / dt, "unit": "decisions/s", "cores": 1, "kind": "port"}}
+    try:  # the reference's data-structure shape (string-keyed maps, per-pack efficiency map) on a slice of the batch
+        from gangfit import workloads as wl
+        from oracle import binding as ob
+
+        wm = wl.headline(n_nodes, n_apps, seed=0x5EED0010)
+        sm = wm.snapshot
+        am = ob.make_apps(wm.drv, wm.exe, wm.k, wm.flags)[:200]
+        t0 = time.perf_counter()
+        ob.fit_maps(0, sm.avail, am, sm.driver_order, sm.exec_order, chain=False, sched=sm.sched)
+        dtm = time.perf_counter() - t0
+        out["reference_shaped_1_core"] = {"value": len(am) / dtm, "unit": "decisions/s", "cores": 1, "kind": "port",
+                                          "sample": f"first {len(am)} apps of the batch on string-keyed maps incl. the per-node "
+                                                    f"efficiency map of every pack (oracle/gangfit_oracle_maps.cpp), {dtm:.2f} s"}
+    except Exception as e:
+        out["reference_shaped_1_core"] = {"error": f"{type(e).__name__}: {e}"}
     cores = os.cpu_count() or 1
     try:
         with mp.get_context("spawn").Pool(cores) as pool:
@@ -123,7 +138,8 @@ def cpu_baseline_congested(w, max_apps: int = 48):
             "sample": f"first {len(apps)} apps of the congested batch, literal oracle, {dt:.1f} s"}
 
 
-def cpu_chain_baseline(algo, avail, sched, zone, driver_order, exec_order, drv, exe, k, flags, reps: int, with_eff_reps: int = 0):
+def cpu_chain_baseline(algo, avail, sched, zone, driver_order, exec_order, drv, exe, k, flags, reps: int, with_eff_reps: int = 0,
+                       maps_reps: int = 0):
     """The FIFO Filter's compute on one CPU core: the literal chain (fitEarlierDrivers + final pack, resource.go:224-262,
     309-328) over the SAME queue, a different head per repetition like the GPU leg.  `with_eff_reps` > 0 adds the
     reference-shaped variant: every successful pack also builds the per-node PackingEfficiencies map (binpack.go:77)."""
@@ -146,9 +162,21 @@ def cpu_chain_baseline(algo, avail, sched, zone, driver_order, exec_order, drv, 
             ob.fit_fifo_chain(algo, avail, np.roll(apps, -i), driver_order, exec_order, sched=sched, zone=zone,
                               with_efficiencies=True)
             ts.append((time.perf_counter() - t0) * 1e3)
+        out["with_efficiency_maps_p50_ms"] = _median(ts)
+        out["with_efficiency_maps_note"] = ("same dense-array chain plus ComputePackingEfficiencies over all nodes on every "
+                                            "successful pack (binpack.go:77), which the reference computes and "
+                                            "fitEarlierDrivers discards")
+    if maps_reps > 0 and sched is not None and algo in (0, 1) and zone is None:
+        ts = []
+        for i in range(maps_reps):
+            t0 = time.perf_counter()
+            ob.fit_maps(algo, avail, np.roll(apps, -i), driver_order, exec_order, chain=True, sched=sched)
+            ts.append((time.perf_counter() - t0) * 1e3)
         out["reference_shaped_p50_ms"] = _median(ts)
-        out["reference_shaped_note"] = ("same chain plus ComputePackingEfficiencies over all nodes on every successful pack "
-                                        "(binpack.go:77), which the reference computes and fitEarlierDrivers discards")
+        out["reference_shaped_note"] = ("the same chain on the reference's data structures (oracle/gangfit_oracle_maps.cpp): string "
+                                        "node names, hash maps for metadata / reserved / usage, a fresh N-sized reserved map per "
+                                        "driver candidate (binpack.go:72) and the per-node efficiency map of every successful pack "
+                                        "(binpack.go:77); int64 quantities — still cheaper than resource.Quantity arithmetic")
     return out
 
 
@@ -349,14 +377,24 @@ def main():
     }
 
     def fifo_latency(c, algo, queue, calls, warm=5):
+        """One blocking gf_fit_batch(FIFO_CHAIN) per call, a different head each time.  The interpreter's cyclic garbage
+        collector is held off while the calls are timed (a generation-2 pass over this process's arrays costs tens of
+        milliseconds and belongs to Python, not to the Filter)."""
+        import gc
+
         lat, o = [], None
-        for i in range(calls + warm):
-            rolled = np.roll(queue, -i)
-            t0 = time.perf_counter()
-            o = c.fit_batch(FIFO, algo, rolled)
-            dt = time.perf_counter() - t0
-            if i >= warm:
-                lat.append(dt * 1e3)
+        rolled_all = [np.roll(queue, -i) for i in range(calls + warm)]
+        gc.collect()
+        gc.disable()
+        try:
+            for i in range(calls + warm):
+                t0 = time.perf_counter()
+                o = c.fit_batch(FIFO, algo, rolled_all[i])
+                dt = time.perf_counter() - t0
+                if i >= warm:
+                    lat.append(dt * 1e3)
+        finally:
+            gc.enable()
         return lat, o
 
     if rank == 0 and world == 1:
@@ -398,8 +436,10 @@ def main():
                   "decisions_per_s": len(apps) / (_percentile(lat, 0.5) * 1e-3), "chain_failed_at": o.failed_at}
             if not args.no_cpu_baseline:
                 ff["cpu_baseline"] = cpu_chain_baseline(0, s.avail, s.sched, None, s.driver_order, s.exec_order, w.drv, w.exe, w.k,
-                                                        w.flags, reps=20, with_eff_reps=5)
+                                                        w.flags, reps=20, with_eff_reps=5, maps_reps=3)
                 ff["speedup_vs_cpu_p50"] = ff["cpu_baseline"]["p50_ms"] / ff["p50_ms"]
+                if "reference_shaped_p50_ms" in ff["cpu_baseline"]:
+                    ff["speedup_vs_reference_shaped_cpu_p50"] = ff["cpu_baseline"]["reference_shaped_p50_ms"] / ff["p50_ms"]
             out["fifo_filter"] = ff
         except Exception as e:
             out["fifo_filter"] = {"error": f"{type(e).__name__}: {e}"}

@@ -212,8 +212,6 @@ struct gf_ctx {
     DeviceBuf<gf_shard_driver> g_drv_loc, g_drv_all;
     DeviceBuf<uint32_t> g_exec2;                         // 2 * half: placements (node + 1) | capacities
     hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};    // behind partials+push | drivers+push | emit
-    hipStream_t join_stream = nullptr;                   // group object only: where the shards' events are joined
-    hipEvent_t join_ev[2] = {nullptr, nullptr};
 
     // findNodes requests (gf_find_nodes)
     DeviceBuf<int32_t> d_fk;
@@ -636,12 +634,6 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
                 (void)hipGetLastError();
             }
         g->info = g->group[0]->info;
-        if (hipSetDevice(g->device) != hipSuccess || hipStreamCreateWithFlags(&g->join_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&g->join_ev[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->join_ev[1], hipEventDisableTiming) != hipSuccess) {
-            gf_destroy(g);
-            return GF_ERR_HIP;
-        }
         *out = g;
         return GF_OK;
     }
@@ -707,9 +699,6 @@ void gf_destroy(gf_ctx* ctx) {
         for (gf_ctx* s : ctx->group) gf_destroy(s);
         ctx->group.clear();
         (void)hipSetDevice(ctx->device);
-        for (hipEvent_t& e : ctx->join_ev)
-            if (e) (void)hipEventDestroy(e);
-        if (ctx->join_stream) (void)hipStreamDestroy(ctx->join_stream);
         ctx->h_apps.release();
         ctx->h_results.release();
         ctx->h_exec.release();
@@ -2155,17 +2144,16 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         if (s > 0) exec_others.p[exec_others.n++] = c->g_exec2.ptr;
     }
     part_all.n = drv_all.n = S;
-    // Every stream continues only behind event `which` of every shard: the first device's join stream waits for the S events
-    // and records one join event all streams wait for — 2 S + 1 runtime calls per exchange instead of S (S - 1).
-    auto everyone_waits = [&](int which) -> hipError_t {
-        hipError_t e = hipSetDevice(first->device);
-        for (uint32_t s = 0; s < S && e == hipSuccess; ++s) e = hipStreamWaitEvent(g->join_stream, g->group[s]->g_ev[which], 0);
-        if (e == hipSuccess) e = hipEventRecord(g->join_ev[which], g->join_stream);
-        for (uint32_t t = 0; t < S && e == hipSuccess; ++t) {
-            e = hipSetDevice(g->group[t]->device);
-            if (e == hipSuccess) e = hipStreamWaitEvent(g->group[t]->stream, g->join_ev[which], 0);
+    auto everyone_waits = [&](int which) -> hipError_t {  // stream t continues only behind event `which` of every other shard
+        // (S (S - 1) stream waits; joining the events on one stream first — 2 S + 1 calls — measured slower with eight shards on
+        //  one device: the extra hop costs more than the calls it saves)
+        for (uint32_t t = 0; t < S; ++t) {
+            hipError_t e = hipSetDevice(g->group[t]->device);
+            for (uint32_t s = 0; s < S && e == hipSuccess; ++s)
+                if (s != t) e = hipStreamWaitEvent(g->group[t]->stream, g->group[s]->g_ev[which], 0);
+            if (e != hipSuccess) return e;
         }
-        return e;
+        return hipSuccess;
     };
     // ---- step 1: per-range capacity sums, gathered everywhere
     for (uint32_t s = 0; s < S; ++s) {

@@ -35,12 +35,11 @@ assert APP_DTYPE.itemsize == 56 and RESULT_DTYPE.itemsize == 16
 
 def build(force: bool = False) -> str:
     """Compile oracle/gangfit_oracle.c with gcc (seconds)."""
-    src = os.path.join(_HERE, "gangfit_oracle.c")
-    hdr = os.path.join(_HERE, "gangfit_oracle.h")
+    deps = [os.path.join(_HERE, f) for f in ("gangfit_oracle.c", "gangfit_oracle_maps.cpp", "gangfit_oracle.h", "Makefile")]
     stale = (
         force
         or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps)
     )
     if stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libgangfit_oracle.so"])
@@ -86,6 +85,8 @@ def lib() -> C.CDLL:
         L.go_fit_fifo_chain_with_efficiencies.restype = C.c_int32
         L.go_fit_fifo_chain_with_efficiencies.argtypes = [C.c_int, p, p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p,
                                                           C.c_uint32, p, p, p]
+        L.go_fit_maps.restype = C.c_int32
+        L.go_fit_maps.argtypes = [C.c_int, C.c_int, p, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, C.c_uint32, p, p, p]
         L.go_find_nodes_chain.restype = None
         L.go_find_nodes_chain.argtypes = [C.c_int, p, C.c_uint32, p, p, C.c_uint32, p, C.c_uint32, p, p, p, p]
         _lib = L
@@ -280,3 +281,19 @@ def find_nodes(avail, exe, k, ordered_nodes, closed_form: bool = False, chained:
                                       len(o), _ptr(placed[q:q + 1]), _ptr(np.zeros(1, dtype=np.uint64)),
                                       _ptr(out[int(off[q]):]), _ptr(adds[q:q + 1]))
     return FindNodesOut(placed, off, out[:-1], adds, avail)
+
+
+def fit_maps(algo: int, avail, apps: np.ndarray, driver_order, exec_order, chain: bool, sched=None) -> BatchOut:
+    """The FIFO chain (chain=True) or an independent batch on STRING-KEYED MAPS (oracle/gangfit_oracle_maps.cpp): the
+    reference's data-structure shape, incl. the per-node efficiency map of every successful pack.  Tightly-pack /
+    distribute-evenly.  Same results as fit_fifo_chain / fit_independent; exists for the CPU baseline."""
+    avail, d, x = _prep(avail, driver_order, exec_order)
+    sched, _ = _aux(avail, sched, None)
+    avail = avail.copy()
+    apps = np.ascontiguousarray(apps)
+    res = np.zeros(len(apps), dtype=RESULT_DTYPE)
+    off = exec_offsets(apps["k"])
+    out = np.zeros(int(apps["k"].astype(np.int64).sum()) + 1, dtype=np.uint32)
+    failed = lib().go_fit_maps(algo, int(chain), _ptr(avail), _ptr(sched), len(avail), _ptr(apps), len(apps), _ptr(d), len(d),
+                               _ptr(x), len(x), _ptr(res), _ptr(off), _ptr(out))
+    return BatchOut(res, off, out[:-1], int(failed), avail if chain else None)

@@ -134,6 +134,14 @@ uint32_t go_executor_first_fit_reserved(const int64_t *avail, uint32_t n_nodes, 
 uint32_t go_executor_min_frag(const int64_t *avail, uint32_t n_nodes, const int64_t *reserved, const int64_t exe[3],
                               const uint32_t *exec_order, uint32_t n_x, const uint8_t *hosts);
 
+/* The same FIFO chain (chain != 0) or independent batch (chain == 0) written with the reference's data structures — string
+ * node names, hash maps for the metadata, `reserved`, the usage map and the per-node PackingEfficiencies of every
+ * successful pack (oracle/gangfit_oracle_maps.cpp).  tightly-pack and distribute-evenly only.  Same results as
+ * go_fit_fifo_chain / go_fit_independent; this is the CPU baseline whose COST resembles the Go code's. */
+int32_t go_fit_maps(int algo, int chain, int64_t *avail, const int64_t *sched, uint32_t n_nodes, const go_app *apps,
+                    uint32_t n_apps, const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order, uint32_t n_x,
+                    go_result *results, const uint64_t *exec_off, uint32_t *exec_out);
+
 /* findNodes (internal/extender/failover.go:412-436): tightly-pack with partial results, no driver, and no `Sub` of the
  * add that fails the comparison.  Returns the number of executors placed (<= executor_count); exec_out receives them;
  * adds_out (nullable, n_nodes, zeroed here) = number of `reserved[n].Add(executorResources)` calls per node, i.e. the

@@ -235,3 +235,27 @@ def test_executor_first_fit():
     assert ob.executor_first_fit(avail, [2, 2, 0], [0, 1, 2]) == 1
     assert ob.executor_first_fit(avail, [2, 2, 1], [0, 1, 2]) == 2
     assert ob.executor_first_fit(avail, [20, 2, 0], [0, 1, 2]) == ob.NO_NODE
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+def test_map_shaped_restatement_agrees_with_the_dense_one(algo):
+    """oracle/gangfit_oracle_maps.cpp (string-keyed maps: the reference's data-structure shape, used as a CPU baseline) must
+    give the dense-array oracle's answers: independent batch and FIFO chain, unknown names and skippable drivers included."""
+    from test_gpu_parity import _random_problem
+
+    rng = np.random.default_rng(50 + algo)
+    for n, layout, tight in ((7, "general", True), (64, "merged", True), (150, "merged", False), (65, "identical", True)):
+        avail, D, X, drv, exe, k = _random_problem(rng, n, 40, tight, layout)
+        k = np.minimum(k, 60).astype(np.int32)
+        flags = (rng.random(len(k)) < 0.8).astype(np.uint32)
+        apps = ob.make_apps(drv, np.maximum(exe, 1), k, flags)
+        sched = np.abs(avail) + 3
+        want = ob.fit_independent(algo, avail, apps, D, X)
+        got = ob.fit_maps(algo, avail, apps, D, X, chain=False, sched=sched)
+        assert np.array_equal(got.results, want.results)
+        for a in np.nonzero(want.results["has_capacity"])[0]:
+            assert np.array_equal(got.placement(int(a))[2], want.placement(int(a))[2])
+        want = ob.fit_fifo_chain(algo, avail, apps, D, X)
+        got = ob.fit_maps(algo, avail, apps, D, X, chain=True, sched=sched)
+        assert got.failed_at == want.failed_at and np.array_equal(got.results, want.results)
+        assert np.array_equal(got.avail_after, want.avail_after)
