@@ -213,7 +213,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # "nccl" (= RCCL over xGMI) always, except for the smoke test of this N > 1 control flow on a ONE-GPU box, where both
+        # ranks share cuda:0 (RCCL refuses that) and GANGFIT_BENCH_BACKEND=gloo stands in
+        backend = os.environ.get("GANGFIT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     # ---- workload: same node table everywhere, a different slice of the pending queue per rank
@@ -277,8 +283,14 @@ def main():
         for _ in range(args.steps):
             step()
         graph = ctx.graph_end(stream)
-    except Exception as e:
-        graph_error = f"{type(e).__name__}: {e}"
+    except Exception:
+        graph = None
+    if dist is not None:  # every rank must take the same path below (the windows contain collectives)
+        okf = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0 and graph is not None:
+            ctx.graph_destroy(graph)
+            graph = None
     eager_wall, eager_kern_ms, eager_walls = timed(step, args.steps, 0, 3 if graph is not None else args.windows)
     if graph is not None:
         def window_graph():
@@ -534,7 +546,7 @@ def main():
                         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                             env.pop(k, None)
                         p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "group_bench.py"), "--devices", devs,
-                                            "--config", cfgname, "--steps", "20"], capture_output=True, text=True, timeout=100, env=env)
+                                            "--config", cfgname, "--steps", "20"], capture_output=True, text=True, timeout=70, env=env)
                         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
                         grp[cfgname] = json.loads(line[-1]) if line else {"error": (p.stderr or p.stdout)[-400:]}
                     except Exception as e:
