@@ -163,6 +163,20 @@ int gf_snapshot_build(gf_ctx *ctx, uint32_t n_nodes, const int64_t *alloc_cpu_mi
                       const uint32_t *zone_of_node, uint32_t n_zones, const uint32_t *name_rank,
                       const uint32_t *driver_label_rank, const uint32_t *exec_label_rank, uint32_t *driver_order_out,
                       uint32_t *n_d_out, uint32_t *exec_order_out, uint32_t *n_x_out);
+/* The same in two steps, for hosts that keep the cluster resident: gf_cluster_set uploads the columns that change only when
+ * the node set does (allocatable, overhead, zone ids, name ranks, default node flags — an informer event in the Go host);
+ * gf_snapshot_build_resident then builds and installs a snapshot from them and this request's reservation entries, so that
+ * a Filter moves only the reservations (and, when node_flags is not NULL, its own candidate flags: the driver candidates
+ * are the request's NodeNames) across PCIe.  gf_snapshot_build is exactly gf_cluster_set followed by
+ * gf_snapshot_build_resident(node_flags = NULL). */
+int gf_cluster_set(gf_ctx *ctx, uint32_t n_nodes, const int64_t *alloc_cpu_milli, const int64_t *alloc_mem_bytes,
+                   const int64_t *alloc_gpu, const int64_t *over_cpu_milli, const int64_t *over_mem_bytes,
+                   const int64_t *over_gpu, const uint32_t *node_flags, const uint32_t *zone_of_node, uint32_t n_zones,
+                   const uint32_t *name_rank);
+int gf_snapshot_build_resident(gf_ctx *ctx, uint32_t n_res, const uint32_t *res_node, const int64_t *res_cpu_milli,
+                               const int64_t *res_mem_bytes, const int64_t *res_gpu, const uint32_t *node_flags,
+                               const uint32_t *driver_label_rank, const uint32_t *exec_label_rank,
+                               uint32_t *driver_order_out, uint32_t *n_d_out, uint32_t *exec_order_out, uint32_t *n_x_out);
 /* The installed snapshot, n_nodes x 3 row-major each (either may be NULL). */
 int gf_snapshot_get(gf_ctx *ctx, int64_t *avail_out, int64_t *sched_out);
 

@@ -194,6 +194,14 @@ struct gf_ctx {
     DeviceBuf<double> d_eff;
     PinnedBuf<double> h_avg;
 
+    // gf_cluster_set: the static columns of gf_snapshot_build, resident
+    DeviceBuf<int64_t> d_cl_i64;   // allocatable (3n) | overhead (3n)
+    DeviceBuf<uint32_t> d_cl_u32;  // zone | name_rank | node_flags (n each)
+    std::vector<uint32_t> cl_flags, cl_zone;  // host copies (candidate lists, ctx->zone)
+    uint32_t cl_n = 0, cl_zones = 1;
+    bool cl_over = false, have_cluster = false;
+    int64_t cl_max_over[3] = {0, 0, 0};
+
     // gf_snapshot_build
     DeviceBuf<int64_t> d_bi64;   // alloc | overhead | usage | avail | sched (3n each) | keys_a | keys_b (n each) | res_req (3r) | zone_sum
     DeviceBuf<uint32_t> d_bu32;  // zone | name_rank | perm_a | perm_b (n each) | res_node (r) | zone_order | zone_rank
@@ -743,6 +751,8 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_reserved.release();
     ctx->d_eff.release();
     ctx->h_avg.release();
+    ctx->d_cl_i64.release();
+    ctx->d_cl_u32.release();
     ctx->d_bi64.release();
     ctx->d_bu32.release();
     ctx->d_btemp.release();
@@ -1420,32 +1430,15 @@ int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* re
     return gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, 1, app, result, exec_nodes, exec_nodes_cap, nullptr);
 }
 
-int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli, const int64_t* alloc_mem_bytes,
-                      const int64_t* alloc_gpu, const int64_t* over_cpu_milli, const int64_t* over_mem_bytes,
-                      const int64_t* over_gpu, uint32_t n_res, const uint32_t* res_node, const int64_t* res_cpu_milli,
-                      const int64_t* res_mem_bytes, const int64_t* res_gpu, const uint32_t* node_flags,
-                      const uint32_t* zone_of_node, uint32_t n_zones, const uint32_t* name_rank,
-                      const uint32_t* driver_label_rank, const uint32_t* exec_label_rank, uint32_t* driver_order_out,
-                      uint32_t* n_d_out, uint32_t* exec_order_out, uint32_t* n_x_out) {
-    if (ctx != nullptr && !ctx->group.empty()) {  // the caller's order lists come from the first device only
-        gf_ctx* const g = ctx;
-        std::lock_guard<std::recursive_mutex> glock(g->mu);
-        for (size_t i = 0; i < g->group.size(); ++i) {
-            const bool first = i == 0;
-            const int rc = gf_snapshot_build(g->group[i], n_nodes, alloc_cpu_milli, alloc_mem_bytes, alloc_gpu, over_cpu_milli,
-                                             over_mem_bytes, over_gpu, n_res, res_node, res_cpu_milli, res_mem_bytes, res_gpu,
-                                             node_flags, zone_of_node, n_zones, name_rank, driver_label_rank, exec_label_rank,
-                                             first ? driver_order_out : nullptr, first ? n_d_out : nullptr,
-                                             first ? exec_order_out : nullptr, first ? n_x_out : nullptr);
-            if (rc != GF_OK) {
-                g->err = g->group[i]->err;
-                return rc;
-            }
-        }
-        return GF_OK;
-    }
+int gf_cluster_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli, const int64_t* alloc_mem_bytes,
+                   const int64_t* alloc_gpu, const int64_t* over_cpu_milli, const int64_t* over_mem_bytes,
+                   const int64_t* over_gpu, const uint32_t* node_flags, const uint32_t* zone_of_node, uint32_t n_zones,
+                   const uint32_t* name_rank) {
+    GF_EACH(ctx, gf_cluster_set(ctx, n_nodes, alloc_cpu_milli, alloc_mem_bytes, alloc_gpu, over_cpu_milli, over_mem_bytes,
+                                over_gpu, node_flags, zone_of_node, n_zones, name_rank));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    ctx->have_cluster = false;
     const uint32_t n = n_nodes;
     if (n >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "too many nodes");
     if (n > 0 && (!alloc_cpu_milli || !alloc_mem_bytes || !alloc_gpu || !node_flags || !name_rank))
@@ -1453,8 +1446,6 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     const bool with_over = over_cpu_milli || over_mem_bytes || over_gpu;
     if (with_over && !(over_cpu_milli && over_mem_bytes && over_gpu))
         return fail(ctx, GF_ERR_INVALID, "overhead columns must be all NULL or all set");
-    if (n_res > 0 && (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu))
-        return fail(ctx, GF_ERR_INVALID, "reservation columns must not be NULL");
     if (zone_of_node == nullptr) n_zones = 1;
     if (n_zones == 0 || n_zones > 4096) return fail(ctx, GF_ERR_INVALID, "n_zones = %u outside [1, 4096]", n_zones);
     {  // name_rank must be a permutation: it seeds the stable sort with the name order (nodesorting.go:92)
@@ -1469,26 +1460,109 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     }
     const int64_t* cols[3] = {alloc_cpu_milli, alloc_mem_bytes, alloc_gpu};
     const int64_t* ocols[3] = {over_cpu_milli, over_mem_bytes, over_gpu};
-    const int64_t* rcols[3] = {res_cpu_milli, res_mem_bytes, res_gpu};
     const int64_t lim = GF_MAX_ABS_QUANTITY >> 1;
-    int64_t max_res[3] = {0, 0, 0}, max_over[3] = {0, 0, 0};
     for (int j = 0; j < 3; ++j) {
+        ctx->cl_max_over[j] = 0;
         for (uint32_t i = 0; i < n; ++i) {
             if (cols[j][i] < 0 || cols[j][i] >= GF_MAX_ABS_QUANTITY || (with_over && (ocols[j][i] < 0 || ocols[j][i] >= lim)))
                 return fail(ctx, GF_ERR_INVALID, "allocatable / overhead value out of range at node %u", i);
-            if (with_over && ocols[j][i] > max_over[j]) max_over[j] = ocols[j][i];
+            if (with_over && ocols[j][i] > ctx->cl_max_over[j]) ctx->cl_max_over[j] = ocols[j][i];
         }
+    }
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t N = n;
+    GF_HIP(ctx, gf_wait_stream(st));  // nothing in flight may still read the columns that are about to be replaced
+    GF_HIP(ctx, ctx->d_cl_i64.reserve(6 * N + 1));
+    GF_HIP(ctx, ctx->d_cl_u32.reserve(3 * N + 1));
+    for (int j = 0; j < 3 && N; ++j) {
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_i64.ptr + j * N, cols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (with_over)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_i64.ptr + (3 + j) * N, ocols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    }
+    if (N) {
+        if (zone_of_node)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_u32.ptr, zone_of_node, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        else
+            GF_HIP(ctx, hipMemsetAsync(ctx->d_cl_u32.ptr, 0, N * sizeof(uint32_t), st));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_u32.ptr + N, name_rank, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_u32.ptr + 2 * N, node_flags, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    GF_HIP(ctx, gf_wait_stream(st));  // the caller's arrays are free again
+    ctx->cl_flags.assign(node_flags, node_flags + n);
+    if (zone_of_node)
+        ctx->cl_zone.assign(zone_of_node, zone_of_node + n);
+    else
+        ctx->cl_zone.clear();
+    ctx->cl_n = n;
+    ctx->cl_zones = n_zones;
+    ctx->cl_over = with_over;
+    ctx->have_cluster = true;
+    return GF_OK;
+}
+
+int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli, const int64_t* alloc_mem_bytes,
+                      const int64_t* alloc_gpu, const int64_t* over_cpu_milli, const int64_t* over_mem_bytes,
+                      const int64_t* over_gpu, uint32_t n_res, const uint32_t* res_node, const int64_t* res_cpu_milli,
+                      const int64_t* res_mem_bytes, const int64_t* res_gpu, const uint32_t* node_flags,
+                      const uint32_t* zone_of_node, uint32_t n_zones, const uint32_t* name_rank,
+                      const uint32_t* driver_label_rank, const uint32_t* exec_label_rank, uint32_t* driver_order_out,
+                      uint32_t* n_d_out, uint32_t* exec_order_out, uint32_t* n_x_out) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);  // cluster + build are one sequence
+    const int rc = gf_cluster_set(ctx, n_nodes, alloc_cpu_milli, alloc_mem_bytes, alloc_gpu, over_cpu_milli, over_mem_bytes,
+                                  over_gpu, node_flags, zone_of_node, n_zones, name_rank);
+    if (rc != GF_OK) return rc;
+    return gf_snapshot_build_resident(ctx, n_res, res_node, res_cpu_milli, res_mem_bytes, res_gpu, nullptr, driver_label_rank,
+                                      exec_label_rank, driver_order_out, n_d_out, exec_order_out, n_x_out);
+}
+
+int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_node, const int64_t* res_cpu_milli,
+                               const int64_t* res_mem_bytes, const int64_t* res_gpu, const uint32_t* node_flags,
+                               const uint32_t* driver_label_rank, const uint32_t* exec_label_rank,
+                               uint32_t* driver_order_out, uint32_t* n_d_out, uint32_t* exec_order_out, uint32_t* n_x_out) {
+    if (ctx != nullptr && !ctx->group.empty()) {  // the caller's order lists come from the first device only
+        gf_ctx* const g = ctx;
+        std::lock_guard<std::recursive_mutex> glock(g->mu);
+        for (size_t i = 0; i < g->group.size(); ++i) {
+            const bool first = i == 0;
+            const int rc = gf_snapshot_build_resident(g->group[i], n_res, res_node, res_cpu_milli, res_mem_bytes, res_gpu, node_flags,
+                                                      driver_label_rank, exec_label_rank, first ? driver_order_out : nullptr,
+                                                      first ? n_d_out : nullptr, first ? exec_order_out : nullptr,
+                                                      first ? n_x_out : nullptr);
+            if (rc != GF_OK) {
+                g->err = g->group[i]->err;
+                return rc;
+            }
+        }
+        return GF_OK;
+    }
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_snapshot_build_resident");
+    const uint32_t n = ctx->cl_n;
+    const uint32_t n_zones = ctx->cl_zones;
+    const bool with_over = ctx->cl_over;
+    if (n_res > 0 && (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu))
+        return fail(ctx, GF_ERR_INVALID, "reservation columns must not be NULL");
+    if (node_flags) ctx->cl_flags.assign(node_flags, node_flags + n);  // this request's candidate flags
+    const uint32_t* const zone_of_node = ctx->cl_zone.empty() ? nullptr : ctx->cl_zone.data();
+    const uint32_t* const flags_host = ctx->cl_flags.data();
+    const int64_t* rcols[3] = {res_cpu_milli, res_mem_bytes, res_gpu};
+    const int64_t lim = GF_MAX_ABS_QUANTITY >> 1;
+    int64_t max_res[3] = {0, 0, 0};
+    for (int j = 0; j < 3; ++j)
         for (uint32_t i = 0; i < n_res; ++i) {
             if (rcols[j][i] < 0 || rcols[j][i] >= lim) return fail(ctx, GF_ERR_INVALID, "reservation %u out of range", i);
             if (rcols[j][i] > max_res[j]) max_res[j] = rcols[j][i];
         }
-    }
     if ((uint64_t)n_res >= (1ull << 32) - 1) return fail(ctx, GF_ERR_INVALID, "too many reservations");
     {  // the per-node sums (usage + overhead) must stay below 2^62: the device accumulates in 64 bits and would wrap silently.
         // Coarse bound first (every entry on one node); only when that fails, the real per-node entry counts.
         auto fits = [&](uint64_t count) {
             for (int j = 0; j < 3; ++j)
-                if ((unsigned __int128)count * (uint64_t)max_res[j] + (uint64_t)max_over[j] >= (unsigned __int128)GF_MAX_ABS_QUANTITY) return false;
+                if ((unsigned __int128)count * (uint64_t)max_res[j] + (uint64_t)ctx->cl_max_over[j] >= (unsigned __int128)GF_MAX_ABS_QUANTITY)
+                    return false;
             return true;
         };
         if (!fits(n_res)) {
@@ -1509,26 +1583,27 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     }
     GF_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    // ---- device buffers
+    // ---- device buffers (the static columns live in the resident cluster buffers)
     const size_t N = n, R = n_res, Z = n_zones;
     const size_t NCH = (N + 1 + 63) / 64;  // chunks of the slot space (nodes + sentinel)
     GF_HIP(ctx, gf_wait_stream(st));  // nothing in flight may still read buffers that are about to grow
-    GF_HIP(ctx, ctx->d_bi64.reserve(15 * N + 2 * N + 3 * R + 3 * Z + 3 * NCH + 16));
-    GF_HIP(ctx, ctx->d_bu32.reserve(5 * N + R + 5 * Z + 16));
+    GF_HIP(ctx, ctx->d_bi64.reserve(9 * N + 2 * N + 3 * R + 3 * Z + 6 * NCH + 16));
+    GF_HIP(ctx, ctx->d_bu32.reserve(2 * N + R + 5 * Z + 16));
     const size_t temp = gangfit::snapshot_sort_temp_bytes(n);
     GF_HIP(ctx, ctx->d_btemp.reserve(temp + 16));
-    int64_t* d_alloc = ctx->d_bi64.ptr;
+    int64_t* d_alloc = ctx->d_cl_i64.ptr;
     int64_t* d_over = d_alloc + 3 * N;
-    int64_t* d_usage = d_over + 3 * N;
+    int64_t* d_usage = ctx->d_bi64.ptr;
     int64_t* d_avail = d_usage + 3 * N;
     int64_t* d_sched = d_avail + 3 * N;
     int64_t* d_keys_a = d_sched + 3 * N;
     int64_t* d_keys_b = d_keys_a + N;
     int64_t* d_res_req = d_keys_b + N;
     int64_t* d_zone_sum = d_res_req + 3 * R;
-    uint32_t* d_zone = ctx->d_bu32.ptr;
+    uint32_t* d_zone = ctx->d_cl_u32.ptr;
     uint32_t* d_name_rank = d_zone + N;
-    uint32_t* d_perm_a = d_name_rank + N;
+    uint32_t* d_flags = d_name_rank + N;
+    uint32_t* d_perm_a = ctx->d_bu32.ptr;
     uint32_t* d_perm_b = d_perm_a + N;
     uint32_t* d_res_node = d_perm_b + N;
     uint32_t* d_zone_order = d_res_node + R;
@@ -1537,20 +1612,12 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     uint32_t* d_zhasx = d_zfirst + Z;
     uint32_t* d_zeval = d_zhasx + Z;
     uint32_t* d_scalars = d_zeval + Z;  // 4
-    uint32_t* d_flags = d_scalars + 4;  // N
     unsigned long long* d_gcd_part = reinterpret_cast<unsigned long long*>(d_zone_sum + 3 * Z);
-    long long* d_units = reinterpret_cast<long long*>(d_gcd_part + 3 * NCH);
-    for (int j = 0; j < 3; ++j) {
-        GF_HIP(ctx, hipMemcpyAsync(d_alloc + j * N, cols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        if (with_over) GF_HIP(ctx, hipMemcpyAsync(d_over + j * N, ocols[j], N * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        if (R) GF_HIP(ctx, hipMemcpyAsync(d_res_req + j * R, rcols[j], R * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    }
+    long long* d_units = reinterpret_cast<long long*>(d_gcd_part + 6 * NCH);  // gcd partials | magnitude partials | units
+    for (int j = 0; j < 3 && R; ++j)
+        GF_HIP(ctx, hipMemcpyAsync(d_res_req + j * R, rcols[j], R * sizeof(int64_t), hipMemcpyHostToDevice, st));
     if (R) GF_HIP(ctx, hipMemcpyAsync(d_res_node, res_node, R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    if (zone_of_node)
-        GF_HIP(ctx, hipMemcpyAsync(d_zone, zone_of_node, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    else
-        GF_HIP(ctx, hipMemsetAsync(d_zone, 0, N * sizeof(uint32_t), st));
-    GF_HIP(ctx, hipMemcpyAsync(d_name_rank, name_rank, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (node_flags) GF_HIP(ctx, hipMemcpyAsync(d_flags, node_flags, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     gangfit::SnapshotBuild b{};
     b.n_nodes = n;
     b.n_res = n_res;
@@ -1578,7 +1645,6 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
         // ---- the slot tables on the device too: nothing of size O(n_nodes) returns to the host unless the caller asks
         //      for the orders.  (Label re-sorts can break the merged layout: those go through gf_orders_set below.)
         const uint32_t n_slots = n + 1, n_chunks = (uint32_t)NCH;
-        GF_HIP(ctx, hipMemcpyAsync(d_flags, node_flags, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         GF_HIP(ctx, ctx->d_snap.reserve(3 * (size_t)n_slots));
         GF_HIP(ctx, ctx->d_work.reserve(3 * (size_t)n_slots));
         GF_HIP(ctx, ctx->d_sched.reserve(3 * (size_t)n_slots));
@@ -1656,7 +1722,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
             uint32_t nd = 0, nx = 0;
             for (size_t i = 0; i < N; ++i) {
                 const uint32_t node = ctx->h_border.ptr[i];
-                const uint32_t fl = node_flags[node];
+                const uint32_t fl = flags_host[node];
                 if (fl & GF_NODE_DRIVER_CANDIDATE) {
                     if (driver_order_out) driver_order_out[nd] = node;
                     ++nd;
@@ -1686,7 +1752,7 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
     X.reserve(N);
     for (size_t i = 0; i < N; ++i) {
         const uint32_t node = ctx->h_border.ptr[i];
-        const uint32_t f = node_flags[node];
+        const uint32_t f = flags_host[node];
         if (f & GF_NODE_DRIVER_CANDIDATE) D.push_back(node);
         if (!(f & GF_NODE_UNSCHEDULABLE) && (f & GF_NODE_READY)) X.push_back(node);
     }

@@ -301,7 +301,7 @@ struct SnapshotFinalize {
     uint64_t* d_masks;          // 2 * n_chunks: executor | driver candidate bits
     int64_t* d_cmax;            // 3 * n_chunks
     int64_t* d_node_tab;        // 6 * n_nodes
-    unsigned long long* d_gcd_part;  // 3 * n_chunks
+    unsigned long long* d_gcd_part;  // 6 * n_chunks: chunk gcds, then chunk maxima of the magnitudes
     long long* d_units;         // 3
     uint32_t* d_zfirst;         // n_zones
     uint32_t* d_zhasx;          // n_zones

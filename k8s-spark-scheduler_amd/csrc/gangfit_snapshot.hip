@@ -174,15 +174,18 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
     const bool dbit = real && (flags & GF_NODE_DRIVER_CANDIDATE);
     const uint64_t xm = __ballot(xbit), dm = __ballot(dbit);
     int64_t m[3];
-    uint64_t g[3];
+    uint64_t g[3], mag[3];
     for (int j = 0; j < 3; ++j) {
         m[j] = in_range ? a[j] : INT64_MIN;
         uint64_t v = real ? (uint64_t)(a[j] < 0 ? -a[j] : a[j]) : 0ull;
         uint64_t any = v;
+        mag[j] = v;  // largest magnitude of the chunk: how far a batch may refine the units (narrow_begin)
         for (int d = 1; d < 64; d <<= 1) {
             const int64_t om = __shfl_xor(m[j], d, 64);
             m[j] = om > m[j] ? om : m[j];
             any |= (uint64_t)__shfl_xor((long long)any, d, 64);
+            const uint64_t og = (uint64_t)__shfl_xor((long long)mag[j], d, 64);
+            mag[j] = og > mag[j] ? og : mag[j];
         }
         // gcd of the chunk: the common power of two comes from the OR of the magnitudes; what is left of byte / milli
         // quantities almost always fits 32 bits, where Euclid's steps are cheap (gfx950 has no 64-bit divider)
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
         for (int j = 0; j < 3; ++j) {
             f.d_cmax[(size_t)j * f.n_chunks + c] = m[j];
             f.d_gcd_part[(size_t)j * f.n_chunks + c] = g[j];
+            f.d_gcd_part[(size_t)(3 + j) * f.n_chunks + c] = mag[j];
         }
     }
     // zones by first appearance in the driver order, and whether they own an executor candidate (single_az.go:36-41)
@@ -230,18 +234,32 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
 
 // One workgroup: the per-dimension units (gcd over the chunk gcds) and the zone evaluation list.
 __global__ __launch_bounds__(256) void finalize_reduce_kernel(SnapshotFinalize f) {
-    __shared__ unsigned long long part[3][256];
+    __shared__ unsigned long long part[6][256];
     for (int j = 0; j < 3; ++j) {
-        uint64_t g = 0;
-        for (uint32_t c = threadIdx.x; c < f.n_chunks; c += blockDim.x) g = gcd_u64(g, f.d_gcd_part[(size_t)j * f.n_chunks + c]);
+        uint64_t g = 0, mg = 0;
+        for (uint32_t c = threadIdx.x; c < f.n_chunks; c += blockDim.x) {
+            g = gcd_u64(g, f.d_gcd_part[(size_t)j * f.n_chunks + c]);
+            const uint64_t v = f.d_gcd_part[(size_t)(3 + j) * f.n_chunks + c];
+            mg = v > mg ? v : mg;
+        }
         part[j][threadIdx.x] = g;
+        part[3 + j][threadIdx.x] = mg;
     }
     __syncthreads();
+    for (uint32_t w = blockDim.x / 2; w > 0; w >>= 1) {  // tree: a serial pass of one thread over 768 software gcds took 0.1 ms
+        if (threadIdx.x < w)
+            for (int j = 0; j < 3; ++j) {
+                part[j][threadIdx.x] = gcd_u64(part[j][threadIdx.x], part[j][threadIdx.x + w]);
+                const uint64_t o = part[3 + j][threadIdx.x + w];
+                if (o > part[3 + j][threadIdx.x]) part[3 + j][threadIdx.x] = o;
+            }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         for (int j = 0; j < 3; ++j) {
-            uint64_t g = 0;
-            for (uint32_t t = 0; t < blockDim.x; ++t) g = gcd_u64(g, part[j][t]);
+            const uint64_t g = part[j][0];
             f.d_units[j] = g ? (long long)g : 1ll;
+            f.d_units[3 + j] = (long long)(part[3 + j][0] / (g ? g : 1ull));  // largest scaled magnitude
         }
         // evaluation list: zones that have a driver candidate AND an executor candidate, ordered by their first driver slot
         uint32_t nz = 0;
@@ -280,17 +298,11 @@ __global__ __launch_bounds__(256) void finalize_narrow_zones_kernel(SnapshotFina
     for (int j = 0; j < 3; ++j) {
         if (s < ns) f.d_nsnap[(size_t)j * ns + s] = v[j];
         int32_t m = s < ns ? v[j] : INT32_MIN;
-        int32_t mag = real ? (v[j] < 0 ? -v[j] : v[j]) : 0;  // largest |scaled value|: how far a batch may refine the units
         for (int d = 1; d < 64; d <<= 1) {
             const int32_t o = __shfl_xor(m, d, 64);
             m = o > m ? o : m;
-            const int32_t g = __shfl_xor(mag, d, 64);
-            mag = g > mag ? g : mag;
         }
-        if (lane == 0 && c < f.n_chunks) {
-            f.d_ncmax[(size_t)j * f.n_chunks + c] = m;
-            atomicMax(reinterpret_cast<unsigned long long*>(f.d_units) + 3 + j, (unsigned long long)mag);
-        }
+        if (lane == 0 && c < f.n_chunks) f.d_ncmax[(size_t)j * f.n_chunks + c] = m;
     }
     uint32_t ei = GF_NO_NODE;
     bool xbit = false, dbit = false;
@@ -315,7 +327,6 @@ hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t strea
     if (e != hipSuccess) return e;
     if ((e = hipMemsetAsync(f.d_zhasx, 0, (size_t)f.n_zones * sizeof(uint32_t), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(f.d_scalars, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(f.d_units + 3, 0, 3 * sizeof(long long), stream)) != hipSuccess) return e;  // largest scaled magnitudes
     const dim3 block(256), grid((unsigned)(((size_t)f.n_chunks * 64 + 255) / 256));
     hipLaunchKernelGGL(finalize_slots_kernel, grid, block, 0, stream, f);
     hipLaunchKernelGGL(finalize_reduce_kernel, dim3(1), block, 0, stream, f);

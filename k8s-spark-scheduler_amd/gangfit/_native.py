@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
     "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
-    "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy",
+    "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
 ]
 
 
@@ -123,6 +123,10 @@ def load() -> C.CDLL:
     L.gf_launch_floor.argtypes = [p, p, u32, C.POINTER(C.c_float)]
     L.gf_snapshot_build.restype = i32
     L.gf_snapshot_build.argtypes = [p, u32, p, p, p, p, p, p, u32, p, p, p, p, p, p, u32, p, p, p, p, p, p, p]
+    L.gf_cluster_set.restype = i32
+    L.gf_cluster_set.argtypes = [p, u32, p, p, p, p, p, p, p, p, u32, p]
+    L.gf_snapshot_build_resident.restype = i32
+    L.gf_snapshot_build_resident.argtypes = [p, u32, p, p, p, p, p, p, p, p, p, p, p]
     L.gf_snapshot_get.restype = i32
     L.gf_snapshot_get.argtypes = [p, p, p]
     L.gf_executor_fit.restype = i32

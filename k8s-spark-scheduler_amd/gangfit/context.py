@@ -136,6 +136,43 @@ class Context:
         self.n_nodes = n
         return d_out[: nd.value].copy(), x_out[: nx.value].copy()
 
+    def set_cluster(self, alloc, node_flags, name_rank, overhead=None, zone=None, n_zones: int = 1):
+        """gf_cluster_set: the static columns stay resident; build_snapshot_resident then only moves the reservations."""
+        alloc = np.ascontiguousarray(alloc, dtype=np.int64).reshape(-1, 3)
+        n = len(alloc)
+        cols = [np.ascontiguousarray(alloc[:, j]) for j in range(3)]
+        ocols = [None] * 3
+        if overhead is not None:
+            overhead = np.ascontiguousarray(overhead, dtype=np.int64).reshape(-1, 3)
+            ocols = [np.ascontiguousarray(overhead[:, j]) for j in range(3)]
+        flags = np.ascontiguousarray(node_flags, dtype=np.uint32)
+        ranks = np.ascontiguousarray(name_rank, dtype=np.uint32)
+        z = None if zone is None else np.ascontiguousarray(zone, dtype=np.uint32)
+        self._check(self._lib.gf_cluster_set(self._h, n, *[N.ptr(c) for c in cols], *[N.ptr(c) for c in ocols], N.ptr(flags),
+                                             N.ptr(z), n_zones, N.ptr(ranks)))
+        self._cluster_n = n
+
+    def build_snapshot_resident(self, res_node=None, res_req=None, node_flags=None, driver_label_rank=None,
+                                exec_label_rank=None, want_orders: bool = True):
+        n = self._cluster_n
+        rn = np.zeros(0, dtype=np.uint32) if res_node is None else np.ascontiguousarray(res_node, dtype=np.uint32)
+        rr = np.zeros((0, 3), dtype=np.int64) if res_req is None else np.ascontiguousarray(res_req, dtype=np.int64).reshape(-1, 3)
+        rcols = [np.ascontiguousarray(rr[:, j]) for j in range(3)]
+        fl = None if node_flags is None else np.ascontiguousarray(node_flags, dtype=np.uint32)
+        dl = None if driver_label_rank is None else np.ascontiguousarray(driver_label_rank, dtype=np.uint32)
+        el = None if exec_label_rank is None else np.ascontiguousarray(exec_label_rank, dtype=np.uint32)
+        self.n_nodes = n
+        if not want_orders:
+            self._check(self._lib.gf_snapshot_build_resident(self._h, len(rn), N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(fl),
+                                                             N.ptr(dl), N.ptr(el), None, None, None, None))
+            return None, None
+        d_out, x_out = np.zeros(n + 1, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint32)
+        nd, nx = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.gf_snapshot_build_resident(self._h, len(rn), N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(fl),
+                                                         N.ptr(dl), N.ptr(el), N.ptr(d_out), C.byref(nd), N.ptr(x_out),
+                                                         C.byref(nx)))
+        return d_out[: nd.value].copy(), x_out[: nx.value].copy()
+
     def snapshot(self):
         """(avail, sched) of the installed snapshot, (n_nodes, 3) int64 each."""
         a = np.zeros((self.n_nodes, 3), dtype=np.int64)

@@ -1,6 +1,7 @@
 #include "extender.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 namespace gangfit::host {
 
@@ -286,7 +287,9 @@ std::vector<std::pair<std::string, bool>> SparkSchedulerExtender::scanForUnsched
 namespace gangfit::host {
 
 bool FlatCluster::Build(const std::vector<Node>& nodes, FlatCluster* out, std::string* err) {
+    static std::atomic<uint64_t> next_version{1};
     FlatCluster c;
+    c.version = next_version.fetch_add(1);
     const size_t n = nodes.size();
     std::map<std::string, uint32_t> zone_ids;  // label order
     for (const Node& nd : nodes) {
@@ -434,12 +437,32 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
     // ---- snapshot + orders on the device, then the chain
     gf_ctx* ctx = binpacker_.ctx;
     CtxSequence seq(ctx);
-    if (gf_snapshot_build(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(),
-                          overhead.empty() ? nullptr : over[0].data(), overhead.empty() ? nullptr : over[1].data(),
-                          overhead.empty() ? nullptr : over[2].data(), (uint32_t)rnode.size(), rnode.data(), rreq[0].data(),
-                          rreq[1].data(), rreq[2].data(), flags.data(), cluster.zone.data(), (uint32_t)cluster.zone_labels.size(),
-                          cluster.name_rank.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != GF_OK)
+    if (overhead.empty()) {
+        // the node-side columns change only when the node set does: they stay on the device (gf_cluster_set), a Filter moves
+        // its reservation entries and its own candidate flags only.  (Another user of the context may have replaced the
+        // resident cluster in between; a host with one extender per context — the reference's shape — never does.)
+        if (resident_cluster_ != cluster.version || cluster.version == 0) {
+            if (gf_cluster_set(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(), nullptr, nullptr,
+                               nullptr, cluster.base_flags.data(), cluster.zone.data(), (uint32_t)cluster.zone_labels.size(),
+                               cluster.name_rank.data()) != GF_OK)
+                return not_served(std::string("gf_cluster_set: ") + gf_last_error(ctx));
+            resident_cluster_ = cluster.version;
+        }
+        if (gf_snapshot_build_resident(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(), rreq[2].data(),
+                                       flags.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != GF_OK) {
+            resident_cluster_ = 0;
+            return not_served(std::string("gf_snapshot_build_resident: ") + gf_last_error(ctx));
+        }
+    } else if (gf_snapshot_build(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(), over[0].data(),
+                                 over[1].data(), over[2].data(), (uint32_t)rnode.size(), rnode.data(), rreq[0].data(),
+                                 rreq[1].data(), rreq[2].data(), flags.data(), cluster.zone.data(),
+                                 (uint32_t)cluster.zone_labels.size(), cluster.name_rank.data(), nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr) != GF_OK) {
+        resident_cluster_ = 0;
         return not_served(std::string("gf_snapshot_build: ") + gf_last_error(ctx));
+    } else {
+        resident_cluster_ = 0;  // gf_snapshot_build replaced the resident cluster (with this request's overhead)
+    }
     uint64_t total_k = 0;
     for (const gf_app& a : apps) total_k += (uint64_t)a.k;
     std::vector<gf_result> results(apps.size());

@@ -62,6 +62,7 @@ struct FlatCluster {
     std::vector<uint32_t> name_rank, zone, base_flags;  // base_flags: GF_NODE_UNSCHEDULABLE / GF_NODE_READY
     std::vector<std::string> zone_labels;            // zone id -> label
     std::vector<int64_t> alloc[3];
+    uint64_t version = 0;  // unique per Build: lets a caller keep the columns resident on the device (gf_cluster_set)
     static bool Build(const std::vector<Node>& nodes, FlatCluster* out, std::string* err);
 };
 
@@ -127,6 +128,7 @@ public:
     bool shouldSkipDriverFifo(const Pod& pod, const std::string& instanceGroup) const;
 
 private:
+    uint64_t resident_cluster_ = 0;  // FlatCluster::version whose static columns sit on the device (selectDriverNodeFlat)
     Binpacker binpacker_;
     NodeSorter sorter_;
     bool isFIFO_;

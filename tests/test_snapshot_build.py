@@ -116,3 +116,40 @@ def test_sums_that_could_wrap_are_refused(gf_ctx):
     avail, _, _, _ = ps.build(alloc, flags, ranks, res_node=node, res_req=req)
     got, _ = gf_ctx.snapshot()
     assert np.array_equal(got, avail)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("labels", [False, True])
+def test_resident_cluster_then_reservations_only(gf_ctx, labels):
+    """gf_cluster_set once, then several gf_snapshot_build_resident calls with different reservations and different candidate
+    flags: each must equal gf_snapshot_build / the restatement on the same inputs."""
+    n = 3000
+    c = _cluster(77, n, 500, 3, with_overhead=True, labels=labels)
+    gf_ctx.set_cluster(c["alloc"], c["node_flags"], c["name_rank"], overhead=c["overhead"], zone=c["zone"], n_zones=c["n_zones"])
+    rng = np.random.default_rng(5)
+    for rep in range(3):
+        m = int(rng.integers(0, 9000))
+        res_node = rng.integers(0, n + 2, size=m).astype(np.uint32)
+        res_req = np.stack([rng.choice([500, 1000, 4000], size=m), rng.choice([1, 4, 16], size=m) * GIB, (rng.random(m) < 0.05).astype(np.int64)],
+                           axis=1).astype(np.int64)
+        flags = c["node_flags"].copy()
+        if rep:  # this request's NodeNames: other driver candidates
+            flags = (flags & ~np.uint32(ps.DRIVER_CANDIDATE)) | np.where(rng.random(n) < 0.5, ps.DRIVER_CANDIDATE, 0).astype(np.uint32)
+        D, X = gf_ctx.build_snapshot_resident(res_node=res_node, res_req=res_req, node_flags=flags if rep else None,
+                                              driver_label_rank=c["driver_label_rank"], exec_label_rank=c["exec_label_rank"])
+        cc = dict(c, res_node=res_node, res_req=res_req, node_flags=flags)
+        avail, sched, rD, rX = ps.build(**cc)
+        got_avail, got_sched = gf_ctx.snapshot()
+        assert np.array_equal(got_avail, avail) and np.array_equal(got_sched, sched)
+        assert np.array_equal(D, rD) and np.array_equal(X, rX)
+        w = wl.config(2, n_nodes=16, n_apps=48)
+        apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+        oapps = ob.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+        gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, 4, apps)
+        ref = ob.fit_fifo_chain(4, avail, oapps, rD, rX, sched=sched, zone=c["zone"])
+        assert gpu.failed_at == ref.failed_at and np.array_equal(gpu.results, ref.results)
+    with gangfit.Context(0) as fresh:
+        with pytest.raises(gangfit.GangfitError) as e:  # no cluster yet
+            fresh._cluster_n = 1
+            fresh.build_snapshot_resident()
+        assert e.value.code == gangfit._native.GF_ERR_STATE
