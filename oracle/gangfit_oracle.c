@@ -362,6 +362,24 @@ static int spark_binpack_closed(int algo, const int64_t *avail, uint32_t n_nodes
                                 const uint32_t *driver_order, uint32_t n_d, const uint32_t *exec_order,
                                 uint32_t n_x, uint32_t *driver_out, uint32_t *exec_out) {
     static const int64_t zero[3] = {0, 0, 0};
+    if (algo == GO_ALGO_DISTRIBUTE_EVENLY) {
+        /* A known name listed twice in the executor order is ONE key of availableNodes but is visited twice per pass by the
+         * loop over the slice (distribute_evenly.go:50): the capacity form below (a duplicate has capacity 0) only matches
+         * the literal code for tightly-pack.  The orders of the reference derive from map keys and never repeat a name
+         * (nodesorting.go:153-159), and the device ABI rejects duplicates; if a caller builds one anyway, the literal loops
+         * answer. */
+        uint8_t *seen = (uint8_t *)calloc((size_t)n_nodes + 1, 1);
+        int dup = 0;
+        if (seen)
+            for (uint32_t i = 0; i < n_x && !dup; ++i)
+                if (exec_order[i] < n_nodes) {
+                    dup = seen[exec_order[i]];
+                    seen[exec_order[i]] = 1;
+                }
+        free(seen);
+        if (dup)
+            return go_spark_binpack(algo, avail, n_nodes, app, driver_order, n_d, exec_order, n_x, driver_out, exec_out);
+    }
     const int64_t k = app->k;
     int64_t *c0 = (int64_t *)malloc(((size_t)n_x + 1) * sizeof(int64_t));
     /* pos_in_x[node] = position in exec order (first occurrence), or -1 */
