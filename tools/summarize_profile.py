@@ -58,15 +58,29 @@ def main():
     json.dump(tj, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as out:
         out.write(f"# rocprofv3 summary — {tag}\n\nCommand: `tools/profile_round.sh {tag}` on one MI355X (gfx950), "
-                  "i.e. `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline` "
-                  "and one `--pmc` pass per counter set (`--no-extras`).\n\n## kernel stats (all kernels of the bench run)\n\n")
+                  "i.e. `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30 "
+                  "--no-cpu-baseline`, the same with `--headline-only`, and one `--pmc` pass per counter set (FETCH_SIZE, "
+                  "WRITE_SIZE and the L2 pair on the headline alone; the SQ and LDS sets on the full run so that the FIFO chain "
+                  "kernels are covered).\n\n")
+        hstats = os.path.join(src, "stats_headline", "stats_kernel_stats.csv")
+        if os.path.exists(hstats):
+            shutil.copy(hstats, os.path.join(dst, f"{tag}_kernel_stats_headline.csv"))
+            out.write("## the headline alone (`--headline-only`: every dispatch of fit_independent_kernel is a headline launch)\n\n")
+            out.write("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
+            for r in csv.DictReader(open(hstats)):
+                if "fit_independent" in r["Name"] or "empty_kernel" in r["Name"]:
+                    out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
+            out.write("\n")
+        out.write("## kernel stats (all kernels of the full bench run)\n\n")
         out.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
         for r in krows:
             out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | "
                       f"{float(r['Percentage']):.3f} |\n")
-        out.write("\nNote: under `--stats` `fit_independent_kernel` covers every launch of the run (tightly-pack, "
-                  "distribute-evenly, nominal and congested batches); the PMC passes below run `--no-extras` and "
-                  "contain the headline tightly-pack launches only.\n\n## PMC passes (mean per launch)\n\n")
+        out.write("\nNote: in the full run `fit_independent_kernel` covers every launch (tightly-pack, distribute-evenly, "
+                  "nominal and congested batches, config 3 and 4, the host-entry batches that read their records over PCIe); the "
+                  "headline-only table above isolates the headline launches.  FETCH_SIZE / WRITE_SIZE / TCC passes ran "
+                  "`--headline-only`; the SQ / LDS passes ran the full bench (means over all launches of a kernel).\n\n"
+                  "## PMC passes (mean per launch)\n\n")
         out.write("| kernel | counter | launches | mean | min | max |\n|---|---|---|---|---|---|\n")
         for (k, c), v in pmc.items():
             if "fit_" not in k and "translate" not in k:
