@@ -348,22 +348,23 @@ def main():
                                       "(separate passes, gfx950 FETCH_SIZE x2 correction) — a committed profile, not this run"}
         except Exception:
             traffic_prof = None
-    # one launch at a time between its own pair of events: the kernel's duration without the gap to its neighbours (what
-    # rocprofv3 --kernel-trace --stats reports per dispatch; kern_ms above is the K-step window divided by K, gaps included)
+    # one launch at a time between its own pair of events on an idle stream: what a LONE batch costs (the launch is not
+    # overlapped with a predecessor).  kern_ms above — the K-step window divided by K — is what rocprofv3's average dispatch
+    # duration agrees with (profiles/<tag>_summary.md, headline-only table).
     singles = []
     for _ in range(60):
         ctx.timer_begin(stream)
         step(TIGHT)
         singles.append(ctx.timer_end())
-    kernel_only_ms = _median(singles[10:])
+    isolated_launch_ms = _median(singles[10:])
     achieved = visited_bytes / (kern_ms * 1e-3) / 1e9
     roofline = {
         "bound": "latency", "nominal_bound": "hbm",
         "kernel": "fit_independent_kernel<tightly-pack>", "kernel_ms": kern_ms,
-        "kernel_only_ms": kernel_only_ms,
-        "kernel_ms_note": "kernel_ms = HIP events around a K-step window / K (dispatch gaps included: what a batch costs in a "
-                          "stream of batches); kernel_only_ms = events around single launches (compare with the rocprofv3 "
-                          "average duration in profiles/)",
+        "isolated_launch_ms": isolated_launch_ms,
+        "kernel_ms_note": "kernel_ms = HIP events around a K-step window / K: what a batch costs in a stream of batches, and what "
+                          "the rocprofv3 average dispatch duration in profiles/ agrees with; isolated_launch_ms = events around one "
+                          "launch on an idle stream (a lone batch also pays the un-overlapped launch)",
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "bytes_counted": "visited (in-kernel counters of this run): the scan is lazy like the reference's loop",
         "visited_bytes_per_launch": visited_bytes,

@@ -16,7 +16,7 @@ BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 # the headline alone: every fit_independent_kernel dispatch of this trace is a headline launch (its average duration is the
-# figure bench.py's roofline.kernel_only_ms must agree with)
+# figure bench.py's roofline.kernel_ms must agree with)
 timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats_headline" -o stats -- $BENCH --headline-only > "$OUT/stats_headline.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -T -f csv -d "$OUT/pmc_fetch" -o pmc -- $BENCH --headline-only > "$OUT/pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -T -f csv -d "$OUT/pmc_write" -o pmc -- $BENCH --headline-only > "$OUT/pmc_write.log" 2>&1
