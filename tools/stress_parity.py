@@ -16,7 +16,8 @@ t_end = time.time() + budget
 n_cases = 0
 ctxs = {}
 for name, env in (("default", {}), ("generic", {"GANGFIT_FIFO_ZONED": "generic", "GANGFIT_FIFO_KERNEL": "v2"}),
-                  ("small-lds", {"GANGFIT_LDS_BUDGET": "50000"}), ("block-cooperative", {"GANGFIT_FIFO_SOLO": "0"})):
+                  ("small-lds", {"GANGFIT_LDS_BUDGET": "50000"}), ("block-cooperative", {"GANGFIT_FIFO_SOLO": "0"}),
+                  ("plain-paths", {"GANGFIT_SPARSE_GPU": "0", "GANGFIT_ZEROCOPY": "0", "GANGFIT_WAIT": "block"})):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     ctxs[name] = gangfit.Context(0)
@@ -57,6 +58,17 @@ while time.time() < t_end:
         sched[:, 1] *= 1 << 20
         drv[:, 1] *= 1 << 20
         exe[:, 1] *= 1 << 20
+    if rng.random() < 0.4:  # gpu nodes a minority: the sparse gpu view of the independent batch (most executors need a gpu)
+        frac = float(rng.choice([0.03, 0.1, 0.2]))
+        avail[:, 2] = np.where(rng.random(n) < frac, rng.integers(1, 9, size=n), rng.integers(-1, 1, size=n))
+        sched[:, 2] = np.maximum(avail[:, 2], 0) + rng.integers(0, 3, size=n)
+        exe[:, 2] = np.where(rng.random(a) < 0.7, rng.integers(1, 4, size=a), 0)
+    if rng.random() < 0.3:  # requests finer than the table's gcd units: the per-batch unit refinement of the int32 chains
+        f = int(rng.choice([2, 4, 6, 8]))
+        avail[:, 1] *= f
+        sched[:, 1] *= f
+        avail[:, 0] *= 2
+        sched[:, 0] *= 2
     if rng.random() < 0.5:  # a handful of templates: few distinct request shapes, runs of equal shapes (the indexed chains)
         t = rng.integers(0, min(a, int(rng.integers(1, 8))), size=a)
         drv, exe = drv[t], exe[t]
@@ -87,6 +99,14 @@ while time.time() < t_end:
                     bad = "fifo residual"
                 if bad:
                     bad = "FIFO " + bad
+            if bad is None and algo == 0 and cname == "default":  # findNodes, chained, on the same table
+                Xk = X[X < n]
+                fk = np.clip(k, 1, 50).astype(np.int32)
+                placed, last, off, nodes, adds = ctx.find_nodes(exe, fk, chained=True)
+                want = ob.find_nodes(avail, exe, fk, Xk, chained=True)
+                if not (np.array_equal(placed, want.placed) and np.array_equal(adds, want.adds) and
+                        np.array_equal(ctx.residual(), want.avail_after)):
+                    bad = "findNodes"
             n_cases += 1
             if bad:
                 print(f"MISMATCH seed={seed} ctx={cname} algo={algo} n={n} a={a} layout={layout} tight={tight} nz={nz} kcap={kcap}: {bad}")
