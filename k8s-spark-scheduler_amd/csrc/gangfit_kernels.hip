@@ -115,6 +115,16 @@ struct App {
     uint64_t exec_off;
 };
 
+// 1 / e for cap_dim, without the ~11 double-precision instructions (scale, rcp, four fma, fmas, fixup) of an IEEE division —
+// per dimension, per wavefront, on the critical path of every decision.  cap_dim needs a relative error below 2^-21 only
+// (K + 1 <= 2^20 + 1 quotient units must stay below one; its proof says 2^-50 because that is what the division gave): the
+// hardware estimate (V_RCP_F64, good to 2^-23 or better) plus one Newton step — error squared — is far inside that.
+// gf_selftest checks cap_dim with this reciprocal against a plain 64-bit divide on adversarial operands, on the device.
+__device__ __forceinline__ double fast_rcp(double e) {
+    const double r = __builtin_amdgcn_rcp(e);
+    return __builtin_fma(__builtin_fma(-e, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ App load_app(const gf_app* __restrict__ apps, uint32_t a) {
     const gf_app* p = apps + a;  // wave-uniform address: scalar loads
     App r;
@@ -127,9 +137,9 @@ __device__ __forceinline__ App load_app(const gf_app* __restrict__ apps, uint32_
     r.k = p->k;
     r.flags = p->flags;
     r.exec_off = p->exec_off;
-    r.rcp0 = r.exe0 > 0 ? 1.0 / (double)r.exe0 : 0.0;
-    r.rcp1 = r.exe1 > 0 ? 1.0 / (double)r.exe1 : 0.0;
-    r.rcp2 = r.exe2 > 0 ? 1.0 / (double)r.exe2 : 0.0;
+    r.rcp0 = r.exe0 > 0 ? fast_rcp((double)r.exe0) : 0.0;
+    r.rcp1 = r.exe1 > 0 ? fast_rcp((double)r.exe1) : 0.0;
+    r.rcp2 = r.exe2 > 0 ? fast_rcp((double)r.exe2) : 0.0;
     return r;
 }
 
@@ -1564,7 +1574,7 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
         default: a = -(int64_t)(splitmix64(s) >> 3); break;           // negative availability
         }
         if (a > lim) a = lim;
-        const double rcp = 1.0 / (double)e;
+        const double rcp = (it & 1u) ? fast_rcp((double)e) : 1.0 / (double)e;  // both reciprocals cap_dim is used with
         int32_t want;
         if (a < 0)
             want = 0;
