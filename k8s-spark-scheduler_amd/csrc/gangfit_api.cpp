@@ -161,6 +161,8 @@ struct gf_ctx {
     DeviceBuf<int32_t> d_wide_needed;       // set by prepare_apps_kernel when a request has no narrow form
     DeviceBuf<int32_t> d_capmat;            // minimal-fragmentation chain: capacity per (request shape, slot)
     bool fifo_minfrag_matrix = true;        // GANGFIT_MINFRAG_MATRIX=0 recomputes capacities in every pass
+    DeviceBuf<int32_t> d_mfhist;            // ... and the capacity histograms per (candidate view, request shape)
+    bool fifo_minfrag_hist = true;          // GANGFIT_MINFRAG_HIST=0: block-cooperative passes instead of the histogram path
     // narrow (scaled int32) form of the table: value = scaled * unit[dim]; exists when every |value / unit| < 2^30
     bool narrow_ok = false;
     int64_t unit[3] = {1, 1, 1};
@@ -422,9 +424,12 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     *run_if = nullptr;
     if (!(ctx->merged && ctx->narrow_ok && ctx->fifo_zoned_lds) || (zoned && (nz == 0 || nz > 16))) return GF_OK;
     const uint32_t zviews = zoned ? nz : 0u;
-    uint32_t n_shapes = 64;
-    while (n_shapes > 4 && gangfit::fifo_minfrag_lds_bytes(64, ctx->n_chunks, zviews, n_shapes) > ctx->lds_budget) n_shapes /= 2;
-    const size_t fixed = gangfit::fifo_minfrag_lds_bytes(0, ctx->n_chunks, zviews, n_shapes);
+    // 64 shape ids per role (rows of the capacity matrix, histograms); as many of them as LDS allows next to the masks also
+    // get chunk-index rows (64 down to 0 — the histogram path does without), then as much of the table as fits
+    const uint32_t n_shapes = 64;
+    uint32_t n_idx = 64;
+    while (n_idx > 0 && gangfit::fifo_minfrag_lds_bytes(64, ctx->n_chunks, zviews, n_idx) > ctx->lds_budget) n_idx /= 2;
+    const size_t fixed = gangfit::fifo_minfrag_lds_bytes(0, ctx->n_chunks, zviews, n_idx);
     if (ctx->lds_budget <= fixed + 12 * 64) return GF_OK;
     uint32_t lds_slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
     lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
@@ -435,12 +440,18 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     // capacity matrix: one int32 per (request shape, slot); skipped (capacities recomputed per pass) beyond 1 GiB
     int32_t* capmat = nullptr;
     if ((uint64_t)n_shapes * ctx->n_slots * sizeof(int32_t) <= (UINT64_C(1) << 30) && ctx->fifo_minfrag_matrix) {
-        GF_HIP(ctx, ctx->d_capmat.reserve((size_t)n_shapes * ctx->n_slots));
+        GF_HIP(ctx, ctx->d_capmat.reserve((size_t)n_shapes * ctx->n_slots + 2048));  // rows are read 2048 slots at a time
         capmat = ctx->d_capmat.ptr;
     }
+    int32_t* hist = nullptr;
+    if (capmat != nullptr && ctx->fifo_minfrag_hist) {
+        GF_HIP(ctx, ctx->d_mfhist.reserve(gangfit::fifo_minfrag_hist_words(zviews, n_shapes)));
+        hist = ctx->d_mfhist.ptr;
+    }
     GF_HIP(ctx, gangfit::launch_fit_fifo_minfrag_lds(zoned, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr, lds_slots,
-                                                     n_shapes, n_apps, d_apps, ctx->d_napps.ptr, ctx->d_wide_needed.ptr,
-                                                     d_results, d_exec_nodes, ctx->d_zexec.ptr, half, d_failed, capmat, stream));
+                                                     n_shapes, n_idx, n_apps, d_apps, ctx->d_napps.ptr, ctx->d_wide_needed.ptr,
+                                                     d_results, d_exec_nodes, ctx->d_zexec.ptr, half, d_failed, capmat, hist,
+                                                     ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
     *run_if = ctx->d_wide_needed.ptr;
     return GF_OK;
 }
@@ -677,6 +688,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (const char* z = std::getenv("GANGFIT_FIFO_SOLO")) ctx->fifo_solo = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
     if (const char* z = std::getenv("GANGFIT_MINFRAG_MATRIX")) ctx->fifo_minfrag_matrix = std::strcmp(z, "0") != 0;
+    if (const char* z = std::getenv("GANGFIT_MINFRAG_HIST")) ctx->fifo_minfrag_hist = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SPARSE_GPU")) ctx->sparse_gpu = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_ZEROCOPY")) ctx->zero_copy = std::strcmp(z, "0") != 0;
     if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;
@@ -733,6 +745,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_napps.release();
     ctx->d_wide_needed.release();
     ctx->d_capmat.release();
+    ctx->d_mfhist.release();
     ctx->d_nsnap.release();
     ctx->d_nwork.release();
     ctx->d_ncmax.release();

@@ -197,12 +197,17 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
 // LDS-resident, block-cooperative chain for minimal-fragmentation, plain (zoned = false) or single-AZ
 // (gangfit_fifo_minfrag.inc); same contract as launch_fit_fifo_zoned_lds.
 size_t fifo_minfrag_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes);
+// int32 words of the capacity histograms (one per candidate view and executor shape; gangfit_fifo_minfrag.inc)
+size_t fifo_minfrag_hist_words(uint32_t n_zones, uint32_t n_shapes);
 hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
-                                       const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
+                                       const int64_t* d_sched, uint32_t lds_slots,
+                                       uint32_t n_shapes /* shape ids per role */, uint32_t n_idx /* ... with index rows in LDS */,
+                                       uint32_t n_apps,
                                        const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
                                        int32_t* d_chain_failed_at, int32_t* d_capmat /* n_shapes x n_slots, nullable */,
-                                       hipStream_t stream);
+                                       int32_t* d_hist /* fifo_minfrag_hist_words, nullable: no histogram path */,
+                                       ScanStats* d_stats /* nullable */, hipStream_t stream);
 
 // ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
 // (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.

@@ -1919,31 +1919,46 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
     return hipGetLastError();
 }
 
+size_t fifo_minfrag_hist_words(uint32_t n_zones, uint32_t n_shapes) {
+    return 2 * (size_t)(n_zones ? n_zones : 1u) * n_shapes * (size_t)kMfBins;  // histograms, then first positions
+}
+
 size_t fifo_minfrag_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes) {
     return fifo_minfrag_fixed_lds(n_chunks, n_zones + 1, n_shapes) + 12 * (size_t)lds_slots;
 }
 
 hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
-                                       const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
+                                       const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_idx,
+                                       uint32_t n_apps,
                                        const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                       int32_t* d_chain_failed_at, int32_t* d_capmat, hipStream_t stream) {
+                                       int32_t* d_chain_failed_at, int32_t* d_capmat, int32_t* d_hist, ScanStats* d_stats,
+                                       hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
-    if ((zoned && zones.n_zones > 16) || !table.d_identity || n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
+    if ((zoned && zones.n_zones > 16) || !table.d_identity || n_shapes == 0 || n_shapes > kZShapes || n_idx > n_shapes)
+        return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return e;
+    if (d_capmat == nullptr) d_hist = nullptr;  // the histograms are patched together with the matrix
+    if (d_hist != nullptr) {
+        const size_t half_words = fifo_minfrag_hist_words(zoned ? zones.n_zones : 0u, n_shapes) / 2;
+        e = hipMemsetAsync(d_hist, 0, half_words * sizeof(int32_t), stream);  // histograms
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(d_hist + half_words, 0x7F, half_words * sizeof(int32_t), stream);  // first positions: kMfNoPos
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
                        (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_shapes);
+    const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_idx);
     if (zoned)
         e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
-                                 n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat);
+                                 n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, d_stats);
     else
         e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<false>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
-                                 n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat);
+                                 n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, d_stats);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);

@@ -53,11 +53,27 @@ class Workload:
     flags: np.ndarray  # (A,) uint32
 
 
-def reference_node_order(avail: np.ndarray) -> np.ndarray:
-    """Single-zone priority order of getNodeNamesInPriorityOrder (internal/sort/nodesorting.go:74-122):
-    free memory ascending, then free cpu ascending, then name — the node index stands for the name."""
+def reference_node_order(avail: np.ndarray, zone: Optional[np.ndarray] = None) -> np.ndarray:
+    """Priority order of getNodeNamesInPriorityOrder (internal/sort/nodesorting.go:74-122): AZ priority first (zones ranked
+    by their summed free resources, memory then cpu, ascending — :98-104; ties keep the zone id order here, the reference's
+    sort.Slice leaves them unspecified), then free memory ascending, then free cpu ascending, then name — the node index
+    stands for the name.  One zone (zone=None): the order of the resources alone."""
     idx = np.arange(len(avail))
-    return np.lexsort((idx, avail[:, 0], avail[:, 1])).astype(np.uint32)
+    if zone is None:
+        return np.lexsort((idx, avail[:, 0], avail[:, 1])).astype(np.uint32)
+    zone = np.asarray(zone).astype(np.int64)
+    nz = int(zone.max()) + 1 if len(zone) else 0
+    zsum = np.zeros((nz, 2), dtype=object)
+    for z in range(nz):  # python ints: the sums of 10^5 byte counts stay exact
+        sel = zone == z
+        zsum[z, 0] = int(avail[sel, 1].astype(object).sum()) if sel.any() else 0
+        zsum[z, 1] = int(avail[sel, 0].astype(object).sum()) if sel.any() else 0
+    present = [z for z in range(nz) if (zone == z).any()]
+    ranked = sorted(present, key=lambda z: (zsum[z, 0], zsum[z, 1], z))
+    prio = np.zeros(nz, dtype=np.int64)
+    for r, z in enumerate(ranked):
+        prio[z] = r
+    return np.lexsort((idx, avail[:, 0], avail[:, 1], prio[zone])).astype(np.uint32)
 
 
 def make_snapshot(n_nodes: int, seed: int, used_lo: float = 0.0, used_hi: float = 0.9) -> Snapshot:

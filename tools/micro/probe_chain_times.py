@@ -20,6 +20,16 @@ for algo, name, reps in ((0, "tight", 7), (1, "even", 7), (4, "saz-tight", 4), (
     for _ in range(reps):
         t0 = time.perf_counter(); ctx.fit_batch(1, algo, apps); ts.append((time.perf_counter() - t0) * 1e3)
     out.append(f"{name} {min(ts):.3f}")
+# the reference's own order is AZ-major (nodesorting.go:82-122): every zone is a contiguous range of the priority order
+zo = wl.reference_node_order(s.avail, zone3)
+ctx.set_orders(zo, zo)
+for algo, name, reps in ((3, "azmajor:az-aware", 4), (4, "azmajor:saz-tight", 4), (5, "azmajor:saz-minfrag", 2)):
+    ctx.fit_batch(1, algo, apps)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); ctx.fit_batch(1, algo, apps); ts.append((time.perf_counter() - t0) * 1e3)
+    out.append(f"{name} {min(ts):.3f}")
+ctx.set_orders(s.driver_order, s.exec_order)
 a2, tk = gangfit.with_offsets(apps)
 import torch
 dev = torch.device("cuda:0")

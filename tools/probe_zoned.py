@@ -11,8 +11,13 @@ w = wl.headline(n_nodes, 1000)
 s = w.snapshot
 ctx = gangfit.Context(0)
 ctx.set_snapshot(s.avail, s.sched)
-ctx.set_zones((wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32))
-ctx.set_orders(s.driver_order, s.exec_order)
+zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32)
+ctx.set_zones(zone)
+if len(sys.argv) > 3 and sys.argv[3] == "azmajor":  # the reference's own order: zones are contiguous ranges (nodesorting.go:82-122)
+    zo = wl.reference_node_order(s.avail, zone)
+    ctx.set_orders(zo, zo)
+else:
+    ctx.set_orders(s.driver_order, s.exec_order)
 apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
 for algo in (4, 3):
     ctx.fit_batch(1, algo, apps)
