@@ -670,23 +670,34 @@ def main():
 
             happs = gangfit.make_apps(base.drv, base.exe, base.k, base.flags)
             zone3 = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+            # three zones; the priority order is the reference's own: AZ-major (nodesorting.go:82-122 sorts by AZ priority first),
+            # so every zone is a contiguous range of it.  The same zones scattered over the single-zone order (what rounds 1 and
+            # 2 measured: no extender produces it) is kept as `zones_interleaved_*` for continuity.
+            zorder = wl.reference_node_order(s.avail, zone3)
             ctx.set_snapshot(s.avail, s.sched)
             ctx.set_zones(zone3)
-            ctx.set_orders(s.driver_order, s.exec_order)
-            SAZ, MF, SAZMF = (gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.GF_ALGO_MINIMAL_FRAGMENTATION,
-                              gangfit.GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)
-            for name, algo, n_fifo in (("single_az_tightly_pack", SAZ, 20), ("minimal_fragmentation", MF, 10),
-                                       ("single_az_minimal_fragmentation", SAZMF, 6)):
+            SAZ, MF, SAZMF, AZA = (gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.GF_ALGO_MINIMAL_FRAGMENTATION,
+                                   gangfit.GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION, gangfit.GF_ALGO_AZ_AWARE_TIGHTLY_PACK)
+            for name, algo, n_fifo in (("single_az_tightly_pack", SAZ, 20), ("az_aware_tightly_pack", AZA, 10),
+                                       ("minimal_fragmentation", MF, 10), ("single_az_minimal_fragmentation", SAZMF, 10)):
+                zoned = algo != MF
+                order = zorder if zoned else s.exec_order
+                ctx.set_orders(order, order)
                 p50, _ = host_ms(lambda: ctx.fit_batch(IND, algo, happs), n=10)
                 flat, _ = fifo_latency(ctx, algo, happs, n_fifo, warm=1)
-                extras[name] = {"zones": 3 if algo != MF else 1,
+                extras[name] = {"zones": 3 if zoned else 1, "priority_order": "az-major (reference)" if zoned else "single zone (reference)",
                                 "independent_decisions_per_s_host_entry": len(happs) / (p50 * 1e-3),
                                 "fifo_filter_p50_ms": _percentile(flat, 0.5), "fifo_filter_p99_ms": _percentile(flat, 0.99)}
                 if not args.no_cpu_baseline:
                     extras[name]["fifo_filter_cpu_baseline"] = cpu_chain_baseline(
-                        int(algo), s.avail, s.sched, zone3 if algo != MF else None, s.driver_order, s.exec_order, base.drv, base.exe,
+                        int(algo), s.avail, s.sched, zone3 if zoned else None, order, order, base.drv, base.exe,
                         base.k, base.flags, reps=2)
                     extras[name]["speedup_vs_cpu_p50"] = extras[name]["fifo_filter_cpu_baseline"]["p50_ms"] / extras[name]["fifo_filter_p50_ms"]
+                if zoned:
+                    ctx.set_orders(s.driver_order, s.exec_order)
+                    flat, _ = fifo_latency(ctx, algo, happs, 4, warm=1)
+                    extras[name]["zones_interleaved_fifo_filter_p50_ms"] = _percentile(flat, 0.5)
+            ctx.set_orders(s.driver_order, s.exec_order)
             exe_reqs = np.ascontiguousarray(base.exe)
             p50, _ = host_ms(lambda: ctx.executor_fit(exe_reqs))
             m50, _ = host_ms(lambda: ctx.executor_fit(exe_reqs, minimal_fragmentation=True))

@@ -165,8 +165,9 @@ def test_headline_size(gf_ctx):
 
 
 @pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "60000"},
-                                 {"GANGFIT_MINFRAG_MATRIX": "0"}],
-                         ids=["lds-chain", "generic-chain", "lds-chain-global-tail", "lds-chain-no-capacity-matrix"])
+                                 {"GANGFIT_MINFRAG_MATRIX": "0"}, {"GANGFIT_MINFRAG_HIST": "0"}, {"GANGFIT_LDS_BUDGET": "30000"}],
+                         ids=["lds-chain", "generic-chain", "lds-chain-global-tail", "lds-chain-no-capacity-matrix",
+                              "lds-chain-block-passes", "lds-chain-few-index-rows"])
 @pytest.mark.parametrize("algo", [MF, SAZMF])
 def test_fifo_chain_kernel_variants(algo, env):
     """The block-cooperative LDS chain (gangfit_fifo_minfrag.inc), the generic global-memory chain and the hybrid
@@ -202,5 +203,55 @@ def test_fifo_chain_kernel_variants(algo, env):
             assert gpu.failed_at == ref.failed_at
             _assert_same(gpu, ref, apps)
             assert np.array_equal(ctx.residual(), ref.avail_after)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"GANGFIT_MINFRAG_HIST": "0"}], ids=["histograms", "block-passes"])
+@pytest.mark.parametrize("algo", [MF, SAZMF])
+def test_fifo_chain_histogram_path(algo, env):
+    """What the histogram path of gangfit_fifo_minfrag.inc has to get right: the AZ-major priority order of the reference
+    (zones are contiguous ranges), a handful of templates (rows and histograms reused and patched across hundreds of commits),
+    tiny executor requests next to them (capacities of 256 and more: those shapes keep the block-cooperative passes, in the
+    same chain), drivers that share a node with their executors, level walks over many levels and gangs of several hundred."""
+    import os
+
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = gangfit.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    oalgo = ob.ALGO_MINIMAL_FRAGMENTATION if algo == MF else ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION
+    rng = np.random.default_rng(4242 + algo)
+    try:
+        for rep in range(4):
+            n, a = (6000, 400) if rep < 2 else (1200, 300)
+            w = wl.headline(n, a, seed=0x77 + rep)
+            s = w.snapshot
+            zone = (wl.splitmix64(0xB1 + rep, n, 3) % np.uint64(3 if algo == SAZMF else 1)).astype(np.uint32)
+            order = wl.reference_node_order(s.avail, zone if algo == SAZMF else None)
+            drv, exe, k = w.drv.copy(), w.exe.copy(), w.k.copy()
+            t = rng.integers(0, 9, size=a)  # nine templates
+            drv, exe = drv[t], exe[t]
+            if rep % 2 == 1:
+                tiny = rng.random(a) < 0.1
+                exe[tiny] = np.array([100, 256 << 20, 0])  # hundreds of executors per node
+                k = np.where(rng.random(a) < 0.15, rng.integers(100, 500, size=a), k).astype(np.int32)
+            if rep >= 2:  # a drained cluster: many small capacities, gangs spread over many levels
+                k = np.minimum(k * 6, 400).astype(np.int32)
+            flags = (rng.random(a) < 0.9).astype(np.uint32)
+            _setup(ctx, s.avail, s.sched, zone, order, order)
+            apps = gangfit.make_apps(drv, exe, k, flags)
+            gpu = ctx.fit_batch(FIFO, algo, apps)
+            ref = ob.fit_fifo_chain(oalgo, s.avail, ob.make_apps(drv, exe, k, flags), order, order, sched=s.sched, zone=zone)
+            assert gpu.failed_at == ref.failed_at
+            _assert_same(gpu, ref, apps)
+            assert np.array_equal(ctx.residual(), ref.avail_after)
+            assert ref.results["has_capacity"].sum() > 20
     finally:
         ctx.close()

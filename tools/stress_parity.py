@@ -17,7 +17,7 @@ n_cases = 0
 ctxs = {}
 for name, env in (("default", {}), ("generic", {"GANGFIT_FIFO_ZONED": "generic", "GANGFIT_FIFO_KERNEL": "v2"}),
                   ("small-lds", {"GANGFIT_LDS_BUDGET": "50000"}), ("block-cooperative", {"GANGFIT_FIFO_SOLO": "0"}),
-                  ("plain-paths", {"GANGFIT_SPARSE_GPU": "0", "GANGFIT_ZEROCOPY": "0", "GANGFIT_WAIT": "block"})):
+                  ("plain-paths", {"GANGFIT_SPARSE_GPU": "0", "GANGFIT_ZEROCOPY": "0", "GANGFIT_WAIT": "block", "GANGFIT_MINFRAG_HIST": "0"})):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     ctxs[name] = gangfit.Context(0)
