@@ -1940,13 +1940,7 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
     hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return e;
     if (d_capmat == nullptr) d_hist = nullptr;  // the histograms are patched together with the matrix
-    if (d_hist != nullptr) {
-        const size_t half_words = fifo_minfrag_hist_words(zoned ? zones.n_zones : 0u, n_shapes) / 2;
-        e = hipMemsetAsync(d_hist, 0, half_words * sizeof(int32_t), stream);  // histograms
-        if (e != hipSuccess) return e;
-        e = hipMemsetAsync(d_hist + half_words, 0x7F, half_words * sizeof(int32_t), stream);  // first positions: kMfNoPos
-        if (e != hipSuccess) return e;
-    }
+    // (no initialisation of d_hist: the row fill of a shape writes every bin of its histograms and first positions)
     hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
                        (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
     if ((e = hipGetLastError()) != hipSuccess) return e;
