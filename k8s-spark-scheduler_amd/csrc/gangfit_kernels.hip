@@ -1898,7 +1898,8 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
     // one wavefront per candidate view; the rest of the workgroup only helps with the prologue and shares every barrier and
     // the per-app control flow, i.e. takes issue slots from the views' wavefronts: no more wavefronts than views need
     const uint32_t n_cand = zones.n_zones + (az_aware ? 1u : 0u);
-    const int wg_waves = n_cand <= 4 ? 4 : (n_cand <= 8 ? 8 : 16);
+    // ... plus one that expands the winner's placement behind the commit barrier (none left with 16 views)
+    const int wg_waves = n_cand < 4 ? 4 : (n_cand < 8 ? 8 : 16);
 #define GF_ZL(AZ, NWV)                                                                                                      \
     e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<AZ, NWV>, NWV, lds, stream, table, ntable, zones, d_sched, lds_slots, \
                              n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,      \

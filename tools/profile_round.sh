@@ -25,7 +25,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLE
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE -T -f csv -d "$OUT/pmc_lds" -o pmc -- $BENCH > "$OUT/pmc_lds.log" 2>&1
 # the whole Filter through the C++ mirror of the reference's interface (three configurations; profiles/<tag>_host_filter.txt)
 if [ -x "$ROOT/k8s-spark-scheduler_amd/host_bench" ]; then
-  ( cd "$ROOT/k8s-spark-scheduler_amd" && timeout 100 ./host_bench 10000 1000 2000 tightly-pack; timeout 100 ./host_bench 10000 1000 2000 single-az-tightly-pack; timeout 200 ./host_bench 100000 1000 20000 tightly-pack ) > "$OUT/host_filter.txt" 2>&1
+  ( cd "$ROOT/k8s-spark-scheduler_amd" && timeout 100 ./host_bench 10000 1000 2000 tightly-pack; timeout 100 ./host_bench 10000 1000 2000 single-az-tightly-pack; timeout 100 ./host_bench 10000 1000 2000 single-az-minimal-fragmentation; timeout 200 ./host_bench 100000 1000 20000 tightly-pack ) > "$OUT/host_filter.txt" 2>&1
 fi
 find "$OUT" -name '*.csv' | head -40
 grep -h '^{' "$OUT"/*.log | cut -c1-300 | head -8
