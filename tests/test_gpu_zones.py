@@ -244,3 +244,22 @@ def test_zoned_fifo_chain_kernel_variants(algo, env):
             assert np.array_equal(ctx.residual(), ref.avail_after)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("algo", [SAZ, AZA])
+def test_zoned_fifo_chain_az_major_order(gf_ctx, algo):
+    """The order the reference's extender actually produces: AZ-major (nodesorting.go:82-122) — every zone a contiguous range of
+    the priority lists — at the headline size, 1 000 applications, against the literal oracle incl. residuals."""
+    w = wl.headline(10000, 1000)
+    s = w.snapshot
+    zone = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+    order = wl.reference_node_order(s.avail, zone)
+    _setup(gf_ctx, s.avail, s.sched, zone, order, order)
+    flags = (np.arange(len(w.k)) % 11 != 0).astype(np.uint32)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, flags)
+    gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps)
+    ref = ob.fit_fifo_chain(O_ALGO[algo], s.avail, ob.make_apps(w.drv, w.exe, w.k, flags), order, order, sched=s.sched, zone=zone)
+    assert gpu.failed_at == ref.failed_at
+    _assert_same(gpu, ref, apps)
+    assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+    assert ref.results["has_capacity"].sum() > 900
