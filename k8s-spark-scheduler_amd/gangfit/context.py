@@ -153,11 +153,16 @@ class Context:
         self._cluster_n = n
 
     def build_snapshot_resident(self, res_node=None, res_req=None, node_flags=None, driver_label_rank=None,
-                                exec_label_rank=None, want_orders: bool = True):
+                                exec_label_rank=None, want_orders: bool = True, res_cols=None):
+        """gf_snapshot_build_resident.  res_cols = (cpu, mem, gpu) contiguous int64 columns of the reservation entries, for
+        callers that keep them that way (the C ABI takes columns; res_req = (n, 3) rows is split here on every call)."""
         n = self._cluster_n
         rn = np.zeros(0, dtype=np.uint32) if res_node is None else np.ascontiguousarray(res_node, dtype=np.uint32)
-        rr = np.zeros((0, 3), dtype=np.int64) if res_req is None else np.ascontiguousarray(res_req, dtype=np.int64).reshape(-1, 3)
-        rcols = [np.ascontiguousarray(rr[:, j]) for j in range(3)]
+        if res_cols is not None:
+            rcols = [np.ascontiguousarray(c, dtype=np.int64) for c in res_cols]
+        else:
+            rr = np.zeros((0, 3), dtype=np.int64) if res_req is None else np.ascontiguousarray(res_req, dtype=np.int64).reshape(-1, 3)
+            rcols = [np.ascontiguousarray(rr[:, j]) for j in range(3)]
         fl = None if node_flags is None else np.ascontiguousarray(node_flags, dtype=np.uint32)
         dl = None if driver_label_rank is None else np.ascontiguousarray(driver_label_rank, dtype=np.uint32)
         el = None if exec_label_rank is None else np.ascontiguousarray(exec_label_rank, dtype=np.uint32)
