@@ -1,5 +1,5 @@
 // Drop into /root/reference/internal/extender/ (package extender: it calls the unexported sparkResourceUsage and
-// findNodes) next to copies of tests/golden/gangfit_golden_v1.json and gangfit_golden_v2.json, then on a machine with
+// findNodes) next to copies of tests/golden/gangfit_golden_v1.json, gangfit_golden_v2.json and gangfit_golden_v3.json, then on a machine with
 // Go 1.19:
 //
 //	go test -mod=vendor -run TestGangfitGolden ./internal/extender/              # diff the REAL packers against the fixtures
@@ -281,7 +281,7 @@ func runFindNodes(t *testing.T, c *goldenCase, want *goldenFindNodes) goldenFind
 }
 
 func TestGangfitGolden(t *testing.T) {
-	for _, file := range []string{"gangfit_golden_v1.json", "gangfit_golden_v2.json"} {
+	for _, file := range []string{"gangfit_golden_v1.json", "gangfit_golden_v2.json", "gangfit_golden_v3.json"} {
 		raw, err := os.ReadFile(file)
 		if err != nil {
 			t.Fatalf("%s: %v (copy it from tests/golden/ of the gangfit repository)", file, err)

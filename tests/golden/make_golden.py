@@ -141,6 +141,77 @@ def main_v2():
     print(out, os.path.getsize(out), "bytes")
 
 
+def az_major_order(avail, zone):
+    """getNodeNamesInPriorityOrder (internal/sort/nodesorting.go:82-122): AZ priority (zones by summed free memory, then cpu,
+    ascending), then free memory, free cpu, name."""
+    n = len(avail)
+    zs = sorted(set(int(z) for z in zone), key=lambda z: (int(avail[zone == z, 1].sum()), int(avail[zone == z, 0].sum()), z))
+    prio = {z: r for r, z in enumerate(zs)}
+    return np.array(sorted(range(n), key=lambda i: (prio[int(zone[i])], int(avail[i, 1]), int(avail[i, 0]), i)), dtype=np.uint32)
+
+
+def round3_cases():
+    """What round 2's chain kernels added paths for: the reference's AZ-major priority order with a handful of request
+    templates (capacity rows, histograms and first positions reused and patched over a whole chain), minimal-fragmentation
+    gangs that walk several capacity levels and end on a partially drained one, tiny executor requests (capacities in the
+    hundreds) next to ordinary ones, drivers that share a node with their executors."""
+    out = []
+    rng = np.random.default_rng(20260923)
+    # (1) three zones, AZ-major order, six templates, 36 applications
+    n = 210
+    alloc = np.array([[16000, 64, 0], [32000, 128, 0], [64000, 256, 8]], dtype=np.int64)[rng.integers(0, 3, size=n)]
+    used = (rng.random((n, 3)) * 0.9 * alloc).astype(np.int64)
+    used[:, 0] = used[:, 0] // 250 * 250
+    avail = alloc - used
+    avail[rng.random(n) < 0.03] = [-500, -1, 0]
+    zone = rng.integers(0, 3, size=n).astype(np.uint32)
+    order = az_major_order(avail, zone)
+    tmpl_d = np.array([[1000, 2, 0], [2000, 4, 0], [500, 1, 0], [1000, 8, 0], [4000, 4, 0], [1000, 2, 1]], dtype=np.int64)
+    tmpl_x = np.array([[1000, 4, 0], [2000, 8, 0], [4000, 16, 0], [500, 2, 0], [8000, 8, 0], [1000, 4, 1]], dtype=np.int64)
+    t = rng.integers(0, 6, size=36)
+    k = np.minimum(1 + rng.geometric(1 / 9.0, size=36), 60).astype(np.int32)
+    out.append(dict(name="AZ-major order, three zones, six templates", avail=avail, sched=alloc.copy(), zone=zone, D=order, X=order,
+                    drv=tmpl_d[t], exe=tmpl_x[t], k=k, flags=(rng.random(36) < 0.9).astype(np.uint32), fifo_k=k, fifo_exe=tmpl_x[t]))
+    # (2) minimal-fragmentation level walks: capacities for exe (1000 m, 1, 0) are small and repeated (1, 2, 3, 5, 8), the
+    #     gangs need several levels, leave remainders that a lower level can or cannot take, and hit capacity == K exactly
+    caps = np.array([1, 2, 3, 5, 8, 2, 3, 1, 5, 2, 3, 3, 1, 8, 2, 5, 1, 1, 2, 3] * 4, dtype=np.int64)
+    n = len(caps)
+    avail = np.stack([caps * 1000 + 300, caps + 0, np.zeros(n, dtype=np.int64)], axis=1)
+    order = np.arange(n, dtype=np.uint32)
+    ks = np.array([8, 9, 11, 13, 16, 4, 21, 6, 30, 7, 2, 17, 40, 3, 5, 26], dtype=np.int32)
+    a = len(ks)
+    out.append(dict(name="minimal-fragmentation level walks", avail=avail, sched=avail + [1000, 1, 0], zone=(order // 27).astype(np.uint32),
+                    D=order, X=order, drv=np.array([[300, 0, 0]] * a, dtype=np.int64), exe=np.array([[1000, 1, 0]] * a, dtype=np.int64),
+                    k=ks, flags=np.ones(a, dtype=np.uint32), fifo_k=ks, fifo_exe=np.array([[1000, 1, 0]] * a, dtype=np.int64)))
+    # (3) tiny requests (hundreds of executors per node) between ordinary ones, two zones in AZ-major order
+    n = 96
+    avail = np.stack([rng.integers(4, 64, size=n) * 1000, rng.integers(8, 256, size=n), np.zeros(n, dtype=np.int64)], axis=1).astype(np.int64)
+    zone = rng.integers(0, 2, size=n).astype(np.uint32)
+    order = az_major_order(avail, zone)
+    exe = np.array([[100, 1, 0], [2000, 8, 0], [50, 1, 0], [1000, 4, 0], [100, 1, 0], [4000, 16, 0]] * 3, dtype=np.int64)
+    a = len(exe)
+    k = np.array([300, 12, 500, 7, 90, 3] * 3, dtype=np.int32)
+    out.append(dict(name="tiny and ordinary requests, two zones", avail=avail, sched=avail + [8000, 32, 0], zone=zone, D=order, X=order,
+                    drv=np.array([[1000, 2, 0]] * a, dtype=np.int64), exe=exe, k=k, flags=np.ones(a, dtype=np.uint32), fifo_k=k,
+                    fifo_exe=exe))
+    return out
+
+
+def main_v3():
+    cases = []
+    for p in round3_cases():
+        case = {key: np.asarray(v).tolist() for key, v in p.items() if key != "name"}
+        case.update(name=p["name"], seed=0, n_nodes=len(p["avail"]))
+        answers_for(p, case)
+        cases.append(case)
+    out = os.path.join(HERE, "gangfit_golden_v3.json")
+    with open(out, "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py (main_v3)", "oracle": "oracle/gangfit_oracle.c (literal loops)",
+                   "units": "cpu milli-cores, memory and gpu in whole units; node i is named n%05d, zone z is named z%d",
+                   "algos": ALGOS, "cases": cases}, f, separators=(",", ":"))
+    print(out, os.path.getsize(out), "bytes")
+
+
 def main():
     cases = []
     for seed, n, a, tight in [(1, 6, 12, True), (2, 70, 24, True), (3, 130, 24, False), (4, 64, 16, True)]:
@@ -175,3 +246,4 @@ def main():
 if __name__ == "__main__":
     main()
     main_v2()
+    main_v3()
