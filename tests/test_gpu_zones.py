@@ -263,3 +263,26 @@ def test_zoned_fifo_chain_az_major_order(gf_ctx, algo):
     _assert_same(gpu, ref, apps)
     assert np.array_equal(gf_ctx.residual(), ref.avail_after)
     assert ref.results["has_capacity"].sum() > 900
+
+
+@pytest.mark.parametrize("nz", [15, 16, 17])
+def test_zoned_fifo_chains_many_zones(gf_ctx, nz):
+    """Sixteen candidate views are what one workgroup holds: with 15 a wavefront is left to expand the winner's placement / to
+    patch the min-frag tables, with 16 none is (the winner does it itself), 17 candidates (az-aware with 16 zones, any packer
+    with 17) run the generic chain."""
+    from test_gpu_minfrag import SAZMF
+    for seed in range(2):
+        rng = np.random.default_rng(1000 + 7 * nz + seed)
+        n, a = (700, 90) if seed == 0 else (2500, 70)
+        avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, n, a, seed == 0, "merged", nz)
+        exe = np.maximum(exe, 1)
+        k = np.minimum(k, 30 if seed == 0 else 400).astype(np.int32)
+        flags = (rng.random(a) < 0.9).astype(np.uint32)
+        _setup(gf_ctx, avail, sched, zone, D, X)
+        apps = gangfit.make_apps(drv, exe, k, flags)
+        for algo, oalgo in ((AZA, O_ALGO[AZA]), (SAZ, O_ALGO[SAZ]), (SAZMF, ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)):
+            gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps)
+            ref = ob.fit_fifo_chain(oalgo, avail, ob.make_apps(drv, exe, k, flags), D, X, sched=sched, zone=zone)
+            assert gpu.failed_at == ref.failed_at
+            _assert_same(gpu, ref, apps)
+            assert np.array_equal(gf_ctx.residual(), ref.avail_after)
