@@ -276,6 +276,37 @@ def main():
         walls = [a for a, _ in ws]
         return _median(walls), _median([b for _, b in ws]), walls
 
+    def timed_graph(fn, steps, warmup, windows):
+        """timed(), with the K steps of a window submitted as one recorded graph (single rank; falls back to eager submission)."""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        g = None
+        try:
+            ctx.graph_begin(stream)
+            for _ in range(steps):
+                fn()
+            g = ctx.graph_end(stream)
+        except Exception:
+            g = None
+        if g is None or dist is not None:
+            if g is not None:
+                ctx.graph_destroy(g)
+            return timed(fn, steps, 0, windows) + ("eager",)
+        walls_, kerns_ = [], []
+        for i in range(max(1, windows) + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.timer_begin(stream)
+            ctx.graph_launch(g, stream)
+            ev = ctx.timer_end()
+            torch.cuda.synchronize()
+            if i:
+                walls_.append(time.perf_counter() - t0)
+                kerns_.append(ev / steps)
+        ctx.graph_destroy(g)
+        return _median(walls_), _median(kerns_), walls_, "graph"
+
     # The K steps of a window are submitted as ONE recorded graph (gf_graph_*: K kernel nodes, the same launches the eager
     # calls make): a 1 000-application batch takes about as long on the device as the host needs to submit one kernel, so
     # eager submission measures the host.  The eager figure (one gf_fit_batch_dev call per step) is reported next to it.
@@ -618,8 +649,8 @@ def main():
         try:
             # distribute-evenly on the same batch
             esteps = min(args.steps, 400)
-            wall_e, kern_e, _ = timed(lambda: step(EVEN), esteps, max(2, args.warmup // 4), 3)
-            extras["distribute_evenly"] = {"decisions_per_s": len(apps) * esteps / wall_e, "kernel_ms": kern_e}
+            wall_e, kern_e, _, how_e = timed_graph(lambda: step(EVEN), esteps, max(2, args.warmup // 4), 3)
+            extras["distribute_evenly"] = {"decisions_per_s": len(apps) * esteps / wall_e, "kernel_ms": kern_e, "submission": how_e}
             # congested cluster (usage ~U[0.95,1]): ~half of the gangs do not fit -> full scans + driver fallback
             wc = wl.headline(args.nodes, args.apps, congested=True)
             sc = wc.snapshot
@@ -634,7 +665,7 @@ def main():
                                   stream=stream)
 
             csteps = max(10, min(args.steps, 400) // 4)
-            wall_c, kern_c, _ = timed(cstep, csteps, 3, 3)
+            wall_c, kern_c, _, how_c = timed_graph(cstep, csteps, 3, 3)
             ctx.scan_stats(enable=True, reset=True)
             cstep()
             torch.cuda.synchronize()
@@ -645,7 +676,7 @@ def main():
             clat, _ = fifo_latency(ctx, TIGHT, capps, 20, warm=2)
             extras["congested"] = {
                 "workload": wc.name, "feasible_fraction": float(res["has_capacity"].mean()),
-                "decisions_per_s": len(capps) * csteps / wall_c, "kernel_ms": kern_c,
+                "decisions_per_s": len(capps) * csteps / wall_c, "kernel_ms": kern_c, "submission": how_c,
                 "achieved_GBps_visited": cvis / (kern_c * 1e-3) / 1e9,
                 "frac_of_hbm_peak_visited": cvis / (kern_c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "algorithmic_full_scan_GBps": cb / (kern_c * 1e-3) / 1e9,
@@ -787,8 +818,8 @@ def main():
                 def step3():
                     ctx.fit_batch_dev(IND, algo, len(apps3), d_apps3.data_ptr(), d_res3.data_ptr(), d_exec3.data_ptr(), total_k3,
                                       stream=stream)
-                wall_3, kern_3, _ = timed(step3, 20, 3, 5)
-                c3[name] = {"decisions_per_s": len(apps3) * 20 / wall_3, "kernel_ms": kern_3,
+                wall_3, kern_3, _, how3 = timed_graph(step3, 20, 3, 5)
+                c3[name] = {"decisions_per_s": len(apps3) * 20 / wall_3, "kernel_ms": kern_3, "submission": how3,
                             "algorithmic_full_scan_GBps": wl.algorithmic_bytes(len(w3.snapshot.exec_order), w3.k) / (kern_3 * 1e-3) / 1e9}
             extras["config3_10k_nodes_x_10k_apps"] = c3
         except Exception as e:  # keep what was measured; the headline line must still be printed
