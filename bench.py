@@ -787,6 +787,24 @@ def main():
                 t2 = time.perf_counter()
                 if i >= 3:
                     lat5.append((t2 - t0) * 1e3)
+            # the same Filter with the usage sums resident too (gf_usage_apply): what changes between two Filters is a
+            # handful of reservations — here one application's K + 1 entries leave and another one's arrive per call
+            ctx.usage_reset()
+            ctx.usage_apply(rnode, res_cols=rcols5, sign=+1)
+            latu = []
+            starts5 = np.concatenate([[0], np.cumsum(ks)])
+            for i in range(min(n_calls5, 100) + 3):
+                rolled = np.roll(q5, -i)
+                j = i % len(ks)
+                sl = slice(int(starts5[j]), int(starts5[j + 1]))
+                dn, dc = rnode[sl], [c[sl] for c in rcols5]
+                t0 = time.perf_counter()
+                ctx.usage_apply(dn, res_cols=dc, sign=-1)   # this application's reservations went away ...
+                ctx.usage_apply(dn, res_cols=dc, sign=+1)   # ... and (the same entries, as another application's) arrived
+                ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+                ctx.fit_batch(FIFO, TIGHT, rolled)
+                if i >= 3:
+                    latu.append((time.perf_counter() - t0) * 1e3)
             # the chain by itself, on the snapshot the last build left (gf_snapshot_build returns before its kernels finish, so
             # the second half of a Filter call above is not the chain alone)
             for i in range(min(n_calls5, 60) + 2):
@@ -798,6 +816,9 @@ def main():
             c5 = {"nodes": n5, "reservation_entries": int(len(rnode)), "earlier_drivers": len(q5) - 1, "calls": len(lat5),
                   "filter_p50_ms": _percentile(lat5, 0.5), "filter_p99_ms": _percentile(lat5, 0.99),
                   "chain_only_p50_ms": _percentile(chain5, 0.5), "chain_only_p99_ms": _percentile(chain5, 0.99),
+                  "filter_resident_usage_p50_ms": _percentile(latu, 0.5), "filter_resident_usage_p99_ms": _percentile(latu, 0.99),
+                  "filter_resident_usage": "two gf_usage_apply calls (one application's entries out, one's in) + "
+                                           "gf_snapshot_build_resident(GF_RESIDENT_USAGE) + the chain: no reservation list travels",
                   "filter": "gf_snapshot_build_resident (reservation replay + metadata + sort + slot tables on the device; the cluster's "
                             "static columns resident: gf_cluster_set) + the FIFO chain, host entry points incl. H2D/D2H",
                   "chain_failed_at": o5.failed_at}

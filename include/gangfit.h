@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GF_VERSION 200 /* 0.2.0 */
+#define GF_VERSION 201 /* 0.2.0 */
 
 /* ---- status codes ---- */
 #define GF_OK 0
@@ -177,6 +177,18 @@ int gf_snapshot_build_resident(gf_ctx *ctx, uint32_t n_res, const uint32_t *res_
                                const int64_t *res_mem_bytes, const int64_t *res_gpu, const uint32_t *node_flags,
                                const uint32_t *driver_label_rank, const uint32_t *exec_label_rank,
                                uint32_t *driver_order_out, uint32_t *n_d_out, uint32_t *exec_order_out, uint32_t *n_x_out);
+/* The third step of keeping the snapshot resident ("keep snapshot resident on device across requests and
+ * apply deltas"): the per-node usage sums of UsageForNodes (LIB/resources/resources.go:31-43) stay on the device next to the
+ * cluster columns.  gf_cluster_set zeroes them (a new node set starts from nothing); gf_usage_apply adds (sign = +1: a
+ * ResourceReservation or soft reservation appeared) or subtracts (sign = -1: it went away) the entries that changed since the
+ * last call — an informer event in the Go host, K + 1 entries per application instead of every entry per Filter;
+ * gf_snapshot_build_resident with n_res = GF_RESIDENT_USAGE then builds from the resident sums and moves no reservation at
+ * all.  Sums of 64-bit integers: the result equals the replay of the full entry list bit for bit, whatever the order of the
+ * updates.  Entries on nodes outside the cluster are ignored like the replay ignores them (resources.go:72). */
+#define GF_RESIDENT_USAGE 0xFFFFFFFFu
+int gf_usage_reset(gf_ctx *ctx);
+int gf_usage_apply(gf_ctx *ctx, uint32_t n_entries, const uint32_t *res_node, const int64_t *res_cpu_milli,
+                   const int64_t *res_mem_bytes, const int64_t *res_gpu, int sign /* +1 add, -1 remove */);
 /* The installed snapshot, n_nodes x 3 row-major each (either may be NULL). */
 int gf_snapshot_get(gf_ctx *ctx, int64_t *avail_out, int64_t *sched_out);
 

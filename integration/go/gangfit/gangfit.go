@@ -401,3 +401,43 @@ func (c *Context) FindNodes(counts []int, executor []*resources.Resources, avail
 	}
 	return nodes, reserved, nil
 }
+
+// UsageApply keeps UsageForNodes (LIB/resources/resources.go:31-43) resident on the device next to the cluster columns of
+// gf_cluster_set: call it from the ResourceReservation / soft-reservation informer handlers with the entries of the object
+// that appeared (add = true) or went away (add = false) — node INDICES in the order given to gf_cluster_set — and build the
+// request's snapshot with gf_snapshot_build_resident(n_res = GF_RESIDENT_USAGE): no reservation list crosses PCIe per Filter.
+// Unverified here (no Go toolchain); the C entry points are exercised by tests/test_snapshot_build.py.
+func (c *Context) UsageApply(nodes []uint32, requests []*resources.Resources, add bool) error {
+	if len(nodes) != len(requests) {
+		return fmt.Errorf("gangfit: %d nodes, %d requests", len(nodes), len(requests))
+	}
+	if len(nodes) == 0 {
+		return nil
+	}
+	var cols [3][]int64
+	for _, r := range requests {
+		v, err := canonical(r)
+		if err != nil {
+			return err
+		}
+		for j := 0; j < 3; j++ {
+			cols[j] = append(cols[j], v[j])
+		}
+	}
+	sign := C.int(1)
+	if !add {
+		sign = -1
+	}
+	if rc := C.gf_usage_apply(c.ctx, C.uint32_t(len(nodes)), p32(nodes), p64(cols[0]), p64(cols[1]), p64(cols[2]), sign); rc != C.GF_OK {
+		return c.err(rc)
+	}
+	return nil
+}
+
+// UsageReset zeroes the resident usage (gf_cluster_set does it too: a new node set starts from nothing).
+func (c *Context) UsageReset() error {
+	if rc := C.gf_usage_reset(c.ctx); rc != C.GF_OK {
+		return c.err(rc)
+	}
+	return nil
+}

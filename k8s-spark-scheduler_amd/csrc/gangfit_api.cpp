@@ -198,6 +198,10 @@ struct gf_ctx {
 
     // gf_cluster_set: the static columns of gf_snapshot_build, resident
     DeviceBuf<int64_t> d_cl_i64;   // allocatable (3n) | overhead (3n)
+    DeviceBuf<int64_t> d_cl_usage;  // resident UsageForNodes sums (3n), maintained by gf_usage_apply
+    DeviceBuf<int64_t> d_delta_i64; // one gf_usage_apply call's entries
+    DeviceBuf<uint32_t> d_delta_u32;
+    __int128 usage_total[3] = {0, 0, 0};  // sum of everything applied: bounds every node's sum
     DeviceBuf<uint32_t> d_cl_u32;  // zone | name_rank | node_flags (n each)
     std::vector<uint32_t> cl_flags, cl_zone;  // host copies (candidate lists, ctx->zone)
     uint32_t cl_n = 0, cl_zones = 1;
@@ -766,6 +770,9 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->h_avg.release();
     ctx->d_cl_i64.release();
     ctx->d_cl_u32.release();
+    ctx->d_cl_usage.release();
+    ctx->d_delta_i64.release();
+    ctx->d_delta_u32.release();
     ctx->d_bi64.release();
     ctx->d_bu32.release();
     ctx->d_btemp.release();
@@ -1501,6 +1508,9 @@ int gf_cluster_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_u32.ptr + N, name_rank, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_cl_u32.ptr + 2 * N, node_flags, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
+    GF_HIP(ctx, ctx->d_cl_usage.reserve(3 * N + 1));
+    GF_HIP(ctx, hipMemsetAsync(ctx->d_cl_usage.ptr, 0, (3 * N + 1) * sizeof(int64_t), st));  // a new node set: no usage yet
+    for (int j = 0; j < 3; ++j) ctx->usage_total[j] = 0;
     GF_HIP(ctx, gf_wait_stream(st));  // the caller's arrays are free again
     ctx->cl_flags.assign(node_flags, node_flags + n);
     if (zone_of_node)
@@ -1530,6 +1540,57 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
                                       exec_label_rank, driver_order_out, n_d_out, exec_order_out, n_x_out);
 }
 
+int gf_usage_reset(gf_ctx* ctx) {
+    GF_EACH(ctx, gf_usage_reset(ctx));
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_usage_reset");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipMemsetAsync(ctx->d_cl_usage.ptr, 0, (3 * (size_t)ctx->cl_n + 1) * sizeof(int64_t), ctx->stream));
+    for (int j = 0; j < 3; ++j) ctx->usage_total[j] = 0;
+    return GF_OK;
+}
+
+int gf_usage_apply(gf_ctx* ctx, uint32_t n_entries, const uint32_t* res_node, const int64_t* res_cpu_milli,
+                   const int64_t* res_mem_bytes, const int64_t* res_gpu, int sign) {
+    GF_EACH(ctx, gf_usage_apply(ctx, n_entries, res_node, res_cpu_milli, res_mem_bytes, res_gpu, sign));
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_usage_apply");
+    if (sign != 1 && sign != -1) return fail(ctx, GF_ERR_INVALID, "sign must be +1 or -1");
+    if (n_entries == 0) return GF_OK;
+    if (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu) return fail(ctx, GF_ERR_INVALID, "entry columns must not be NULL");
+    const int64_t* rcols[3] = {res_cpu_milli, res_mem_bytes, res_gpu};
+    const int64_t lim = GF_MAX_ABS_QUANTITY >> 1;
+    __int128 total[3];
+    for (int j = 0; j < 3; ++j) {
+        __int128 sum = 0;
+        for (uint32_t i = 0; i < n_entries; ++i) {
+            if (rcols[j][i] < 0 || rcols[j][i] >= lim) return fail(ctx, GF_ERR_INVALID, "entry %u out of range", i);
+            if (res_node[i] < ctx->cl_n) sum += rcols[j][i];
+        }
+        total[j] = ctx->usage_total[j] + (sign > 0 ? sum : -sum);
+        // every node's sum lies between 0 and the sum of everything applied: that (plus the overhead) must stay below 2^62
+        if (total[j] < 0) return fail(ctx, GF_ERR_INVALID, "more usage removed than was ever added (dimension %d)", j);
+        if (total[j] + (__int128)ctx->cl_max_over[j] >= (__int128)GF_MAX_ABS_QUANTITY)
+            return fail(ctx, GF_ERR_INVALID, "the resident usage can sum past 2^62: not representable");
+    }
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t R = n_entries;
+    GF_HIP(ctx, gf_wait_stream(st));  // an earlier update may still read the staging buffers that are about to grow
+    GF_HIP(ctx, ctx->d_delta_i64.reserve(3 * R));
+    GF_HIP(ctx, ctx->d_delta_u32.reserve(R));
+    for (int j = 0; j < 3; ++j)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_delta_i64.ptr + j * R, rcols[j], R * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_delta_u32.ptr, res_node, R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, gangfit::launch_usage_apply(n_entries, ctx->cl_n, ctx->d_delta_u32.ptr, ctx->d_delta_i64.ptr, sign,
+                                            ctx->d_cl_usage.ptr, st));
+    GF_HIP(ctx, gf_wait_stream(st));  // the caller's arrays are free again
+    for (int j = 0; j < 3; ++j) ctx->usage_total[j] = total[j];
+    return GF_OK;
+}
+
 int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_node, const int64_t* res_cpu_milli,
                                const int64_t* res_mem_bytes, const int64_t* res_gpu, const uint32_t* node_flags,
                                const uint32_t* driver_label_rank, const uint32_t* exec_label_rank,
@@ -1556,6 +1617,8 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     const uint32_t n = ctx->cl_n;
     const uint32_t n_zones = ctx->cl_zones;
     const bool with_over = ctx->cl_over;
+    const bool usage_resident = n_res == GF_RESIDENT_USAGE;  // the sums gf_usage_apply maintains: no entry travels
+    if (usage_resident) n_res = 0;
     if (n_res > 0 && (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu))
         return fail(ctx, GF_ERR_INVALID, "reservation columns must not be NULL");
     if (node_flags) ctx->cl_flags.assign(node_flags, node_flags + n);  // this request's candidate flags
@@ -1641,7 +1704,8 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     b.d_res_req = d_res_req;
     b.d_zone = d_zone;
     b.d_name_rank = d_name_rank;
-    b.d_usage = d_usage;
+    b.d_usage = usage_resident ? ctx->d_cl_usage.ptr : d_usage;
+    b.usage_resident = usage_resident;
     b.d_avail = d_avail;
     b.d_sched = d_sched;
     b.d_zone_sum = d_zone_sum;

@@ -270,6 +270,7 @@ hipError_t launch_find_nodes(bool chained, const NodeTable& table, uint32_t n_re
 // node indices in priority order.
 struct SnapshotBuild {
     uint32_t n_nodes, n_res, n_zones;
+    bool usage_resident = false;  // d_usage holds the sums already (gf_usage_apply): neither zeroed nor scattered into
     const int64_t* d_alloc;      // 3 * n_nodes
     const int64_t* d_overhead;   // 3 * n_nodes or nullptr
     const uint32_t* d_res_node;  // n_res
@@ -289,6 +290,10 @@ struct SnapshotBuild {
     void* d_temp;                // radix-sort scratch
     size_t temp_bytes;
 };
+// usage[node] += sign * entry for n_entries reservation entries (columns cpu | memory | gpu of d_req); entries on nodes
+// >= n_nodes are ignored.
+hipError_t launch_usage_apply(uint32_t n_entries, uint32_t n_nodes, const uint32_t* d_node, const int64_t* d_req, int sign,
+                              int64_t* d_usage, hipStream_t stream);
 // The slot tables of the merged layout built from the device-resident snapshot columns (what gf_orders_set builds on the
 // host): every node gets the slot of its position in the priority order.
 struct SnapshotFinalize {

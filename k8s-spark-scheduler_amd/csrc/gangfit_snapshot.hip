@@ -18,16 +18,17 @@ namespace gangfit {
 
 namespace {
 
+// sign = +1 / -1: two's-complement addition, so removing an entry is adding its negation
 __global__ void usage_scatter_kernel(uint32_t n_res, uint32_t n_nodes, const uint32_t* __restrict__ res_node,
                                      const int64_t* __restrict__ r0, const int64_t* __restrict__ r1,
-                                     const int64_t* __restrict__ r2, unsigned long long* __restrict__ usage) {
+                                     const int64_t* __restrict__ r2, unsigned long long* __restrict__ usage, int sign = 1) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_res) return;
     const uint32_t n = res_node[i];
     if (n >= n_nodes) return;  // a reservation on a node outside the listed ones is never read (resources.go:72)
-    atomicAdd(&usage[n], (unsigned long long)r0[i]);
-    atomicAdd(&usage[(size_t)n_nodes + n], (unsigned long long)r1[i]);
-    atomicAdd(&usage[2 * (size_t)n_nodes + n], (unsigned long long)r2[i]);
+    atomicAdd(&usage[n], (unsigned long long)(r0[i] * sign));
+    atomicAdd(&usage[(size_t)n_nodes + n], (unsigned long long)(r1[i] * sign));
+    atomicAdd(&usage[2 * (size_t)n_nodes + n], (unsigned long long)(r2[i] * sign));
 }
 
 // available = allocatable - (usage + overhead), schedulable = allocatable - overhead (resources.go:76, 89-90);
@@ -402,18 +403,27 @@ size_t snapshot_sort_temp_bytes(uint32_t n_nodes) {
     return bytes;
 }
 
+hipError_t launch_usage_apply(uint32_t n_entries, uint32_t n_nodes, const uint32_t* d_node, const int64_t* d_req, int sign,
+                              int64_t* d_usage, hipStream_t stream) {
+    if (n_entries == 0 || n_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(usage_scatter_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, n_entries, n_nodes, d_node,
+                       d_req, d_req + n_entries, d_req + 2 * (size_t)n_entries, reinterpret_cast<unsigned long long*>(d_usage),
+                       sign < 0 ? -1 : 1);
+    return hipGetLastError();
+}
+
 hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
     const uint32_t n = b.n_nodes;
     if (n == 0) return hipSuccess;
     hipError_t e;
-    if ((e = hipMemsetAsync(b.d_usage, 0, 3 * (size_t)n * sizeof(int64_t), stream)) != hipSuccess) return e;
+    if (!b.usage_resident && (e = hipMemsetAsync(b.d_usage, 0, 3 * (size_t)n * sizeof(int64_t), stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(b.d_zone_sum, 0, 3 * (size_t)(b.n_zones ? b.n_zones : 1) * sizeof(int64_t), stream)) != hipSuccess)
         return e;
     const dim3 block(256);
-    if (b.n_res > 0)
+    if (b.n_res > 0 && !b.usage_resident)
         hipLaunchKernelGGL(usage_scatter_kernel, dim3((b.n_res + 255) / 256), block, 0, stream, b.n_res, n, b.d_res_node,
                            b.d_res_req, b.d_res_req + b.n_res, b.d_res_req + 2 * (size_t)b.n_res,
-                           reinterpret_cast<unsigned long long*>(b.d_usage));
+                           reinterpret_cast<unsigned long long*>(b.d_usage), 1);
     const dim3 grid((n + 255) / 256);
     hipLaunchKernelGGL(metadata_kernel, grid, block, 0, stream, n, b.d_alloc, b.d_overhead, (const int64_t*)b.d_usage,
                        b.d_zone, b.n_zones, b.d_avail, b.d_sched, reinterpret_cast<unsigned long long*>(b.d_zone_sum));

@@ -37,6 +37,8 @@ RESULT_DTYPE = np.dtype(
 assert APP_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
 
 # every symbol include/gangfit.h declares (tests check that the library exports all of them)
+GF_RESIDENT_USAGE = 0xFFFFFFFF
+
 EXPORTED_SYMBOLS = [
     "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch",
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats",
@@ -44,6 +46,7 @@ EXPORTED_SYMBOLS = [
     "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
     "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
+    "gf_usage_reset", "gf_usage_apply",
 ]
 
 
@@ -125,6 +128,10 @@ def load() -> C.CDLL:
     L.gf_snapshot_build.argtypes = [p, u32, p, p, p, p, p, p, u32, p, p, p, p, p, p, u32, p, p, p, p, p, p, p]
     L.gf_cluster_set.restype = i32
     L.gf_cluster_set.argtypes = [p, u32, p, p, p, p, p, p, p, p, u32, p]
+    L.gf_usage_reset.restype = i32
+    L.gf_usage_reset.argtypes = [p]
+    L.gf_usage_apply.restype = i32
+    L.gf_usage_apply.argtypes = [p, u32, p, p, p, p, i32]
     L.gf_snapshot_build_resident.restype = i32
     L.gf_snapshot_build_resident.argtypes = [p, u32, p, p, p, p, p, p, p, p, p, p, p]
     L.gf_snapshot_get.restype = i32

@@ -152,8 +152,23 @@ class Context:
                                              N.ptr(z), n_zones, N.ptr(ranks)))
         self._cluster_n = n
 
+    def usage_reset(self):
+        """gf_usage_reset: the resident usage sums back to zero."""
+        self._check(self._lib.gf_usage_reset(self._h))
+
+    def usage_apply(self, res_node, res_req=None, sign: int = 1, res_cols=None):
+        """gf_usage_apply: add (sign = +1) or remove (sign = -1) reservation entries to / from the resident usage sums.
+        res_req = (n, 3) rows or res_cols = (cpu, mem, gpu) columns."""
+        rn = np.ascontiguousarray(res_node, dtype=np.uint32)
+        if res_cols is not None:
+            rcols = [np.ascontiguousarray(c, dtype=np.int64) for c in res_cols]
+        else:
+            rr = np.ascontiguousarray(res_req, dtype=np.int64).reshape(-1, 3)
+            rcols = [np.ascontiguousarray(rr[:, j]) for j in range(3)]
+        self._check(self._lib.gf_usage_apply(self._h, len(rn), N.ptr(rn), *[N.ptr(c) for c in rcols], int(sign)))
+
     def build_snapshot_resident(self, res_node=None, res_req=None, node_flags=None, driver_label_rank=None,
-                                exec_label_rank=None, want_orders: bool = True, res_cols=None):
+                                exec_label_rank=None, want_orders: bool = True, res_cols=None, resident_usage: bool = False):
         """gf_snapshot_build_resident.  res_cols = (cpu, mem, gpu) contiguous int64 columns of the reservation entries, for
         callers that keep them that way (the C ABI takes columns; res_req = (n, 3) rows is split here on every call)."""
         n = self._cluster_n
@@ -167,13 +182,14 @@ class Context:
         dl = None if driver_label_rank is None else np.ascontiguousarray(driver_label_rank, dtype=np.uint32)
         el = None if exec_label_rank is None else np.ascontiguousarray(exec_label_rank, dtype=np.uint32)
         self.n_nodes = n
+        n_res = N.GF_RESIDENT_USAGE if resident_usage else len(rn)  # resident_usage: build from the sums of usage_apply
         if not want_orders:
-            self._check(self._lib.gf_snapshot_build_resident(self._h, len(rn), N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(fl),
+            self._check(self._lib.gf_snapshot_build_resident(self._h, n_res, N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(fl),
                                                              N.ptr(dl), N.ptr(el), None, None, None, None))
             return None, None
         d_out, x_out = np.zeros(n + 1, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint32)
         nd, nx = C.c_uint32(0), C.c_uint32(0)
-        self._check(self._lib.gf_snapshot_build_resident(self._h, len(rn), N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(fl),
+        self._check(self._lib.gf_snapshot_build_resident(self._h, n_res, N.ptr(rn), *[N.ptr(c) for c in rcols], N.ptr(fl),
                                                          N.ptr(dl), N.ptr(el), N.ptr(d_out), C.byref(nd), N.ptr(x_out),
                                                          C.byref(nx)))
         return d_out[: nd.value].copy(), x_out[: nx.value].copy()

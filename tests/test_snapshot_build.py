@@ -153,3 +153,55 @@ def test_resident_cluster_then_reservations_only(gf_ctx, labels):
             fresh._cluster_n = 1
             fresh.build_snapshot_resident()
         assert e.value.code == gangfit._native.GF_ERR_STATE
+
+
+@pytest.mark.gpu
+def test_resident_usage_with_deltas(gf_ctx):
+    """gf_usage_apply keeps the UsageForNodes sums on the device: after every batch of added / removed entries the snapshot
+    built from the resident sums (n_res = GF_RESIDENT_USAGE, no entry travels) equals the replay of the live entry list —
+    values, priority orders and a chain on top of it."""
+    n = 2500
+    c = _cluster(91, n, 300, 3, with_overhead=True, labels=False)
+    gf_ctx.set_cluster(c["alloc"], c["node_flags"], c["name_rank"], overhead=c["overhead"], zone=c["zone"], n_zones=c["n_zones"])
+    rng = np.random.default_rng(17)
+
+    def entries(m):
+        node = rng.integers(0, n + 3, size=m).astype(np.uint32)  # a few on nodes outside the cluster: ignored
+        req = np.stack([rng.choice([500, 1000, 4000], size=m), rng.choice([1, 4, 16], size=m) * GIB,
+                        (rng.random(m) < 0.05).astype(np.int64)], axis=1).astype(np.int64)
+        return node, req
+
+    live_node, live_req = np.zeros(0, dtype=np.uint32), np.zeros((0, 3), dtype=np.int64)
+    for rep in range(5):
+        if rep == 3:  # start over
+            gf_ctx.usage_reset()
+            live_node, live_req = live_node[:0], live_req[:0]
+        an, ar = entries(int(rng.integers(1, 4000)))
+        gf_ctx.usage_apply(an, ar, +1)
+        live_node, live_req = np.concatenate([live_node, an]), np.concatenate([live_req, ar])
+        if rep % 2 == 1:  # some reservations go away (in another order than they came)
+            gone = rng.random(len(live_node)) < 0.4
+            idx = rng.permutation(np.nonzero(gone)[0])
+            gf_ctx.usage_apply(live_node[idx], res_cols=[np.ascontiguousarray(live_req[idx, j]) for j in range(3)], sign=-1)
+            live_node, live_req = live_node[~gone], live_req[~gone]
+        D, X = gf_ctx.build_snapshot_resident(resident_usage=True)
+        avail, sched, rD, rX = ps.build(**dict(c, res_node=live_node, res_req=live_req))
+        got_avail, got_sched = gf_ctx.snapshot()
+        assert np.array_equal(got_avail, avail) and np.array_equal(got_sched, sched)
+        assert np.array_equal(D, rD) and np.array_equal(X, rX)
+        # the explicit entry list on the same context gives the same snapshot and leaves the resident sums alone
+        D2, X2 = gf_ctx.build_snapshot_resident(res_node=live_node, res_req=live_req)
+        assert np.array_equal(D2, rD) and np.array_equal(gf_ctx.snapshot()[0], avail)
+        gf_ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+        assert np.array_equal(gf_ctx.snapshot()[0], avail)
+        w = wl.config(2, n_nodes=16, n_apps=40)
+        apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+        gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, 0, apps)
+        ref = ob.fit_fifo_chain(0, avail, ob.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32)), rD, rX)
+        assert gpu.failed_at == ref.failed_at and np.array_equal(gpu.results, ref.results)
+    with pytest.raises(gangfit.GangfitError) as e:  # more removed than was ever added
+        big = np.array([[1 << 40, 1 << 50, 9]], dtype=np.int64)
+        gf_ctx.usage_apply(np.array([0], dtype=np.uint32), big, -1)
+    assert e.value.code == gangfit._native.GF_ERR_INVALID
+    with pytest.raises(gangfit.GangfitError):
+        gf_ctx.usage_apply(np.array([0], dtype=np.uint32), np.array([[1, 1, 1]], dtype=np.int64), 2)

@@ -29,3 +29,7 @@ ctx.set_cluster(alloc5, flags5, ranks5)
 print("resident cluster, row-major reservations + chain", p50(lambda: (ctx.build_snapshot_resident(res_node=rnode, res_req=rreq, want_orders=False), ctx.fit_batch(1, 0, q5))))
 print("resident cluster, reservation columns + chain", p50(lambda: (ctx.build_snapshot_resident(res_node=rnode, res_cols=rcols, want_orders=False), ctx.fit_batch(1, 0, q5))))
 print("chain alone", p50(lambda: ctx.fit_batch(1, 0, q5)))
+ctx.usage_reset(); ctx.usage_apply(rnode, res_cols=rcols, sign=+1)
+dn, dc = rnode[:14], [c[:14] for c in rcols]
+print("resident cluster + resident usage (2 delta calls) + chain", p50(lambda: (ctx.usage_apply(dn, res_cols=dc, sign=-1), ctx.usage_apply(dn, res_cols=dc, sign=+1), ctx.build_snapshot_resident(resident_usage=True, want_orders=False), ctx.fit_batch(1, 0, q5))))
+print("build from resident usage alone", p50(lambda: (ctx.build_snapshot_resident(resident_usage=True, want_orders=False), ctx.synchronize() if hasattr(ctx, "synchronize") else ctx.snapshot)))
