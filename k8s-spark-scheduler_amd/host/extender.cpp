@@ -335,7 +335,9 @@ bool FlatCluster::Build(const std::vector<Node>& nodes, FlatCluster* out, std::s
 bool FlatReservations::Build(const std::vector<ResourceReservation>& reservations,
                              const NodeGroupResources& softReservationUsage, const FlatCluster& cluster,
                              FlatReservations* out, std::string* err) {
+    static std::atomic<uint64_t> next_version{1};
     FlatReservations f;
+    f.version = next_version.fetch_add(1);
     auto push = [&](const std::string& node, const Resources& r) {
         auto it = cluster.index.find(node);
         if (it == cluster.index.end()) return true;  // usage of a node outside this instance group is never read
@@ -447,10 +449,28 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
                                cluster.name_rank.data()) != GF_OK)
                 return not_served(std::string("gf_cluster_set: ") + gf_last_error(ctx));
             resident_cluster_ = cluster.version;
+            resident_usage_ = 0;  // gf_cluster_set zeroed the resident usage
         }
-        if (gf_snapshot_build_resident(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(), rreq[2].data(),
-                                       flags.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != GF_OK) {
+        // a caller that keeps its flattened reservations (flat->version != 0) gets the usage sums kept on the device too: they
+        // are sent when the list changes, and a Filter between two changes moves no reservation at all.  (A host that tracks
+        // its ResourceReservation events would send only the K + 1 entries of the object that changed: gf_usage_apply.)
+        const bool keep_usage = flat != &local && flat->version != 0;
+        if (keep_usage && resident_usage_ != flat->version) {
+            resident_usage_ = 0;
+            if (gf_usage_reset(ctx) != GF_OK ||
+                gf_usage_apply(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(), rreq[2].data(), +1) != GF_OK)
+                return not_served(std::string("gf_usage_apply: ") + gf_last_error(ctx));
+            resident_usage_ = flat->version;
+        }
+        const int brc = keep_usage
+                            ? gf_snapshot_build_resident(ctx, GF_RESIDENT_USAGE, nullptr, nullptr, nullptr, nullptr, flags.data(),
+                                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)
+                            : gf_snapshot_build_resident(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(),
+                                                         rreq[2].data(), flags.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                         nullptr);
+        if (brc != GF_OK) {
             resident_cluster_ = 0;
+            resident_usage_ = 0;
             return not_served(std::string("gf_snapshot_build_resident: ") + gf_last_error(ctx));
         }
     } else if (gf_snapshot_build(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(), over[0].data(),

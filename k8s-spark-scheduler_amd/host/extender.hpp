@@ -73,6 +73,8 @@ struct FlatCluster {
 struct FlatReservations {
     std::vector<uint32_t> node;
     std::vector<int64_t> req[3];
+    uint64_t version = 0;  // unique per Build: lets the extender keep the usage sums of this entry list resident on the device
+                           // (gf_usage_apply) for as long as the list does not change
     static bool Build(const std::vector<ResourceReservation>& reservations, const NodeGroupResources& softReservationUsage,
                       const FlatCluster& cluster, FlatReservations* out, std::string* err);
 };
@@ -129,6 +131,7 @@ public:
 
 private:
     uint64_t resident_cluster_ = 0;  // FlatCluster::version whose static columns sit on the device (selectDriverNodeFlat)
+    uint64_t resident_usage_ = 0;    // FlatReservations::version whose usage sums sit on the device (for resident_cluster_)
     Binpacker binpacker_;
     NodeSorter sorter_;
     bool isFIFO_;
