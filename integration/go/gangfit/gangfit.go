@@ -67,8 +67,9 @@ func canonical(r *resources.Resources) (out [3]int64, err error) {
 // func.  One device id = one MI355X; several ids = ONE context over several GPUs of the box: independent batches of the
 // plain packers are then node-range sharded inside the library (SURVEY.md 8e), nothing else changes for the caller.
 type Context struct {
-	mu  sync.Mutex // snapshot+zones+orders+fit must not interleave between goroutines (Predicate vs UnschedulablePodMarker)
-	ctx *C.gf_ctx
+	mu    sync.Mutex // snapshot+zones+orders+fit must not interleave between goroutines (Predicate vs UnschedulablePodMarker)
+	ctx   *C.gf_ctx
+	names []string // node order of the last ClusterSet (resident flow)
 }
 
 func New(devices ...int) (*Context, error) {
@@ -428,6 +429,8 @@ func (c *Context) UsageApply(nodes []uint32, requests []*resources.Resources, ad
 	if !add {
 		sign = -1
 	}
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	if rc := C.gf_usage_apply(c.ctx, C.uint32_t(len(nodes)), p32(nodes), p64(cols[0]), p64(cols[1]), p64(cols[2]), sign); rc != C.GF_OK {
 		return c.err(rc)
 	}
@@ -436,8 +439,118 @@ func (c *Context) UsageApply(nodes []uint32, requests []*resources.Resources, ad
 
 // UsageReset zeroes the resident usage (gf_cluster_set does it too: a new node set starts from nothing).
 func (c *Context) UsageReset() error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
 	if rc := C.gf_usage_reset(c.ctx); rc != C.GF_OK {
 		return c.err(rc)
 	}
 	return nil
+}
+
+// ---- the resident flow (INTEGRATION.md, L-resident): the node columns and the usage sums live on the device, a Filter sends
+// its candidate flags and its queue.  Unverified here (no Go toolchain); host/extender.cpp::selectDriverNodeFlat is the C++
+// version of the same calls and is tested.
+
+// Cluster is the node-side state of one instance group in a FIXED node order (index i everywhere below = Names[i]).
+type Cluster struct {
+	Names    []string
+	Alloc    [3][]int64 // allocatable: cpu milli, memory bytes, gpus
+	Overhead [3][]int64 // nil columns: no overhead
+	Flags    []uint32   // GF_NODE_READY | GF_NODE_UNSCHEDULABLE | GF_NODE_DRIVER_CANDIDATE defaults
+	Zone     []uint32   // dense zone ids (nil: one zone)
+	NZones   int
+	NameRank []uint32 // rank of Names[i] in lexicographic order (nodesorting.go:92: the name breaks ties)
+}
+
+// ResidentUsage as n_res of SnapshotBuildResident: build from the sums UsageApply maintains.
+const ResidentUsage = ^uint32(0)
+
+// ClusterSet uploads the node columns (gf_cluster_set); it also zeroes the resident usage.
+func (c *Context) ClusterSet(cl *Cluster) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	nz := cl.NZones
+	if nz < 1 {
+		nz = 1
+	}
+	if rc := C.gf_cluster_set(c.ctx, C.uint32_t(len(cl.Names)), p64(cl.Alloc[0]), p64(cl.Alloc[1]), p64(cl.Alloc[2]),
+		p64(cl.Overhead[0]), p64(cl.Overhead[1]), p64(cl.Overhead[2]), p32(cl.Flags), p32(cl.Zone), C.uint32_t(nz),
+		p32(cl.NameRank)); rc != C.GF_OK {
+		return c.err(rc)
+	}
+	c.names = append(c.names[:0], cl.Names...)
+	return nil
+}
+
+// SnapshotBuildResident builds and installs this request's snapshot from the resident state
+// (gf_snapshot_build_resident with n_res = GF_RESIDENT_USAGE); requestFlags may be nil (the cluster's defaults).
+func (c *Context) SnapshotBuildResident(requestFlags []uint32) error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	if rc := C.gf_snapshot_build_resident(c.ctx, C.uint32_t(ResidentUsage), nil, nil, nil, nil, p32(requestFlags), nil, nil,
+		nil, nil, nil, nil); rc != C.GF_OK {
+		return c.err(rc)
+	}
+	return nil
+}
+
+// FitBatchOnInstalledSnapshot is FitBatch without the snapshot upload: node names come from the last ClusterSet.
+func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (results []Result, failedAt int, err error) {
+	capps := make([]C.gf_app, len(apps))
+	total := 0
+	for i, a := range apps {
+		d, err := canonical(a.Driver)
+		if err != nil {
+			return nil, -1, err
+		}
+		e, err := canonical(a.Executor)
+		if err != nil {
+			return nil, -1, err
+		}
+		if a.ExecutorCount < 0 || a.ExecutorCount > C.GF_MAX_K {
+			return nil, -1, ErrNotRepresentable
+		}
+		for j := 0; j < 3; j++ {
+			capps[i].drv[j], capps[i].exe[j] = C.int64_t(d[j]), C.int64_t(e[j])
+		}
+		capps[i].k = C.int32_t(a.ExecutorCount)
+		if a.Skippable {
+			capps[i].flags = C.GF_APP_SKIPPABLE
+		}
+		total += a.ExecutorCount
+	}
+	cres := make([]C.gf_result, len(apps))
+	execNodes := make([]uint32, total+1)
+	var failed C.int32_t = -1
+	mode := C.gf_mode(C.GF_MODE_INDEPENDENT)
+	if fifo {
+		mode = C.GF_MODE_FIFO_CHAIN
+	}
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var pa *C.gf_app
+	var pr *C.gf_result
+	if len(apps) > 0 {
+		pa, pr = &capps[0], &cres[0]
+	}
+	if rc := C.gf_fit_batch(c.ctx, mode, C.gf_algo(algo), C.uint32_t(len(apps)), pa, pr, p32(execNodes),
+		C.uint64_t(total), &failed); rc != C.GF_OK {
+		return nil, -1, c.err(rc)
+	}
+	results = make([]Result, len(apps))
+	off := 0
+	for i := range apps {
+		r := &results[i]
+		r.Evaluated = cres[i].evaluated != 0
+		r.HasCapacity = cres[i].has_capacity != 0
+		r.ExecutorNodes = make([]string, 0, int(cres[i].exec_len))
+		if r.HasCapacity {
+			r.DriverNode = c.names[cres[i].driver_node]
+			for _, ix := range execNodes[off : off+int(cres[i].exec_len)] {
+				r.ExecutorNodes = append(r.ExecutorNodes, c.names[ix])
+			}
+		}
+		off += apps[i].ExecutorCount
+	}
+	return results, int(failed), nil
 }
