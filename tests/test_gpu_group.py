@@ -84,6 +84,20 @@ def test_group_device_built_snapshot_and_headline_size():
         out = g.fit_batch(IND, 0, apps)
         assert 0 < ref.results["has_capacity"].sum()
         _assert_same(out, ref, apps)
+        # the resident flow on a multi-device context: the cluster columns and the usage deltas go to every device
+        ranks = rng.permutation(n).astype(np.uint32)
+        g.set_cluster(alloc, np.full(n, 6, dtype=np.uint32), ranks)
+        g.usage_apply(rnode[:20000], rreq[:20000], +1)
+        g.usage_apply(rnode[20000:], rreq[20000:], +1)
+        g.usage_apply(rnode[5000:9000], rreq[5000:9000], -1)
+        D2, X2 = g.build_snapshot_resident(resident_usage=True)
+        keep = np.r_[0:5000, 9000:30000]
+        with gangfit.Context(0) as one:
+            D1, X1 = one.build_snapshot(alloc, np.full(n, 6, dtype=np.uint32), ranks, res_node=rnode[keep], res_req=rreq[keep])
+            avail1, _ = one.snapshot()
+        assert np.array_equal(D2, D1) and np.array_equal(X2, X1) and np.array_equal(g.snapshot()[0], avail1)
+        ref = ob.fit_independent(1, avail1, oapps, D1, X1, closed_form=True)
+        _assert_same(g.fit_batch(IND, 1, apps), ref, apps)
 
 
 def test_group_argument_errors():
