@@ -491,8 +491,9 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         if (inner == GF_ALGO_TIGHTLY_PACK && ctx->merged && ctx->narrow_ok && ctx->fifo_zoned_lds && nz + (az_aware ? 1u : 0u) <= 16) {
             // as many shape-index rows as LDS allows next to the masks (64 down to 4), then as much of the table as fits
             uint32_t n_shapes = 64;
-            while (n_shapes > 4 && gangfit::fifo_zoned_lds_bytes(64, ctx->n_chunks, nz, n_shapes) > ctx->lds_budget) n_shapes /= 2;
-            const size_t fixed = gangfit::fifo_zoned_lds_bytes(0, ctx->n_chunks, nz, n_shapes);
+            const uint32_t n_cand = nz + (az_aware ? 1u : 0u);
+            while (n_shapes > 4 && gangfit::fifo_zoned_lds_bytes(64, ctx->n_chunks, nz, n_cand, n_shapes) > ctx->lds_budget) n_shapes /= 2;
+            const size_t fixed = gangfit::fifo_zoned_lds_bytes(0, ctx->n_chunks, nz, n_cand, n_shapes);
             if (ctx->lds_budget > fixed + 12 * 64) {
                 uint32_t lds_slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
                 lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;

@@ -187,7 +187,8 @@ hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bo
 // (gangfit_fifo_zoned.inc).  Returns at once when a request of the batch has no scaled form (*d_wide_needed != 0 after
 // its own prepare step): the caller then launches launch_fit_fifo_generic with d_run_if = d_wide_needed.
 // d_spill: 2 * 16 rows of spill_stride uint32 (run-list tails beyond the LDS capacity).
-size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes);
+// n_cand = candidate views = zones (+ 1 for az-aware: the plain pack); the workgroup's size follows from it.
+size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_cand, uint32_t n_shapes);
 hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
                                      const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                      const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,

@@ -1877,8 +1877,8 @@ namespace {
 inline dim3 app_grid_of(uint32_t n_apps) { return dim3((n_apps + kWavesPerBlock - 1) / kWavesPerBlock); }
 }  // namespace
 
-size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_shapes) {
-    return fifo_zoned_fixed_lds(n_chunks, n_zones + 1, 16, n_shapes) + 12 * (size_t)lds_slots;
+size_t fifo_zoned_lds_bytes(uint32_t lds_slots, uint32_t n_chunks, uint32_t n_zones, uint32_t n_cand, uint32_t n_shapes) {
+    return fifo_zoned_fixed_lds(n_chunks, n_zones + 1, (uint32_t)fifo_zoned_waves(n_cand), n_shapes) + 12 * (size_t)lds_slots;
 }
 
 hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, const NarrowTable& ntable, const ZoneTable& zones,
@@ -1894,12 +1894,12 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
                        (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
-    const size_t lds = fifo_zoned_lds_bytes(lds_slots, table.n_chunks, zones.n_zones, n_shapes);
     // one wavefront per candidate view; the rest of the workgroup only helps with the prologue and shares every barrier and
     // the per-app control flow, i.e. takes issue slots from the views' wavefronts: no more wavefronts than views need
     const uint32_t n_cand = zones.n_zones + (az_aware ? 1u : 0u);
-    // ... plus one that expands the winner's placement behind the commit barrier (none left with 16 views)
-    const int wg_waves = n_cand < 4 ? 4 : (n_cand < 8 ? 8 : 16);
+    const size_t lds = fifo_zoned_lds_bytes(lds_slots, table.n_chunks, zones.n_zones, n_cand, n_shapes);
+    // ... plus one that expands the winner's placement next to the commit (none left with 16 views)
+    const int wg_waves = fifo_zoned_waves(n_cand);
 #define GF_ZL(AZ, NWV)                                                                                                      \
     e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<AZ, NWV>, NWV, lds, stream, table, ntable, zones, d_sched, lds_slots, \
                              n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,      \
