@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GF_VERSION 201 /* 0.2.0 */
+#define GF_VERSION 300 /* 0.3.0 */
 
 /* ---- status codes ---- */
 #define GF_OK 0
@@ -130,6 +130,19 @@ void gf_ctx_unlock(gf_ctx *ctx);
 /* Message for the last failing call on this context (C-owned, valid until the next call on ctx). */
 const char *gf_last_error(gf_ctx *ctx);
 
+/* Diagnostic / test switches of one context (a deployment needs none of them: every default is the fast path; tests use
+ * them to drive the fallback kernels on inputs the fast paths would take).  Applies to what is installed or launched
+ * afterwards.  Keys:
+ *   "chain_cache"            0: every FIFO chain replays from the snapshot (also GANGFIT_CHAIN_CACHE=0 in the environment)
+ *   "fifo_generic"           1: FIFO chains run on the wide / generic global-memory kernels only
+ *   "lds_budget"             bytes of LDS one workgroup may use (<= the device's): smaller table fronts, global tails
+ *   "minfrag_matrix", "minfrag_hist", "sparse_gpu", "zero_copy"   0 disables the respective structure
+ *   "snapshot_finalize_host" 1: gf_snapshot_build* builds the slot tables through gf_orders_set on the host
+ *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
+ * GF_ERR_INVALID for an unknown key or a value out of range.  The only environment variables the library reads are
+ * GANGFIT_WAIT=block (completion waits park the thread instead of polling) and GANGFIT_CHAIN_CACHE=0. */
+int gf_set_option(gf_ctx *ctx, const char *key, int64_t value);
+
 /* Upload the per-node snapshot = the AvailableResources / SchedulableResources columns of
  * resources.NodeGroupSchedulingMetadata (LIB/resources/resources.go:61-100, 158-166).
  * avail_*: n_nodes values each (may be negative: overcommitted node).  sched_*: nullable (only needed by
@@ -211,6 +224,19 @@ int gf_orders_set(gf_ctx *ctx, const uint32_t *driver_order, uint32_t n_d, const
  * Blocking.  Includes H2D of the app records and D2H of the results. */
 int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app *apps, gf_result *results,
                  uint32_t *exec_nodes, uint64_t exec_nodes_cap, int32_t *chain_failed_at);
+
+/* Incremental FIFO chains.  The reference replays every earlier driver on every Filter (internal/extender/resource.go:309-328);
+ * with an unchanged snapshot, driver j + 1's chain is driver j's chain plus one application.  gf_fit_batch(GF_MODE_FIFO_CHAIN)
+ * therefore keeps the last queue, its results and a checkpoint of the working table every 32 applications (more for tables
+ * whose 128 checkpoints would exceed 2 GiB), and a call whose queue starts with the same records resumes from the last
+ * checkpoint inside the common prefix (the filtered driver of either queue excluded: nothing is committed behind it).
+ * Every call that installs a snapshot, zones or orders (gf_snapshot_set, gf_zones_set, gf_orders_set, gf_snapshot_build*)
+ * and gf_set_option drop the cache.  Results, placements, chain_failed_at and gf_residual_get are those of the full replay,
+ * bit for bit: a checkpoint IS the table the replay holds at that application.  Served: tightly-pack and distribute-evenly
+ * on the merged layout with every request in scaled form; everything else replays.
+ * out[0] = chains served with the cache armed, out[1] = of those resumed from a checkpoint, out[2] = applications
+ * evaluated, out[3] = applications skipped (taken from the cache).  reset != 0 zeroes the counters afterwards. */
+int gf_chain_cache_stats(gf_ctx *ctx, int reset, uint64_t out[4]);
 
 /* Same decision kernels on DEVICE-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = the context's own
  * stream).  d_apps must carry exec_off and must already be validated (k in [0, GF_MAX_K], requests in [0, 2^62)).

@@ -153,28 +153,23 @@ struct gf_ctx {
     PinnedBuf<int64_t> h_gtab;
     PinnedBuf<uint32_t> h_gidx;
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
-    bool sparse_gpu = true;        // GANGFIT_SPARSE_GPU=0 disables the view
-    bool zero_copy = true;         // GANGFIT_ZEROCOPY=0: gf_fit_batch always stages through device buffers
+    bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
+    bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
     PinnedBuf<uint64_t> h_masks;
-    DeviceBuf<gangfit::DevApp> d_dev_apps;  // FIFO chain: app records with reciprocals (prepare_apps_kernel)
-    DeviceBuf<gangfit::NApp> d_napps;       // the same in the narrow domain
+    DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (prepare_apps_kernel)
     DeviceBuf<int32_t> d_wide_needed;       // set by prepare_apps_kernel when a request has no narrow form
     DeviceBuf<int32_t> d_capmat;            // minimal-fragmentation chain: capacity per (request shape, slot)
-    bool fifo_minfrag_matrix = true;        // GANGFIT_MINFRAG_MATRIX=0 recomputes capacities in every pass
+    bool fifo_minfrag_matrix = true;        // option "minfrag_matrix" = 0 recomputes capacities in every pass
     DeviceBuf<int32_t> d_mfhist;            // ... and the capacity histograms per (candidate view, request shape)
-    bool fifo_minfrag_hist = true;          // GANGFIT_MINFRAG_HIST=0: block-cooperative passes instead of the histogram path
+    bool fifo_minfrag_hist = true;          // option "minfrag_hist" = 0: block-cooperative passes instead of the histogram path
     // narrow (scaled int32) form of the table: value = scaled * unit[dim]; exists when every |value / unit| < 2^30
     bool narrow_ok = false;
     int64_t unit[3] = {1, 1, 1};
     int64_t nmax[3] = {0, 0, 0};  // largest |scaled value| per dimension: how far the units may still be refined per batch
     DeviceBuf<int32_t> d_nsnap, d_nwork, d_ncmax, d_ncmax_w;
     PinnedBuf<int32_t> h_ntable;
-    // GANGFIT_FIFO_KERNEL: "narrow" (default: narrow first, v2 as its wide fallback), "fused" (wide fused only),
-    // "v2" (general-layout kernel only), "narrow+fused" (narrow first, wide fused as the fallback)
-    bool fifo_use_narrow = true, fifo_wide_fused = false;
-    bool fifo_solo = true;     // narrow chain = one controlling wavefront (gangfit_fifo_solo.inc); GANGFIT_FIFO_SOLO=0 selects the block-cooperative kernel
-    bool fifo_zoned_lds = true;  // GANGFIT_FIFO_ZONED=generic forces the global-memory chain for the zone-aware packers
-    int fifo_waves = 8;        // wavefronts of the block-cooperative FIFO-chain kernels (1, 4, 8 or 16; 8 measured best with the exact chunk index); GANGFIT_FIFO_WAVES overrides
+    bool fifo_generic = false;  // option "fifo_generic": chains run on the wide / generic global-memory kernels only
+    bool force_general_layout = false;  // option "force_general_layout": gf_orders_set never merges the two orders
     uint32_t lds_budget = 0;   // bytes of LDS one workgroup may use
 
     // zone views + efficiency tables (single-AZ packers, LIB/binpack/single_az.go; efficiency.go)
@@ -186,7 +181,7 @@ struct gf_ctx {
     uint32_t n_zones = 0, zstride = 0;
     uint32_t zd_row0 = 0;              // row of d_zmasks where the driver masks start (n_zones, or the zone count of a device build)
     bool host_stale = false;           // the host mirrors (avail / sched / h_node_slot) still sit on the device (gf_snapshot_build)
-    bool snapshot_finalize_on_device = true;  // GANGFIT_SNAPSHOT_FINALIZE=host builds the slot tables through gf_orders_set
+    bool snapshot_finalize_on_device = true;  // option "snapshot_finalize_host" = 1 builds the slot tables through gf_orders_set
     DeviceBuf<gf_result> d_zres;
     DeviceBuf<uint32_t> d_zexec;
     DeviceBuf<double> d_zavg, d_avg;
@@ -245,6 +240,32 @@ struct gf_ctx {
     PinnedBuf<uint32_t> h_exec;
     PinnedBuf<int32_t> h_failed;
     bool stats_on = false;
+
+    // ---- incremental FIFO chains (gf_fit_batch, GF_MODE_FIFO_CHAIN).  The reference replays every earlier driver on every
+    //      Filter (resource.go:309-328); with an unchanged snapshot driver j + 1's chain is driver j's chain plus one
+    //      application.  The chain kernels therefore dump their working table every 2^shift applications (ChainCkpt), the
+    //      host keeps the last chain's records, results and placements, and the next chain resumes from the last checkpoint
+    //      inside the longest common prefix of the two queues.  Anything that installs a snapshot, zones or orders bumps
+    //      snap_epoch and with it drops the cache.  Results are those of a full replay bit for bit: a checkpoint IS the
+    //      table a replay would hold at that application.
+    uint64_t snap_epoch = 1;
+    bool chain_cache_on = true;  // GANGFIT_CHAIN_CACHE=0 / option "chain_cache" = 0: every chain replays from the snapshot
+    struct ChainCache {
+        bool valid = false;
+        uint64_t epoch = 0;
+        int algo = -1;
+        int64_t unit[3] = {0, 0, 0};  // narrow units the checkpoints are scaled in
+        uint32_t shift = 5;
+        uint32_t n_apps = 0;
+        uint32_t n_ckpt = 0;          // checkpoints 1 .. n_ckpt hold the table before application i << shift
+        int32_t failed_at = -1;
+        std::vector<gf_app> apps;     // the queue of the last chain (with exec_off)
+        std::vector<gf_result> results;
+        std::vector<uint32_t> exec;
+        DeviceBuf<int32_t> d_ckpt;    // [n][3 * n_slots]
+        size_t slot_words = 0;        // 3 * n_slots of the snapshot the buffer was laid out for
+    } chain;
+    uint64_t chain_stat[4] = {0, 0, 0, 0};  // chains | resumed chains | applications evaluated | applications skipped
 };
 
 namespace {
@@ -373,48 +394,70 @@ int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
 // therefore refined to gcd(table unit, every request of the batch) and the working copy is multiplied up by the ratio —
 // as long as every scaled magnitude stays below 2^30; comparisons, subtractions and floor divisions are invariant under a
 // common factor, so the chain is bit-identical.  Device-resident batches (gf_fit_batch_dev) keep the table's units.
-int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t stream, gangfit::NarrowTable* nt) {
-    int64_t eff[3] = {ctx->unit[0], ctx->unit[1], ctx->unit[2]};
-    int32_t factor[3] = {1, 1, 1};
-    if (h_apps != nullptr) {
-        for (uint32_t a = 0; a < n_apps; ++a)
+// *proven (nullable): every request of the batch is a multiple of the resulting units and fits the narrow range, i.e. the
+// narrow kernel will not hand the batch to its wide twin (what prepare_apps_kernel tests on the device).
+void narrow_units(const gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, int64_t eff[3], int32_t factor[3], bool* proven) {
+    for (int j = 0; j < 3; ++j) {
+        eff[j] = ctx->unit[j];
+        factor[j] = 1;
+    }
+    if (proven) *proven = false;
+    if (h_apps == nullptr) return;
+    for (uint32_t a = 0; a < n_apps; ++a)
+        for (int j = 0; j < 3; ++j)
+            for (const int64_t v : {h_apps[a].drv[j], h_apps[a].exe[j]})
+                if (v > 0 && v % eff[j] != 0) {
+                    int64_t x = eff[j], y = v;
+                    while (y) {
+                        const int64_t t = x % y;
+                        x = y;
+                        y = t;
+                    }
+                    eff[j] = x;
+                }
+    bool ok = true;
+    for (int j = 0; j < 3; ++j) {
+        const int64_t f = ctx->unit[j] / eff[j];
+        const int64_t room = ctx->nmax[j] > 0 ? ((INT64_C(1) << 30) - 1) / ctx->nmax[j] : (INT64_C(1) << 30) - 1;
+        ok = ok && f <= room;
+        factor[j] = ok ? (int32_t)f : 1;
+    }
+    if (!ok)
+        for (int j = 0; j < 3; ++j) {
+            eff[j] = ctx->unit[j];
+            factor[j] = 1;
+        }
+    if (proven) {
+        bool all = true;
+        for (uint32_t a = 0; a < n_apps && all; ++a)
             for (int j = 0; j < 3; ++j)
                 for (const int64_t v : {h_apps[a].drv[j], h_apps[a].exe[j]})
-                    if (v > 0 && v % eff[j] != 0) {
-                        int64_t x = eff[j], y = v;
-                        while (y) {
-                            const int64_t t = x % y;
-                            x = y;
-                            y = t;
-                        }
-                        eff[j] = x;
-                    }
-        bool ok = true;
-        for (int j = 0; j < 3; ++j) {
-            const int64_t f = ctx->unit[j] / eff[j];
-            const int64_t room = ctx->nmax[j] > 0 ? ((INT64_C(1) << 30) - 1) / ctx->nmax[j] : (INT64_C(1) << 30) - 1;
-            ok = ok && f <= room;
-            factor[j] = ok ? (int32_t)f : 1;
-        }
-        if (!ok)
-            for (int j = 0; j < 3; ++j) {
-                eff[j] = ctx->unit[j];
-                factor[j] = 1;
-            }
+                    all = all && v >= 0 && v % eff[j] == 0 && v / eff[j] < (INT64_C(1) << 30);
+        *proven = all;
     }
+}
+
+// restore (nullable): a checkpoint of an earlier chain in the SAME units — the working copy starts from it instead of the
+// snapshot (incremental chains).
+int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t stream, gangfit::NarrowTable* nt,
+                 const int32_t* restore = nullptr) {
+    int64_t eff[3];
+    int32_t factor[3];
+    narrow_units(ctx, h_apps, n_apps, eff, factor, nullptr);
     nt->cpu = ctx->d_nwork.ptr;
     nt->mem = nt->cpu + ctx->n_slots;
     nt->gpu = nt->mem + ctx->n_slots;
     for (int j = 0; j < 3; ++j) nt->unit[j] = eff[j];
+    const size_t table_bytes = 3 * (size_t)ctx->n_slots * sizeof(int32_t);
     if (factor[0] == 1 && factor[1] == 1 && factor[2] == 1) {
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, ctx->d_nsnap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int32_t),
-                                   hipMemcpyDeviceToDevice, stream));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, restore ? restore : ctx->d_nsnap.ptr, table_bytes, hipMemcpyDeviceToDevice, stream));
         nt->cmax = ctx->d_ncmax.ptr;
         return GF_OK;
     }
     GF_HIP(ctx, ctx->d_ncmax_w.reserve(3 * (size_t)ctx->n_chunks));
     GF_HIP(ctx, gangfit::launch_narrow_rescale(ctx->d_nsnap.ptr, ctx->d_nwork.ptr, ctx->n_slots, ctx->d_ncmax.ptr,
                                                ctx->d_ncmax_w.ptr, ctx->n_chunks, factor, stream));
+    if (restore) GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, restore, table_bytes, hipMemcpyDeviceToDevice, stream));
     nt->cmax = ctx->d_ncmax_w.ptr;
     return GF_OK;
 }
@@ -426,7 +469,7 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
                     gf_result* d_results, uint32_t* d_exec_nodes, uint64_t half, int32_t* d_failed, hipStream_t stream,
                     const int32_t** run_if) {
     *run_if = nullptr;
-    if (!(ctx->merged && ctx->narrow_ok && ctx->fifo_zoned_lds) || (zoned && (nz == 0 || nz > 16))) return GF_OK;
+    if (!(ctx->merged && ctx->narrow_ok && !ctx->fifo_generic) || (zoned && (nz == 0 || nz > 16))) return GF_OK;
     const uint32_t zviews = zoned ? nz : 0u;
     // 64 shape ids per role (rows of the capacity matrix, histograms); as many of them as LDS allows next to the masks also
     // get chunk-index rows (64 down to 0 — the histogram path does without), then as much of the table as fits
@@ -488,7 +531,7 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         const bool az_aware = algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK;
         const int32_t* run_if = nullptr;
         // fast path: tightly-pack family, merged layout, narrow table, every candidate view gets its own wavefront
-        if (inner == GF_ALGO_TIGHTLY_PACK && ctx->merged && ctx->narrow_ok && ctx->fifo_zoned_lds && nz + (az_aware ? 1u : 0u) <= 16) {
+        if (inner == GF_ALGO_TIGHTLY_PACK && ctx->merged && ctx->narrow_ok && !ctx->fifo_generic && nz + (az_aware ? 1u : 0u) <= 16) {
             // as many shape-index rows as LDS allows next to the masks (64 down to 4), then as much of the table as fits
             uint32_t n_shapes = 64;
             const uint32_t n_cand = nz + (az_aware ? 1u : 0u);
@@ -529,9 +572,101 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     return GF_OK;
 }
 
+// How one FIFO chain of gf_fit_batch uses the chain cache (decided by chain_plan before the launch).
+struct ChainRun {
+    uint32_t a_begin = 0;        // first application this launch evaluates (a multiple of 1 << shift); 0 = from the snapshot
+    bool record = false;         // dump checkpoints into ctx->chain.d_ckpt
+    bool narrow_proven = false;  // every request has a scaled form (checked on the host): the wide twin is not launched
+};
+
+// Which chains resume: the plain packers on the solo kernel (merged layout, narrow table) with every request in scaled
+// form.  Returns false when the chain cache is not used for this call (run stays {0, false, false}).
+bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, ChainRun* run) {
+    *run = ChainRun{};
+    gf_ctx::ChainCache& C = ctx->chain;
+    if (mode != GF_MODE_FIFO_CHAIN || !ctx->chain_cache_on || ctx->stats_on || !ctx->have_orders) return false;
+    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY) return false;
+    if (!(ctx->merged && ctx->narrow_ok) || ctx->fifo_generic) return false;
+    int64_t eff[3];
+    int32_t factor[3];
+    bool proven = false;
+    narrow_units(ctx, h_apps, n_apps, eff, factor, &proven);
+    if (!proven) return false;
+    // checkpoint interval: 32 applications, wider when 128 dumps of this table would not fit 2 GiB
+    const size_t slot_words = 3 * (size_t)ctx->n_slots;
+    uint32_t shift = 5;
+    while (shift < 12 && (size_t)(4096u >> shift) * slot_words * sizeof(int32_t) > (UINT64_C(2) << 30)) ++shift;
+    const size_t n_ck = (size_t)((n_apps - 1) >> shift);
+    if (n_ck * slot_words * sizeof(int32_t) > (UINT64_C(4) << 30)) return false;
+    uint32_t a_begin = 0;
+    const bool same = C.valid && C.epoch == ctx->snap_epoch && C.algo == (int)algo && C.shift == shift &&
+                      C.slot_words == slot_words && C.unit[0] == eff[0] && C.unit[1] == eff[1] && C.unit[2] == eff[2];
+    if (same) {
+        // longest common prefix of the two queues, the last application of either excluded (nothing is committed behind
+        // the driver being filtered: its table is not a state of the longer chain)
+        uint32_t lim = (n_apps < C.n_apps ? n_apps : C.n_apps) - 1;
+        uint32_t m = 0;
+        while (m < lim && std::memcmp(&h_apps[m], &C.apps[m], sizeof(gf_app)) == 0) ++m;
+        uint32_t c = m >> shift;
+        if (c > C.n_ckpt) c = C.n_ckpt;
+        a_begin = c << shift;
+    }
+    // the checkpoint buffer keeps what it holds when it grows
+    if (n_ck * slot_words > C.d_ckpt.cap) {
+        size_t want = C.d_ckpt.cap ? C.d_ckpt.cap : 32 * slot_words;
+        while (want < n_ck * slot_words) want *= 2;
+        int32_t* fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(int32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const size_t keep = (size_t)(a_begin >> shift) * slot_words;
+        if (keep && hipMemcpy(fresh, C.d_ckpt.ptr, keep * sizeof(int32_t), hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipFree(fresh);
+            return false;
+        }
+        if (C.d_ckpt.ptr) {
+            (void)gf_wait_stream(ctx->stream);
+            (void)hipFree(C.d_ckpt.ptr);
+        }
+        C.d_ckpt.ptr = fresh;
+        C.d_ckpt.cap = want;
+    }
+    if (!same) C.valid = false;
+    C.shift = shift;
+    C.slot_words = slot_words;
+    for (int j = 0; j < 3; ++j) C.unit[j] = eff[j];
+    run->a_begin = a_begin;
+    run->record = true;
+    run->narrow_proven = true;
+    return true;
+}
+
+// The chain that just ran becomes the cached one (h_results / h_exec hold the complete answer, prefix included).
+void chain_commit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, uint64_t total_k, int32_t failed_at, const ChainRun& run) {
+    gf_ctx::ChainCache& C = ctx->chain;
+    C.apps.assign(ctx->h_apps.ptr, ctx->h_apps.ptr + n_apps);
+    C.results.assign(ctx->h_results.ptr, ctx->h_results.ptr + n_apps);
+    C.exec.assign(ctx->h_exec.ptr, ctx->h_exec.ptr + total_k);
+    C.n_apps = n_apps;
+    C.failed_at = failed_at;
+    C.algo = (int)algo;
+    C.epoch = ctx->snap_epoch;
+    // the chain reached application `last` (the one it aborted at, else the filtered driver): dumps exist up to there
+    const uint32_t last = failed_at >= 0 ? (uint32_t)failed_at : n_apps - 1;
+    C.n_ckpt = last >> C.shift;
+    C.valid = true;
+    ctx->chain_stat[0] += 1;
+    ctx->chain_stat[1] += run.a_begin > 0 ? 1 : 0;
+    ctx->chain_stat[2] += (failed_at >= 0 ? (uint32_t)failed_at + 1 : n_apps) - run.a_begin;
+    ctx->chain_stat[3] += run.a_begin;
+}
+
 // h_apps: the same records on the host when the caller has them (gf_fit_batch), nullptr for device-resident batches.
+// run (nullable): gf_fit_batch's plan for a FIFO chain; d_apps / d_results are always the arrays of the WHOLE queue.
 int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, const gf_app* d_apps,
-           gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
+           gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream,
+           const ChainRun* run = nullptr) {
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
     const uint64_t half = exec_nodes_len + 1;
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
@@ -565,16 +700,18 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps,
                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
     } else if (mode == GF_MODE_FIFO_CHAIN) {
-        // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303)
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
-                                   hipMemcpyDeviceToDevice, stream));
+        gangfit::FifoPlan plan{};
+        plan.narrow = ctx->merged && ctx->narrow_ok && !ctx->fifo_generic;
+        plan.wide = !(plan.narrow && run != nullptr && run->narrow_proven);
+        const uint32_t a_begin = (plan.narrow && run != nullptr) ? run->a_begin : 0u;
+        // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303).
+        // The solo kernel rewrites every real slot of the wide working table in its epilogue: the copy is only needed by the
+        // wide kernel.
+        if (plan.wide)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                       hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
         // as much of the table front as fits next to each kernel's fixed LDS needs stays in LDS for the whole chain
-        gangfit::FifoPlan plan{};
-        plan.n_waves = ctx->fifo_waves;
-        plan.narrow = ctx->merged && ctx->narrow_ok && ctx->fifo_use_narrow;
-        plan.wide_fused = ctx->merged && ctx->fifo_wide_fused;
-        const uint32_t block = 64u * (uint32_t)(ctx->fifo_waves <= 4 ? 4 : (ctx->fifo_waves <= 8 ? 8 : 16));
         auto front = [&](size_t fixed, size_t per_slot, uint32_t round) {
             uint32_t n = ctx->lds_budget > fixed ? (uint32_t)((ctx->lds_budget - fixed) / per_slot) : 0;
             const uint32_t whole = (ctx->n_slots + round - 1) / round * round;  // the whole table, padded to full steps
@@ -583,9 +720,6 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         };
         plan.lds_slots_v2 = front(gangfit::fifo_v2_lds_bytes(0, ctx->n_chunks), 24, 64);
         if (plan.lds_slots_v2 > ctx->n_slots) plan.lds_slots_v2 = ctx->n_slots;
-        plan.lds_slots_fused = front(gangfit::fifo_fused_lds_bytes(0, ctx->n_chunks), 24, block);
-        plan.lds_slots_narrow = front(gangfit::fifo_narrow_lds_bytes(0, ctx->n_chunks), 12, block);
-        plan.solo = ctx->fifo_solo;
         {  // whole 64-slot chunk blocks (784 bytes each: three dimensions + the two candidate masks)
             const size_t fixed = gangfit::fifo_solo_lds_bytes(0, ctx->n_chunks);
             const size_t per_chunk = gangfit::fifo_solo_lds_bytes(64, ctx->n_chunks) - fixed;
@@ -594,14 +728,21 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
             plan.lds_slots_solo = (uint32_t)((fit < whole ? fit : whole) * 64u);
         }
         gangfit::NarrowTable nt{};
+        gangfit::ChainCkpt ck{nullptr, a_begin, ctx->chain.shift};
         if (plan.narrow) {
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
-            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt); nrc != GF_OK) return nrc;
+            const int32_t* restore = nullptr;
+            if (run != nullptr && (run->record || a_begin > 0)) {
+                ck.base = ctx->chain.d_ckpt.ptr;
+                if (a_begin > 0) restore = ck.base + (size_t)((a_begin >> ck.shift) - 1u) * ctx->chain.slot_words;
+            }
+            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
         }
-        if (plan.wide_fused) GF_HIP(ctx, ctx->d_dev_apps.reserve(n_apps));
-        GF_HIP(ctx, gangfit::launch_fit_fifo(algo, plan, make_table(ctx, ctx->d_work.ptr), nt, n_apps, d_apps,
-                                             ctx->d_dev_apps.ptr, ctx->d_napps.ptr, ctx->d_wide_needed.ptr, d_results,
-                                             d_exec_nodes, ctx->d_scratch.ptr, half, d_failed, stats, stream));
+        // a resumed chain is launched on the tail of the queue: exec_off is absolute, so offset pointers are all it takes
+        const uint64_t heads_lo = a_begin > 0 ? h_apps[a_begin].exec_off : 0;
+        GF_HIP(ctx, gangfit::launch_fit_fifo(algo, plan, make_table(ctx, ctx->d_work.ptr), nt, n_apps - a_begin, d_apps + a_begin,
+                                             ctx->d_napps.ptr + a_begin, ctx->d_wide_needed.ptr, d_results + a_begin,
+                                             d_exec_nodes, ctx->d_scratch.ptr, half, heads_lo, d_failed, ck, stats, stream));
     } else {
         return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
     }
@@ -682,25 +823,9 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     ctx->info.clock_khz = prop.clockRate;
     ctx->info.hbm_bytes = (int64_t)prop.totalGlobalMem;
     ctx->lds_budget = (uint32_t)prop.maxSharedMemoryPerMultiProcessor;
-    if (const char* w = std::getenv("GANGFIT_FIFO_WAVES")) {
-        const int v = std::atoi(w);
-        if (v == 1 || v == 4 || v == 8 || v == 16) ctx->fifo_waves = v;
-    }
-    if (const char* k = std::getenv("GANGFIT_FIFO_KERNEL")) {
-        ctx->fifo_use_narrow = std::strncmp(k, "narrow", 6) == 0;
-        ctx->fifo_wide_fused = std::strstr(k, "fused") != nullptr;
-    }
-    if (const char* z = std::getenv("GANGFIT_FIFO_SOLO")) ctx->fifo_solo = std::strcmp(z, "0") != 0;
-    if (const char* z = std::getenv("GANGFIT_FIFO_ZONED")) ctx->fifo_zoned_lds = std::strcmp(z, "generic") != 0;
-    if (const char* z = std::getenv("GANGFIT_MINFRAG_MATRIX")) ctx->fifo_minfrag_matrix = std::strcmp(z, "0") != 0;
-    if (const char* z = std::getenv("GANGFIT_MINFRAG_HIST")) ctx->fifo_minfrag_hist = std::strcmp(z, "0") != 0;
-    if (const char* z = std::getenv("GANGFIT_SPARSE_GPU")) ctx->sparse_gpu = std::strcmp(z, "0") != 0;
-    if (const char* z = std::getenv("GANGFIT_ZEROCOPY")) ctx->zero_copy = std::strcmp(z, "0") != 0;
-    if (const char* z = std::getenv("GANGFIT_SNAPSHOT_FINALIZE")) ctx->snapshot_finalize_on_device = std::strcmp(z, "host") != 0;
-    if (const char* l = std::getenv("GANGFIT_LDS_BUDGET")) {
-        const long v = std::atol(l);
-        if (v >= 0 && (uint32_t)v <= ctx->lds_budget) ctx->lds_budget = (uint32_t)v;
-    }
+    // the one switch of the data path a deployment may want (GANGFIT_WAIT is the other environment variable, see above):
+    // every chain replays from the snapshot, as the reference does
+    if (const char* z = std::getenv("GANGFIT_CHAIN_CACHE")) ctx->chain_cache_on = std::strcmp(z, "0") != 0;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.warpSize != 64) {
         delete ctx;
         return GF_ERR_NO_DEVICE;  // the kernels are gfx950 / wave64 only
@@ -746,8 +871,8 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_gmask.release();
     ctx->h_gtab.release();
     ctx->h_gidx.release();
-    ctx->d_dev_apps.release();
     ctx->d_napps.release();
+    ctx->chain.d_ckpt.release();
     ctx->d_wide_needed.release();
     ctx->d_capmat.release();
     ctx->d_mfhist.release();
@@ -830,6 +955,56 @@ void gf_ctx_unlock(gf_ctx* ctx) {
 }
 
 const char* gf_last_error(gf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return GF_ERR_INVALID;
+    if (!ctx->group.empty()) {
+        std::lock_guard<std::recursive_mutex> glock(ctx->mu);
+        for (gf_ctx* sub : ctx->group)
+            if (const int rc = gf_set_option(sub, key, value); rc != GF_OK) {
+                ctx->err = sub->err;
+                return rc;
+            }
+        return GF_OK;
+    }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const std::string k(key);
+    if (k == "lds_budget") {
+        if (value < 0 || value > (int64_t)ctx->info.lds_bytes_per_cu) return fail(ctx, GF_ERR_INVALID, "lds_budget outside [0, %d]", ctx->info.lds_bytes_per_cu);
+        ctx->lds_budget = (uint32_t)value;
+    } else if (k == "fifo_generic") {
+        ctx->fifo_generic = value != 0;
+    } else if (k == "minfrag_matrix") {
+        ctx->fifo_minfrag_matrix = value != 0;
+    } else if (k == "minfrag_hist") {
+        ctx->fifo_minfrag_hist = value != 0;
+    } else if (k == "sparse_gpu") {
+        ctx->sparse_gpu = value != 0;
+    } else if (k == "zero_copy") {
+        ctx->zero_copy = value != 0;
+    } else if (k == "snapshot_finalize_host") {
+        ctx->snapshot_finalize_on_device = value == 0;
+    } else if (k == "force_general_layout") {
+        ctx->force_general_layout = value != 0;
+    } else if (k == "chain_cache") {
+        ctx->chain_cache_on = value != 0;
+    } else {
+        return fail(ctx, GF_ERR_INVALID, "unknown option '%s'", key);
+    }
+    ctx->chain.valid = false;
+    return GF_OK;
+}
+
+int gf_chain_cache_stats(gf_ctx* ctx, int reset, uint64_t out[4]) {
+    GF_DELEGATE(ctx, gf_chain_cache_stats(ctx, reset, out));
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (out)
+        for (int i = 0; i < 4; ++i) out[i] = ctx->chain_stat[i];
+    if (reset)
+        for (uint64_t& v : ctx->chain_stat) v = 0;
+    return GF_OK;
+}
 
 int gf_hbm_probe(gf_ctx* ctx, uint64_t bytes, uint32_t iters, double* read_gb_per_s, double* copy_gb_per_s) {
     GF_DELEGATE(ctx, gf_hbm_probe(ctx, bytes, iters, read_gb_per_s, copy_gb_per_s));
@@ -958,6 +1133,7 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
     ctx->have_snapshot = true;
     ctx->have_orders = false;
     ctx->work_valid = false;
+    ++ctx->snap_epoch;  // drops the chain cache
     // node-indexed copy for the per-node efficiency map (gf_packing_efficiencies)
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, gf_wait_stream(ctx->stream));
@@ -980,6 +1156,7 @@ int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
     if (ctx->n_nodes > 0 && !zone_of_node) return fail(ctx, GF_ERR_INVALID, "zone array must not be NULL");
     ctx->zone.assign(zone_of_node, zone_of_node + ctx->n_nodes);
     ctx->have_orders = false;  // the zone views are built by gf_orders_set
+    ++ctx->snap_epoch;
     return GF_OK;
 }
 
@@ -1024,7 +1201,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     // ---- merged layout: one order that has both (cleaned) orders as subsequences, if it exists
     std::vector<uint32_t> merged;
     std::vector<uint8_t> mflags;  // bit 0: executor candidate, bit 1: driver candidate
-    bool mergeable = std::getenv("GANGFIT_FORCE_GENERAL_LAYOUT") == nullptr;
+    bool mergeable = !ctx->force_general_layout;
     if (mergeable) {
         merged.reserve(xs.size() + ds.size());
         size_t i = 0, j = 0;
@@ -1324,6 +1501,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     ctx->merged = mergeable;
     ctx->have_orders = true;
     ctx->work_valid = false;
+    ++ctx->snap_epoch;
     return GF_OK;
 }
 
@@ -1378,19 +1556,41 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         }
         (void)hipGetLastError();
     }
-    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
+    // ---- FIFO chains of the plain packers on the solo kernel: resume from the last chain's checkpoints where the queues agree
+    ChainRun run;
+    const bool use_cache = chain_plan(ctx, mode, algo, n_apps, ctx->h_apps.ptr, &run);
+    const uint32_t a0 = run.a_begin;
+    const uint64_t k0 = a0 > 0 ? ctx->h_apps.ptr[a0].exec_off : 0;  // placements of the skipped prefix
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr + a0, ctx->h_apps.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_app),
+                               hipMemcpyHostToDevice, st));
     const int rc = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr,
-                          total_k, ctx->d_failed.ptr, st);
-    if (rc != GF_OK) return rc;
-    GF_HIP(ctx, hipMemcpyAsync(ctx->h_results.ptr, ctx->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, st));
-    if (total_k)
-        GF_HIP(ctx, hipMemcpyAsync(ctx->h_exec.ptr, ctx->d_exec.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                          total_k, ctx->d_failed.ptr, st, use_cache ? &run : nullptr);
+    if (rc != GF_OK) {
+        ctx->chain.valid = false;
+        return rc;
+    }
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_results.ptr + a0, ctx->d_results.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_result),
+                               hipMemcpyDeviceToHost, st));
+    if (total_k > k0)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_exec.ptr + k0, ctx->d_exec.ptr + k0, (size_t)(total_k - k0) * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
     if (mode == GF_MODE_FIFO_CHAIN)
         GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_failed.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GF_HIP(ctx, gf_wait_stream(st));
+    const hipError_t we = gf_wait_stream(st);
+    if (we != hipSuccess) {
+        ctx->chain.valid = false;
+        return fail(ctx, GF_ERR_HIP, "waiting for the batch failed: %s", hipGetErrorString(we));
+    }
+    int32_t failed_at = mode == GF_MODE_FIFO_CHAIN ? ctx->h_failed.ptr[0] : -1;
+    if (a0 > 0) {  // the prefix the chain did not replay comes from the cache; the kernel counted from a0
+        std::memcpy(ctx->h_results.ptr, ctx->chain.results.data(), (size_t)a0 * sizeof(gf_result));
+        if (k0) std::memcpy(ctx->h_exec.ptr, ctx->chain.exec.data(), (size_t)k0 * sizeof(uint32_t));
+        if (failed_at >= 0) failed_at += (int32_t)a0;
+    }
+    if (use_cache) chain_commit(ctx, algo, n_apps, total_k, failed_at, run);
     std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
     if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
-    if (mode == GF_MODE_FIFO_CHAIN && chain_failed_at) *chain_failed_at = ctx->h_failed.ptr[0];
+    if (mode == GF_MODE_FIFO_CHAIN && chain_failed_at) *chain_failed_at = failed_at;
     return GF_OK;
 }
 
@@ -1793,6 +1993,7 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         ctx->zd_row0 = n_zones;
         ctx->have_orders = true;
         ctx->work_valid = false;
+        ++ctx->snap_epoch;
         ctx->host_stale = true;
         if (driver_order_out || exec_order_out || n_d_out || n_x_out) {  // the two lists, for callers that want them
             GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

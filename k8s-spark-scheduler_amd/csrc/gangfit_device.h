@@ -75,20 +75,7 @@ struct EffTables {
     const int64_t* sched[3];
 };
 
-// App record as the FIFO-chain kernel consumes it: gf_app + the per-dimension reciprocals of the executor request
-// (prepare_apps_kernel computes them once per launch).  128 bytes = 8 lanes x 16 bytes.
-struct DevApp {
-    int64_t drv[3];
-    int64_t exe[3];
-    double rcp[3];
-    int32_t k;
-    uint32_t flags;
-    uint64_t exec_off;
-    uint64_t pad[5];
-};
-static_assert(sizeof(DevApp) == 128, "DevApp must be 128 bytes");
-
-// Narrow (scaled int32) domain of the FIFO chain — see gangfit_fifo_narrow.inc.
+// Narrow (scaled int32) domain of the FIFO chain — see gangfit_fifo_common.inc.
 struct NApp {  // 64 bytes, produced by prepare_apps_kernel: requests divided by the table's units
     int32_t drv[3];
     int32_t k;
@@ -130,31 +117,34 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
 
-// FIFO chain (fitEarlierDrivers + final pack).  One workgroup walks the chain; three kernels:
-//   v2     (gangfit_kernels.hip)      — any layout, wide (int64) table, separate driver / executor scans
-//   fused  (gangfit_fifo_fused.inc)   — merged layout, wide table, fused scan
-//   narrow (gangfit_fifo_narrow.inc)  — merged layout, scaled int32 table: the fast path; when a request of the batch is not
-//                                       representable it returns at once and the wide kernel (guarded the other way) runs
-//   solo   (gangfit_fifo_solo.inc)    — the narrow kernel's contract with ONE wavefront walking the chain (default)
+// FIFO chain (fitEarlierDrivers + final pack) of the plain packers.  One workgroup walks the chain; two kernels:
+//   solo (gangfit_fifo_solo.inc) — merged layout, scaled int32 table in LDS, ONE wavefront walking the chain: the fast
+//                                  path; when a request of the batch has no scaled form it returns at once
+//   v2   (gangfit_kernels.hip)   — any layout, wide (int64) table: the fallback (guarded the other way when both run)
 // followed by expand_translate_kernel (run heads -> placement list, slot ids -> node indices).
 struct FifoPlan {
-    int n_waves;                // wavefronts of the workgroup (1 / 4 / 16 for v2; 4 / 8 / 16 for fused and narrow)
-    bool narrow;                // launch the narrow kernel first (merged layout and the table has a narrow form)
-    bool solo;                  // narrow kernel = the one-controlling-wavefront chain (gangfit_fifo_solo.inc)
-    bool wide_fused;            // wide kernel = fused instead of v2 (merged layout only)
+    bool narrow;                // launch the solo kernel (merged layout and the table has a narrow form)
+    bool wide;                  // launch the wide kernel (alone, or guarded by *d_wide_needed behind the solo kernel)
     uint32_t lds_slots_v2;      // table slots each kernel keeps in LDS
-    uint32_t lds_slots_fused;
-    uint32_t lds_slots_narrow;
     uint32_t lds_slots_solo;
 };
+// Checkpoints of a chain (incremental Filter chains, gf_fit_batch): before it stages the application with ABSOLUTE index
+// i << shift (i >= 1) the solo kernel dumps its narrow working table (3 * n_slots int32, the layout of NarrowTable) to
+// base + (i - 1) * 3 * n_slots.  a_base = absolute index of the first application of this launch (a resumed chain is
+// launched on the tail of the queue with the restored table); base == nullptr: no checkpoints.
+struct ChainCkpt {
+    int32_t* base;
+    uint32_t a_base;
+    uint32_t shift;
+};
 size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
-size_t fifo_fused_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
-size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
+// heads_lo: first entry of d_scratch this launch may write run heads to (the placements of a resumed chain start there)
 hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
-                           uint32_t n_apps, const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps,
-                           int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                           uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream);
+                           uint32_t n_apps, const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed,
+                           gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
+                           uint64_t heads_lo, int32_t* d_chain_failed_at, const ChainCkpt& ckpt, ScanStats* d_stats,
+                           hipStream_t stream);
 
 // Zone-aware packers on an independent batch: one wave per (app, zone) runs SparkBinPack on the zone's view, one wave
 // per decision averages the packing efficiencies of [driver] ++ executors in slice order (chooseBestResult,

@@ -1517,8 +1517,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     }
 }
 
-#include "gangfit_fifo_fused.inc"
-#include "gangfit_fifo_narrow.inc"
+#include "gangfit_fifo_common.inc"
 #include "gangfit_fifo_solo.inc"
 #include "gangfit_zones.inc"
 #include "gangfit_fifo_zoned.inc"
@@ -1614,17 +1613,6 @@ size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
     return 24 * ((size_t)lds_slots + n_chunks) + 16 * (size_t)n_chunks + sizeof(Exchange) + sizeof(FifoShared) + 64 +
            ((n_chunks + 15) & ~15u);
 }
-size_t fifo_fused_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
-    return kFusedStage * sizeof(DevApp) + ((sizeof(FusedShared) + 15) & ~(size_t)15) + 24 * (size_t)lds_slots +
-           40 * (size_t)n_chunks + 16;
-}
-size_t fifo_narrow_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
-    const size_t nw = (n_chunks + 63u) / 64u;
-    return kFusedStage * sizeof(NApp) + ((sizeof(NarrowShared) + 15) & ~(size_t)15) + 16 * (size_t)n_chunks +
-           16 * (size_t)kMaxShapes * nw + 16 + sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 +
-           12 * (size_t)n_chunks + 12 * (size_t)lds_slots + 16;
-}
-
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
     const size_t nw = (n_chunks + 63u) / 64u, nwp = nw < 4 ? 4 : nw;
     size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nwp +
@@ -1651,66 +1639,24 @@ hipError_t launch_v2(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, con
                      uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, int32_t* d_failed, ScanStats* d_stats,
                      const int32_t* guard, hipStream_t stream) {
     const size_t lds = fifo_v2_lds_bytes(P.lds_slots_v2, T.n_chunks);
-#define GF_V2(NW, DI)                                                                                              \
-    return launch_one_workgroup(fit_fifo_chain_kernel<ALGO, NW, DI>, NW, lds, stream, T, P.lds_slots_v2, n_apps, d_apps, \
-                                d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard)
-    if (T.d_identity) {
-        if (P.n_waves <= 1) GF_V2(1, true);
-        if (P.n_waves <= 4) GF_V2(4, true);
-        GF_V2(16, true);
-    }
-    if (P.n_waves <= 1) GF_V2(1, false);
-    if (P.n_waves <= 4) GF_V2(4, false);
-    GF_V2(16, false);
-#undef GF_V2
-}
-
-template <int ALGO>
-hipError_t launch_fused(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, const DevApp* d_dev_apps,
-                        gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half,
-                        int32_t* d_failed, ScanStats* d_stats, const int32_t* guard, hipStream_t stream) {
-    const size_t lds = fifo_fused_lds_bytes(P.lds_slots_fused, T.n_chunks);
-#define GF_FU(NW)                                                                                                     \
-    return launch_one_workgroup(fit_fifo_fused_kernel<ALGO, NW>, NW, lds, stream, T, P.lds_slots_fused, n_apps, d_dev_apps, \
-                                d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard)
-    if (P.n_waves <= 4) GF_FU(4);
-    if (P.n_waves <= 8) GF_FU(8);
-    GF_FU(16);
-#undef GF_FU
-}
-
-template <int ALGO>
-hipError_t launch_narrow(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
-                         NApp* d_napps, const int32_t* d_wide_needed, gf_result* d_results,
-                         uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, int32_t* d_failed,
-                         ScanStats* d_stats, hipStream_t stream) {
-    const size_t lds = fifo_narrow_lds_bytes(P.lds_slots_narrow, T.n_chunks);
-#define GF_NA(NW)                                                                                                       \
-    {                                                                                                                   \
-        if (d_stats != nullptr)                                                                                         \
-            return launch_one_workgroup(fit_fifo_narrow_kernel<ALGO, NW, true>, NW, lds, stream, T, NT, P.lds_slots_narrow, \
-                                        n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,       \
-                                        d_failed, d_stats);                                                            \
-        return launch_one_workgroup(fit_fifo_narrow_kernel<ALGO, NW, false>, NW, lds, stream, T, NT, P.lds_slots_narrow, \
-                                    n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, \
-                                    d_stats);                                                                          \
-    }
-    if (P.n_waves <= 4) GF_NA(4);
-    if (P.n_waves <= 8) GF_NA(8);
-    GF_NA(16);
-#undef GF_NA
+    constexpr int NW = 16;
+    if (T.d_identity)
+        return launch_one_workgroup(fit_fifo_chain_kernel<ALGO, NW, true>, NW, lds, stream, T, P.lds_slots_v2, n_apps, d_apps,
+                                    d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard);
+    return launch_one_workgroup(fit_fifo_chain_kernel<ALGO, NW, false>, NW, lds, stream, T, P.lds_slots_v2, n_apps, d_apps,
+                                d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard);
 }
 
 template <int ALGO>
 hipError_t launch_solo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps, NApp* d_napps,
                        const int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                       uint64_t half, int32_t* d_failed, ScanStats* d_stats, hipStream_t stream) {
+                       uint64_t half, int32_t* d_failed, const ChainCkpt& ck, ScanStats* d_stats, hipStream_t stream) {
     const size_t lds = fifo_solo_lds_bytes(P.lds_slots_solo, T.n_chunks);
-    constexpr int NW = 16;  // wavefront 0 walks the chain; all sixteen share the prologue and the epilogue
+    constexpr int NW = 16;  // wavefront 0 walks the chain; all sixteen share the prologue, the checkpoints and the epilogue
     const bool resident = P.lds_slots_solo >= T.n_slots;
 #define GF_SOLO(PR, RE)                                                                                                     \
     return launch_one_workgroup(fit_fifo_solo_kernel<ALGO, NW, PR, RE>, NW, lds, stream, T, NT, P.lds_slots_solo, n_apps,    \
-                                d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats)
+                                d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, ck, d_stats)
     if (d_stats != nullptr) {
         if (resident) GF_SOLO(true, true);
         GF_SOLO(true, false);
@@ -1722,45 +1668,31 @@ hipError_t launch_solo(const FifoPlan& P, const NodeTable& T, const NarrowTable&
 
 template <int ALGO>
 hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
-                            const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps, int32_t* d_wide_needed,
-                            gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half,
-                            int32_t* d_failed, ScanStats* d_stats, hipStream_t stream) {
+                            const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
+                            uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, uint64_t heads_lo, int32_t* d_failed,
+                            const ChainCkpt& ck, ScanStats* d_stats, hipStream_t stream) {
     hipError_t e = hipSuccess;
-    const bool fused = P.wide_fused && T.d_identity;
     const int32_t* guard = nullptr;
-    if (P.narrow || fused) {
-        if (P.narrow) {
-            e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
-            if (e != hipSuccess) return e;
-            // run heads of the tightly-pack fast path: "no head here"
-            if (ALGO == GF_ALGO_TIGHTLY_PACK && half > 1) {
-                e = hipMemsetAsync(d_scratch, 0xFF, (half - 1) * sizeof(uint32_t), stream);
-                if (e != hipSuccess) return e;
-            }
-            guard = d_wide_needed;
-        }
-        hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
-                           fused ? d_dev_apps : (DevApp*)nullptr, P.narrow ? d_napps : (NApp*)nullptr, NT.unit[0],
-                           NT.unit[1], NT.unit[2], d_wide_needed);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     if (P.narrow) {
-        if (P.solo)
-            e = launch_solo<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,
-                                  d_failed, d_stats, stream);
-        else
-            e = launch_narrow<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half,
-                                    d_failed, d_stats, stream);
+        e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
+        if (e != hipSuccess) return e;
+        // run heads of the tightly-pack fast path: "no head here"
+        if (ALGO == GF_ALGO_TIGHTLY_PACK && half > 1 + heads_lo) {
+            e = hipMemsetAsync(d_scratch + heads_lo, 0xFF, (half - 1 - heads_lo) * sizeof(uint32_t), stream);
+            if (e != hipSuccess) return e;
+        }
+        guard = d_wide_needed;
+        hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps, d_napps,
+                           NT.unit[0], NT.unit[1], NT.unit[2], d_wide_needed);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        e = launch_solo<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, ck,
+                              d_stats, stream);
         if (e != hipSuccess) return e;
     }
-    if (fused)
-        e = launch_fused<ALGO>(P, T, n_apps, d_dev_apps, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats,
-                               guard, stream);
-    else
-        e = launch_v2<ALGO>(P, T, n_apps, d_apps, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard,
-                            stream);
-    if (e != hipSuccess) return e;
+    if (P.wide) {
+        e = launch_v2<ALGO>(P, T, n_apps, d_apps, d_results, d_exec_nodes, d_scratch, half, d_failed, d_stats, guard, stream);
+        if (e != hipSuccess) return e;
+    }
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(expand_translate_kernel, grid, block, 0, stream, T.slot_node, n_apps, d_apps, d_results,
@@ -1770,17 +1702,19 @@ hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowT
 }  // namespace
 
 hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
-                           uint32_t n_apps, const gf_app* d_apps, DevApp* d_dev_apps, NApp* d_napps,
-                           int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                           uint64_t scratch_half, int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+                           uint32_t n_apps, const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed,
+                           gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
+                           uint64_t heads_lo, int32_t* d_chain_failed_at, const ChainCkpt& ckpt, ScanStats* d_stats,
+                           hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
+    if (!plan.narrow && !plan.wide) return hipErrorInvalidValue;
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        return launch_fifo_algo<GF_ALGO_TIGHTLY_PACK>(plan, table, ntable, n_apps, d_apps, d_dev_apps, d_napps,
-                                                      d_wide_needed, d_results, d_exec_nodes, d_scratch, scratch_half,
-                                                      d_chain_failed_at, d_stats, stream);
-    return launch_fifo_algo<GF_ALGO_DISTRIBUTE_EVENLY>(plan, table, ntable, n_apps, d_apps, d_dev_apps, d_napps,
-                                                       d_wide_needed, d_results, d_exec_nodes, d_scratch, scratch_half,
-                                                       d_chain_failed_at, d_stats, stream);
+        return launch_fifo_algo<GF_ALGO_TIGHTLY_PACK>(plan, table, ntable, n_apps, d_apps, d_napps, d_wide_needed, d_results,
+                                                      d_exec_nodes, d_scratch, scratch_half, heads_lo, d_chain_failed_at, ckpt,
+                                                      d_stats, stream);
+    return launch_fifo_algo<GF_ALGO_DISTRIBUTE_EVENLY>(plan, table, ntable, n_apps, d_apps, d_napps, d_wide_needed, d_results,
+                                                       d_exec_nodes, d_scratch, scratch_half, heads_lo, d_chain_failed_at, ckpt,
+                                                       d_stats, stream);
 }
 
 hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, const NodeTable& table,
@@ -1891,7 +1825,7 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
     hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
-                       (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
+                       d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
     // one wavefront per candidate view; the rest of the workgroup only helps with the prologue and shares every barrier and
@@ -1943,7 +1877,7 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
     if (d_capmat == nullptr) d_hist = nullptr;  // the histograms are patched together with the matrix
     // (no initialisation of d_hist: the row fill of a shape writes every bin of its histograms and first positions)
     hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
-                       (DevApp*)nullptr, d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
+                       d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_idx);
     if (zoned)

@@ -53,9 +53,10 @@ class BatchOut:
 class Context:
     """gf_ctx wrapper. Raises GangfitError on any negative return code — no silent fallback."""
 
-    def __init__(self, device: int = 0, devices=None):
+    def __init__(self, device: int = 0, devices=None, options=None):
         """devices: a list of device ids makes ONE context over several devices (gf_init with n_dev > 1: independent batches
-        of the plain packers are node-range sharded across them inside the library; an id may repeat)."""
+        of the plain packers are node-range sharded across them inside the library; an id may repeat).
+        options: {key: int} for gf_set_option (test switches: "fifo_generic", "lds_budget", "chain_cache", ...)."""
         self._lib = N.load()
         h = C.c_void_p()
         devs = [device] if devices is None else [int(d) for d in devices]
@@ -65,6 +66,17 @@ class Context:
             raise N.GangfitError(rc, "gf_init failed (no gfx950 device visible?)")
         self._h = h
         self.n_nodes = 0
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
+
+    def set_option(self, key: str, value: int):
+        self._check(self._lib.gf_set_option(self._h, key.encode(), int(value)))
+
+    def chain_cache_stats(self, reset: bool = False):
+        """(chains with the cache armed, chains resumed from a checkpoint, applications evaluated, applications skipped)"""
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self._lib.gf_chain_cache_stats(self._h, 1 if reset else 0, N.ptr(out)))
+        return tuple(int(v) for v in out)
 
     # -- lifecycle
     def close(self):

@@ -34,7 +34,7 @@ def test_header_symbols_are_all_exported(lib_path):
 
 def test_version_and_struct_layout(lib_path):
     lib = _native.load()
-    assert lib.gf_version() == 201
+    assert lib.gf_version() == 300
     # layout promised by the header: 64-byte app records, 16-byte results
     assert _native.APP_DTYPE.itemsize == 64 and _native.APP_DTYPE.fields["exec_off"][1] == 56
     assert _native.RESULT_DTYPE.itemsize == 16

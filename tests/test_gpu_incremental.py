@@ -1,0 +1,193 @@
+"""Incremental FIFO chains (gf_fit_batch resumes from the checkpoints of the previous chain when the queues share a prefix,
+include/gangfit.h "Incremental FIFO chains"): every answer must be the answer of a FULL replay by the literal oracle — results,
+placements, chain_failed_at and the residual table — whatever the cache did.  The reference replays every earlier driver
+on every Filter (internal/extender/resource.go:309-328); parity of FIFO replay itself is unpinned by reference tests (see
+oracle/gangfit_oracle.c header), these tests pin the resumed chain to the replayed one."""
+import numpy as np
+import pytest
+
+import gangfit
+from gangfit import workloads as wl
+from oracle import binding as ob
+from test_gpu_parity import _assert_same, _random_problem
+
+pytestmark = pytest.mark.gpu
+
+TIGHT, EVEN = gangfit.GF_ALGO_TIGHTLY_PACK, gangfit.GF_ALGO_DISTRIBUTE_EVENLY
+FIFO = gangfit.GF_MODE_FIFO_CHAIN
+
+
+def _check(ctx, algo, avail, D, X, drv, exe, k, flags, closed_form=False):
+    apps = gangfit.make_apps(drv, exe, k, flags)
+    gpu = ctx.fit_batch(FIFO, algo, apps)
+    ref = ob.fit_fifo_chain(algo, avail, ob.make_apps(drv, exe, k, flags), D, X, closed_form=closed_form)
+    assert gpu.failed_at == ref.failed_at
+    _assert_same(gpu, ref, apps)
+    assert np.array_equal(ctx.residual(), ref.avail_after)
+    return ref
+
+
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_growing_queue_resumes_and_matches_full_replay(algo):
+    """Creation-order heads on an unchanged snapshot: driver j + 1's chain is driver j's chain plus one application.  Every
+    chain length from 1 to 140 (all staging / checkpoint boundaries: 31 | 32 | 33, 63 | 64 | 65, ...)."""
+    rng = np.random.default_rng(31 + algo)
+    avail, D, X, drv, exe, k = _random_problem(rng, 900, 140, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 25).astype(np.int32)
+    k[::7] = 0
+    flags = np.ones(140, dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+        ctx.chain_cache_stats(reset=True)
+        for n in range(1, 141):
+            _check(ctx, algo, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])
+        chains, resumed, evaluated, skipped = ctx.chain_cache_stats()
+        assert chains == 140
+        assert resumed == 140 - 33  # chains of 34 and more applications find checkpoint 1 (the table before application 32)
+        assert skipped == sum(((n - 2) // 32) * 32 for n in range(2, 141))
+        assert evaluated + skipped == sum(range(1, 141))
+
+
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_headline_creation_order_heads(algo):
+    """10 000 nodes, the headline queue: Filters for drivers 900 .. 999 in creation order (the regime in which a thousand
+    drivers are pending at all), every one against the oracle's full replay; then the rotated heads of bench.py (a cold
+    chain each) in between to show that a miss is a plain replay."""
+    w = wl.headline(10000, 1000)
+    s = w.snapshot
+    flags = np.ones(len(w.k), dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(s.avail, s.sched)
+        ctx.set_orders(s.driver_order, s.exec_order)
+        ctx.chain_cache_stats(reset=True)
+        for n in list(range(900, 1001, 7)) + [1000, 1000, 999]:
+            _check(ctx, algo, s.avail, s.driver_order, s.exec_order, w.drv[:n], w.exe[:n], w.k[:n], flags[:n], closed_form=True)
+        chains, resumed, evaluated, skipped = ctx.chain_cache_stats()
+        assert resumed == chains - 1 and skipped > 5 * evaluated
+        for r in (1, 2):
+            _check(ctx, algo, s.avail, s.driver_order, s.exec_order, np.roll(w.drv, -r, axis=0), np.roll(w.exe, -r, axis=0),
+                   np.roll(w.k, -r), flags, closed_form=True)
+        assert ctx.chain_cache_stats()[1] == resumed  # rotated queues share no prefix
+
+
+def test_divergence_in_the_middle_and_shrinking_queue():
+    rng = np.random.default_rng(5)
+    avail, D, X, drv, exe, k = _random_problem(rng, 2000, 200, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 30).astype(np.int32)
+    flags = np.ones(200, dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+        _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+        ctx.chain_cache_stats(reset=True)
+        for pos in (150, 70, 64, 63, 32, 31, 0, 199, 198):
+            drv = drv.copy()
+            drv[pos] = (drv[pos] + 1) % 9  # another driver request at `pos`: everything from the checkpoint before it replays
+            _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+        st = ctx.chain_cache_stats()
+        assert st[0] == 9 and st[1] == 7  # pos 31 and 0 leave no checkpoint in the common prefix
+        assert st[3] == 128 + 64 + 64 + 32 + 32 + 192 + 192
+        for n in (120, 64, 65, 33, 200):  # a driver was scheduled / deleted: shorter queues, then the long one again
+            _check(ctx, TIGHT, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])
+
+
+def test_aborting_chain_resumes_and_aborts_again():
+    """A non-skippable earlier driver that does not fit ends every later Filter with failure-earlier-driver
+    (resource.go:249-251): the resumed chain must abort at the same application and report the rest as not evaluated."""
+    rng = np.random.default_rng(8)
+    avail, D, X, drv, exe, k = _random_problem(rng, 700, 150, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 20).astype(np.int32)
+    flags = np.ones(150, dtype=np.uint32)
+    flags[100] = 0
+    exe[100] = (10 ** 6, 10 ** 6, 0)  # nothing hosts this executor
+    k[100] = 3
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+        for n in (90, 100, 101, 102, 130, 150):
+            ref = _check(ctx, TIGHT, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])
+            assert ref.failed_at == (100 if n > 101 else -1)
+        flags[100] = 1  # the driver is young enough to be skipped after all (resource.go:264-270): the chain goes on
+        _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+
+
+def test_every_install_drops_the_cache():
+    rng = np.random.default_rng(13)
+    avail, D, X, drv, exe, k = _random_problem(rng, 1200, 100, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 20).astype(np.int32)
+    flags = np.ones(100, dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+        _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+        _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+        assert ctx.chain_cache_stats(reset=True)[1] == 1
+        avail2 = avail.copy()
+        avail2[D[D < len(avail)][:40]] //= 2  # a reservation landed on the front of the order
+        ctx.set_snapshot(avail2)
+        ctx.set_orders(D, X)
+        _check(ctx, TIGHT, avail2, D, X, drv, exe, k, flags)  # same queue, new snapshot: replay
+        assert ctx.chain_cache_stats(reset=True)[1] == 0
+        _check(ctx, EVEN, avail2, D, X, drv, exe, k, flags)   # same queue, another packer: replay
+        assert ctx.chain_cache_stats(reset=True)[1] == 0
+        X2 = X[::-1].copy()
+        ctx.set_orders(X2, X2)
+        _check(ctx, EVEN, avail2, X2, X2, drv, exe, k, flags)  # new orders: replay
+        _check(ctx, EVEN, avail2, X2, X2, drv, exe, k, flags)
+        assert ctx.chain_cache_stats(reset=True)[1] == 1
+        ctx.set_option("chain_cache", 0)
+        _check(ctx, EVEN, avail2, X2, X2, drv, exe, k, flags)
+        assert ctx.chain_cache_stats()[0] == 0
+
+
+def test_finer_request_changes_the_units_and_replays():
+    """The checkpoints are scaled in the chain's units (gcd of the table's units and every request of the queue): a new
+    application with a finer request changes them, and the chain replays in the new units."""
+    rng = np.random.default_rng(21)
+    avail, D, X, drv, exe, k = _random_problem(rng, 800, 90, tight_cluster=False, layout="merged")
+    avail = avail * 8
+    drv, exe = drv * 8, np.maximum(exe, 1) * 8
+    k = np.minimum(k, 20).astype(np.int32)
+    flags = np.ones(90, dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+        _check(ctx, TIGHT, avail, D, X, drv[:80], exe[:80], k[:80], flags[:80])
+        ctx.chain_cache_stats(reset=True)
+        _check(ctx, TIGHT, avail, D, X, drv[:85], exe[:85], k[:85], flags[:85])
+        assert ctx.chain_cache_stats(reset=True)[1] == 1
+        drv[87] = (4, 8, 0)  # half the unit
+        _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+        assert ctx.chain_cache_stats(reset=True)[1] == 0
+        _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
+        assert ctx.chain_cache_stats(reset=True)[1] == 1
+
+
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_resume_with_a_global_table_tail(algo):
+    """Tables larger than the LDS front: the checkpoint is LDS blocks + the global tail (24 000 nodes; and a small LDS
+    budget on 3 000 nodes so that most of the table is tail)."""
+    w = wl.headline(24000, 300)
+    s = w.snapshot
+    flags = np.ones(len(w.k), dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(s.avail, s.sched)
+        ctx.set_orders(s.driver_order, s.exec_order)
+        for n in (200, 201, 260, 300, 299):
+            _check(ctx, algo, s.avail, s.driver_order, s.exec_order, w.drv[:n], w.exe[:n], w.k[:n], flags[:n], closed_form=True)
+        assert ctx.chain_cache_stats()[1] == 4
+    rng = np.random.default_rng(77 + algo)
+    avail, D, X, drv, exe, k = _random_problem(rng, 3000, 160, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 40).astype(np.int32)
+    flags = (rng.random(160) < 0.97).astype(np.uint32)
+    with gangfit.Context(0, options={"lds_budget": 24000}) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+        for n in (100, 101, 130, 160, 129):
+            _check(ctx, algo, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])

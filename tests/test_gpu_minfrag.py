@@ -164,8 +164,8 @@ def test_headline_size(gf_ctx):
         assert ref.results["has_capacity"].mean() > 0.5
 
 
-@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "60000"},
-                                 {"GANGFIT_MINFRAG_MATRIX": "0"}, {"GANGFIT_MINFRAG_HIST": "0"}, {"GANGFIT_LDS_BUDGET": "30000"}],
+@pytest.mark.parametrize("env", [{}, {"fifo_generic": 1}, {"lds_budget": 60000},
+                                 {"minfrag_matrix": 0}, {"minfrag_hist": 0}, {"lds_budget": 30000}],
                          ids=["lds-chain", "generic-chain", "lds-chain-global-tail", "lds-chain-no-capacity-matrix",
                               "lds-chain-block-passes", "lds-chain-few-index-rows"])
 @pytest.mark.parametrize("algo", [MF, SAZMF])
@@ -173,18 +173,7 @@ def test_fifo_chain_kernel_variants(algo, env):
     """The block-cooperative LDS chain (gangfit_fifo_minfrag.inc), the generic global-memory chain and the hybrid
     LDS/global table on the same problems: gangs that need one node, several capacity levels, and more than 64 nodes
     (spilled run lists); a request without a scaled form forces the wide fallback."""
-    import os
-
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        ctx = gangfit.Context(0)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    ctx = gangfit.Context(0, options=env)
     oalgo = ob.ALGO_MINIMAL_FRAGMENTATION if algo == MF else ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION
     rng = np.random.default_rng(77 + algo)
     try:
@@ -207,25 +196,14 @@ def test_fifo_chain_kernel_variants(algo, env):
         ctx.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"GANGFIT_MINFRAG_HIST": "0"}], ids=["histograms", "block-passes"])
+@pytest.mark.parametrize("env", [{}, {"minfrag_hist": 0}], ids=["histograms", "block-passes"])
 @pytest.mark.parametrize("algo", [MF, SAZMF])
 def test_fifo_chain_histogram_path(algo, env):
     """What the histogram path of gangfit_fifo_minfrag.inc has to get right: the AZ-major priority order of the reference
     (zones are contiguous ranges), a handful of templates (rows and histograms reused and patched across hundreds of commits),
     tiny executor requests next to them (capacities of 256 and more: those shapes keep the block-cooperative passes, in the
     same chain), drivers that share a node with their executors, level walks over many levels and gangs of several hundred."""
-    import os
-
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        ctx = gangfit.Context(0)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    ctx = gangfit.Context(0, options=env)
     oalgo = ob.ALGO_MINIMAL_FRAGMENTATION if algo == MF else ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION
     rng = np.random.default_rng(4242 + algo)
     try:

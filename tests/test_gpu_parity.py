@@ -152,33 +152,19 @@ def test_fifo_chain_random(gf_ctx, algo, n, layout):
         assert np.array_equal(gf_ctx.residual(), ref.avail_after)
 
 
-_CHAIN_VARIANTS = [{}, {"GANGFIT_FIFO_SOLO": "0"}, {"GANGFIT_LDS_BUDGET": "24000"},
-                   {"GANGFIT_FIFO_SOLO": "0", "GANGFIT_LDS_BUDGET": "24000"}, {"GANGFIT_FIFO_KERNEL": "fused"},
-                   {"GANGFIT_FIFO_KERNEL": "v2"}]
-_CHAIN_IDS = ["solo", "block-cooperative", "solo-global-tail", "block-cooperative-global-tail", "wide-fused", "wide-v2"]
+_CHAIN_VARIANTS = [{}, {"lds_budget": 24000}, {"fifo_generic": 1}, {"chain_cache": 0}]
+_CHAIN_IDS = ["solo", "solo-global-tail", "wide-v2", "solo-no-chain-cache"]
 
 
-def _ctx_with_env(env):
-    import os
-
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return gangfit.Context(0)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def _ctx_with_env(options):
+    return gangfit.Context(0, options=options)
 
 
 @pytest.mark.parametrize("env", _CHAIN_VARIANTS, ids=_CHAIN_IDS)
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
 def test_fifo_chain_kernel_variants(algo, env):
     """Every chain kernel of the plain packers on the same problems (merged layout): the one-controlling-wavefront chain
-    (gangfit_fifo_solo.inc; whole table in LDS, and with a global-memory tail), the block-cooperative narrow kernel,
-    the wide kernels.  Cases: few request shapes (exact chunk index), more than 64 distinct shapes (chunk-maxima path),
+    (gangfit_fifo_solo.inc; whole table in LDS, and with a global-memory tail) and the wide kernel.  Cases: few request shapes (exact chunk index), more than 64 distinct shapes (chunk-maxima path),
     a depleting cluster where most of the queue cannot fit (capacity bound learnt per shape, driver fallback, several
     distribute-evenly passes), a request without a scaled form (wide fallback)."""
     ctx = _ctx_with_env(env)
@@ -218,7 +204,7 @@ def test_fifo_chain_kernel_variants(algo, env):
         ctx.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_SOLO": "0"}], ids=["solo", "block-cooperative"])
+@pytest.mark.parametrize("env", [{}, {"chain_cache": 0}], ids=["solo", "solo-no-chain-cache"])
 @pytest.mark.parametrize("algo", [TIGHT, EVEN])
 def test_fifo_chain_beyond_the_lds_front(algo, env):
     """24 000 nodes: the table does not fit the LDS front (global tail) and a shape's index row has more than four words

@@ -206,24 +206,13 @@ def test_zoned_fifo_chain_headline_shape(gf_ctx):
     assert np.array_equal(gf_ctx.residual(), ref.avail_after)
 
 
-@pytest.mark.parametrize("env", [{}, {"GANGFIT_FIFO_ZONED": "generic"}, {"GANGFIT_LDS_BUDGET": "48000"}],
+@pytest.mark.parametrize("env", [{}, {"fifo_generic": 1}, {"lds_budget": 48000}],
                          ids=["lds-chain", "generic-chain", "lds-chain-global-tail"])
 @pytest.mark.parametrize("algo", [SAZ, AZA])
 def test_zoned_fifo_chain_kernel_variants(algo, env):
     """The LDS-resident chain of the zone-aware tightly-pack packers (gangfit_fifo_zoned.inc), its global-memory
     fallback, and the hybrid LDS/global table, with gangs large enough to spill the in-LDS run lists (> 64 nodes)."""
-    import os
-
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        ctx = gangfit.Context(0)
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    ctx = gangfit.Context(0, options=env)
     rng = np.random.default_rng(2024 + algo)
     try:
         for rep in range(4):
