@@ -462,28 +462,75 @@ int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t
     return GF_OK;
 }
 
-// The LDS-resident minimal-fragmentation chain when the layout is merged, the table has a narrow form and the tables fit;
-// *run_if is then set to the flag the generic kernel must test (it only runs when a request had no scaled form).
-int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint32_t nz, uint32_t n_apps, const gf_app* h_apps,
-                    const gf_app* d_apps,
-                    gf_result* d_results, uint32_t* d_exec_nodes, uint64_t half, int32_t* d_failed, hipStream_t stream,
-                    const int32_t** run_if) {
-    *run_if = nullptr;
-    if (!(ctx->merged && ctx->narrow_ok && !ctx->fifo_generic) || (zoned && (nz == 0 || nz > 16))) return GF_OK;
+// How one FIFO chain of gf_fit_batch uses the chain cache (decided by chain_plan before the launch).
+struct ChainRun {
+    uint32_t a_begin = 0;        // first application this launch evaluates (a multiple of 1 << shift); 0 = from the snapshot
+    bool record = false;         // dump checkpoints into ctx->chain.d_ckpt
+    bool narrow_proven = false;  // every request has a scaled form (checked on the host): the wide twin is not launched
+};
+
+// The checkpoint arguments of a chain kernel and the table it starts from.
+gangfit::ChainCkpt chain_ckpt_args(gf_ctx* ctx, const ChainRun* run, const int32_t** restore) {
+    gangfit::ChainCkpt ck{nullptr, run ? run->a_begin : 0u, ctx->chain.shift};
+    *restore = nullptr;
+    if (run != nullptr && (run->record || run->a_begin > 0)) {
+        ck.base = ctx->chain.d_ckpt.ptr;
+        if (run->a_begin > 0) *restore = ck.base + (size_t)((run->a_begin >> ck.shift) - 1u) * ctx->chain.slot_words;
+    }
+    return ck;
+}
+
+// Geometry of the LDS-resident chains of the zone-aware tightly-pack packers (gangfit_fifo_zoned.inc) and of the
+// minimal-fragmentation packers (gangfit_fifo_minfrag.inc); false = the generic global-memory chain serves.
+bool zoned_lds_geometry(const gf_ctx* ctx, bool az_aware, uint32_t* n_shapes, uint32_t* lds_slots) {
+    const uint32_t nz = ctx->n_zones;
+    if (!(ctx->merged && ctx->narrow_ok && !ctx->fifo_generic) || nz + (az_aware ? 1u : 0u) > 16) return false;
+    // as many shape-index rows as LDS allows next to the masks (64 down to 4), then as much of the table as fits
+    uint32_t ns = 64;
+    const uint32_t n_cand = nz + (az_aware ? 1u : 0u);
+    while (ns > 4 && gangfit::fifo_zoned_lds_bytes(64, ctx->n_chunks, nz, n_cand, ns) > ctx->lds_budget) ns /= 2;
+    const size_t fixed = gangfit::fifo_zoned_lds_bytes(0, ctx->n_chunks, nz, n_cand, ns);
+    if (ctx->lds_budget <= fixed + 12 * 64) return false;
+    uint32_t slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
+    *lds_slots = slots >= ctx->n_slots ? ctx->n_slots : slots / 64 * 64;
+    *n_shapes = ns;
+    return true;
+}
+bool minfrag_lds_geometry(const gf_ctx* ctx, bool zoned, uint32_t* n_idx, uint32_t* lds_slots) {
+    const uint32_t nz = ctx->n_zones;
+    if (!(ctx->merged && ctx->narrow_ok && !ctx->fifo_generic) || (zoned && (nz == 0 || nz > 16))) return false;
     const uint32_t zviews = zoned ? nz : 0u;
     // 64 shape ids per role (rows of the capacity matrix, histograms); as many of them as LDS allows next to the masks also
     // get chunk-index rows (64 down to 0 — the histogram path does without), then as much of the table as fits
+    uint32_t ni = 64;
+    while (ni > 0 && gangfit::fifo_minfrag_lds_bytes(64, ctx->n_chunks, zviews, ni) > ctx->lds_budget) ni /= 2;
+    const size_t fixed = gangfit::fifo_minfrag_lds_bytes(0, ctx->n_chunks, zviews, ni);
+    if (ctx->lds_budget <= fixed + 12 * 64) return false;
+    uint32_t slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
+    *lds_slots = slots >= ctx->n_slots ? ctx->n_slots : slots / 64 * 64;
+    *n_idx = ni;
+    return true;
+}
+
+// The LDS-resident minimal-fragmentation chain when the layout is merged, the table has a narrow form and the tables fit;
+// *run_if is then set to the flag the generic kernel must test (it only runs when a request had no scaled form) and
+// *served to true.  d_apps / d_results: the arrays of the whole queue (a resumed chain is launched on their tail).
+int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint32_t n_apps, const gf_app* h_apps,
+                    const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint64_t half, int32_t* d_failed,
+                    hipStream_t stream, const ChainRun* run, const int32_t** run_if, bool* served) {
+    *run_if = nullptr;
+    *served = false;
+    uint32_t n_idx = 0, lds_slots = 0;
+    if (!minfrag_lds_geometry(ctx, zoned, &n_idx, &lds_slots)) return GF_OK;
+    const uint32_t nz = ctx->n_zones;
+    const uint32_t zviews = zoned ? nz : 0u;
     const uint32_t n_shapes = 64;
-    uint32_t n_idx = 64;
-    while (n_idx > 0 && gangfit::fifo_minfrag_lds_bytes(64, ctx->n_chunks, zviews, n_idx) > ctx->lds_budget) n_idx /= 2;
-    const size_t fixed = gangfit::fifo_minfrag_lds_bytes(0, ctx->n_chunks, zviews, n_idx);
-    if (ctx->lds_budget <= fixed + 12 * 64) return GF_OK;
-    uint32_t lds_slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
-    lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
     GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
     GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
     gangfit::NarrowTable nt{};
-    if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt); nrc != GF_OK) return nrc;
+    const int32_t* restore = nullptr;
+    const gangfit::ChainCkpt ck = chain_ckpt_args(ctx, run, &restore);
+    if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
     // capacity matrix: one int32 per (request shape, slot); skipped (capacities recomputed per pass) beyond 1 GiB
     int32_t* capmat = nullptr;
     if ((uint64_t)n_shapes * ctx->n_slots * sizeof(int32_t) <= (UINT64_C(1) << 30) && ctx->fifo_minfrag_matrix) {
@@ -495,17 +542,19 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
         GF_HIP(ctx, ctx->d_mfhist.reserve(gangfit::fifo_minfrag_hist_words(zviews, n_shapes)));
         hist = ctx->d_mfhist.ptr;
     }
+    const uint32_t a0 = ck.a_base;
     GF_HIP(ctx, gangfit::launch_fit_fifo_minfrag_lds(zoned, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr, lds_slots,
-                                                     n_shapes, n_idx, n_apps, d_apps, ctx->d_napps.ptr, ctx->d_wide_needed.ptr,
-                                                     d_results, d_exec_nodes, ctx->d_zexec.ptr, half, d_failed, capmat, hist,
-                                                     ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
+                                                     n_shapes, n_idx, n_apps - a0, d_apps + a0, ctx->d_napps.ptr + a0,
+                                                     ctx->d_wide_needed.ptr, d_results + a0, d_exec_nodes, ctx->d_zexec.ptr, half,
+                                                     d_failed, capmat, hist, ck, ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
     *run_if = ctx->d_wide_needed.ptr;
+    *served = true;
     return GF_OK;
 }
 
 int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, const gf_app* d_apps,
                  gf_result* d_results,
-                 uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream) {
+                 uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream, const ChainRun* run) {
     if (!ctx->have_sched)
         return fail(ctx, GF_ERR_STATE, "zone-aware packers compare packing efficiencies: gf_snapshot_set needs the schedulable columns");
     const int inner = algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ? GF_ALGO_MINIMAL_FRAGMENTATION : GF_ALGO_TIGHTLY_PACK;
@@ -524,41 +573,43 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     if (mode == GF_MODE_FIFO_CHAIN) {
         if (nz + 1 > 64) return fail(ctx, GF_ERR_UNSUPPORTED, "more than 63 zones in a FIFO chain");
         if (ctx->cnt_rows < 16) return fail(ctx, GF_ERR_HIP, "multiplicity scratch too small");
-        // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303)
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
-                                   hipMemcpyDeviceToDevice, stream));
+        const bool proven = run != nullptr && run->narrow_proven;  // the LDS chain serves for certain: no generic twin
+        // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303);
+        // the LDS chains rewrite every real slot of the wide working table in their epilogue
+        if (!proven)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                       hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
         const bool az_aware = algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK;
         const int32_t* run_if = nullptr;
+        bool served = false;
         // fast path: tightly-pack family, merged layout, narrow table, every candidate view gets its own wavefront
-        if (inner == GF_ALGO_TIGHTLY_PACK && ctx->merged && ctx->narrow_ok && !ctx->fifo_generic && nz + (az_aware ? 1u : 0u) <= 16) {
-            // as many shape-index rows as LDS allows next to the masks (64 down to 4), then as much of the table as fits
-            uint32_t n_shapes = 64;
-            const uint32_t n_cand = nz + (az_aware ? 1u : 0u);
-            while (n_shapes > 4 && gangfit::fifo_zoned_lds_bytes(64, ctx->n_chunks, nz, n_cand, n_shapes) > ctx->lds_budget) n_shapes /= 2;
-            const size_t fixed = gangfit::fifo_zoned_lds_bytes(0, ctx->n_chunks, nz, n_cand, n_shapes);
-            if (ctx->lds_budget > fixed + 12 * 64) {
-                uint32_t lds_slots = (uint32_t)((ctx->lds_budget - fixed) / 12);
-                lds_slots = lds_slots >= ctx->n_slots ? ctx->n_slots : lds_slots / 64 * 64;
-                GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
-                GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
-                gangfit::NarrowTable nt{};
-                if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt); nrc != GF_OK) return nrc;
-                GF_HIP(ctx, gangfit::launch_fit_fifo_zoned_lds(az_aware, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr,
-                                                               lds_slots, n_shapes, n_apps, d_apps, ctx->d_napps.ptr,
-                                                               ctx->d_wide_needed.ptr, d_results, d_exec_nodes,
-                                                               ctx->d_zexec.ptr, half, d_failed,
-                                                               ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
-                run_if = ctx->d_wide_needed.ptr;  // the generic kernel below only runs when a request had no scaled form
-                zb.zexec = ctx->d_zexec.ptr;
-            }
+        uint32_t n_shapes = 0, lds_slots = 0;
+        if (inner == GF_ALGO_TIGHTLY_PACK && zoned_lds_geometry(ctx, az_aware, &n_shapes, &lds_slots)) {
+            GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
+            GF_HIP(ctx, ctx->d_zexec.reserve(32 * half));
+            gangfit::NarrowTable nt{};
+            const int32_t* restore = nullptr;
+            const gangfit::ChainCkpt ck = chain_ckpt_args(ctx, run, &restore);
+            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
+            const uint32_t a0 = ck.a_base;
+            GF_HIP(ctx, gangfit::launch_fit_fifo_zoned_lds(az_aware, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr,
+                                                           lds_slots, n_shapes, n_apps - a0, d_apps + a0, ctx->d_napps.ptr + a0,
+                                                           ctx->d_wide_needed.ptr, d_results + a0, d_exec_nodes,
+                                                           ctx->d_zexec.ptr, half, d_failed, ck,
+                                                           ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
+            run_if = ctx->d_wide_needed.ptr;  // the generic kernel below only runs when a request had no scaled form
+            zb.zexec = ctx->d_zexec.ptr;
+            served = true;
         }
         if (inner == GF_ALGO_MINIMAL_FRAGMENTATION) {
-            const int rc2 = try_minfrag_lds(ctx, true, zt, nz, n_apps, h_apps, d_apps, d_results, d_exec_nodes, half, d_failed,
-                                            stream, &run_if);
+            const int rc2 = try_minfrag_lds(ctx, true, zt, n_apps, h_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream,
+                                            run, &run_if, &served);
             if (rc2 != GF_OK) return rc2;
             if (run_if) zb.zexec = ctx->d_zexec.ptr;
         }
+        if (served && proven) return GF_OK;
+        if (proven) return fail(ctx, GF_ERR_HIP, "chain plan and launch disagree about the LDS chain");
         GF_HIP(ctx, gangfit::launch_fit_fifo_generic(inner, true, az_aware,
                                                      reserves_executors(algo), make_table(ctx, ctx->d_work.ptr), zt,
                                                      ctx->d_sched.ptr, zb, n_apps, d_apps, d_results, d_exec_nodes,
@@ -572,21 +623,27 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     return GF_OK;
 }
 
-// How one FIFO chain of gf_fit_batch uses the chain cache (decided by chain_plan before the launch).
-struct ChainRun {
-    uint32_t a_begin = 0;        // first application this launch evaluates (a multiple of 1 << shift); 0 = from the snapshot
-    bool record = false;         // dump checkpoints into ctx->chain.d_ckpt
-    bool narrow_proven = false;  // every request has a scaled form (checked on the host): the wide twin is not launched
-};
-
-// Which chains resume: the plain packers on the solo kernel (merged layout, narrow table) with every request in scaled
-// form.  Returns false when the chain cache is not used for this call (run stays {0, false, false}).
+// Which chains resume: every packer, when its LDS-resident chain kernel serves (merged layout, narrow table, the kernel's
+// tables fit) and every request has a scaled form.  Returns false when the chain cache is not used for this call (run stays {0, false, false}).
 bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, ChainRun* run) {
     *run = ChainRun{};
     gf_ctx::ChainCache& C = ctx->chain;
     if (mode != GF_MODE_FIFO_CHAIN || !ctx->chain_cache_on || ctx->stats_on || !ctx->have_orders) return false;
-    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY) return false;
     if (!(ctx->merged && ctx->narrow_ok) || ctx->fifo_generic) return false;
+    {  // the LDS-resident chain kernel of this packer must be the one that serves (they dump and restore the checkpoints)
+        uint32_t g0 = 0, g1 = 0;
+        bool lds_chain = false;
+        switch (algo) {
+        case GF_ALGO_TIGHTLY_PACK:
+        case GF_ALGO_DISTRIBUTE_EVENLY: lds_chain = true; break;
+        case GF_ALGO_SINGLE_AZ_TIGHTLY_PACK: lds_chain = ctx->have_sched && zoned_lds_geometry(ctx, false, &g0, &g1); break;
+        case GF_ALGO_AZ_AWARE_TIGHTLY_PACK: lds_chain = ctx->have_sched && zoned_lds_geometry(ctx, true, &g0, &g1); break;
+        case GF_ALGO_MINIMAL_FRAGMENTATION: lds_chain = minfrag_lds_geometry(ctx, false, &g0, &g1); break;
+        case GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION: lds_chain = ctx->have_sched && minfrag_lds_geometry(ctx, true, &g0, &g1); break;
+        default: break;
+        }
+        if (!lds_chain) return false;
+    }
     int64_t eff[3];
     int32_t factor[3];
     bool proven = false;
@@ -673,21 +730,27 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     if (is_zone_algo(algo)) {
         if (mode != GF_MODE_INDEPENDENT && mode != GF_MODE_FIFO_CHAIN)
             return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
-        return launch_zoned(ctx, mode, algo, n_apps, h_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_failed, stream);
+        return launch_zoned(ctx, mode, algo, n_apps, h_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_failed, stream, run);
     }
     if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY && algo != GF_ALGO_MINIMAL_FRAGMENTATION)
         return fail(ctx, GF_ERR_UNSUPPORTED, "gf_algo %d is not served by the device path", (int)algo);
     if (algo == GF_ALGO_MINIMAL_FRAGMENTATION && mode == GF_MODE_FIFO_CHAIN) {
-        // the generic chain kernel (one candidate view, one wavefront) against the working table in global memory
+        // the LDS chain; else (and as its guarded twin) the generic chain kernel: one candidate view, one wavefront, against
+        // the working table in global memory
+        const bool proven = run != nullptr && run->narrow_proven;
         GF_HIP(ctx, ctx->d_zexec.reserve(half));
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
-                                   hipMemcpyDeviceToDevice, stream));
+        if (!proven)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
+                                       hipMemcpyDeviceToDevice, stream));
         ctx->work_valid = true;
         gangfit::ZoneTable zt{nullptr, nullptr, 0, 0};
         const int32_t* run_if = nullptr;
-        const int rc2 = try_minfrag_lds(ctx, false, zt, 0, n_apps, h_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream,
-                                        &run_if);
+        bool served = false;
+        const int rc2 = try_minfrag_lds(ctx, false, zt, n_apps, h_apps, d_apps, d_results, d_exec_nodes, half, d_failed, stream, run,
+                                        &run_if, &served);
         if (rc2 != GF_OK) return rc2;
+        if (served && proven) return GF_OK;
+        if (proven) return fail(ctx, GF_ERR_HIP, "chain plan and launch disagree about the LDS chain");
         gangfit::ZoneBuffers zb{nullptr, ctx->d_zexec.ptr, half, nullptr, nullptr, 0, nullptr};
         GF_HIP(ctx, gangfit::launch_fit_fifo_generic(GF_ALGO_MINIMAL_FRAGMENTATION, false, false, false,
                                                      make_table(ctx, ctx->d_work.ptr), zt, nullptr, zb, n_apps, d_apps,
@@ -728,14 +791,11 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
             plan.lds_slots_solo = (uint32_t)((fit < whole ? fit : whole) * 64u);
         }
         gangfit::NarrowTable nt{};
-        gangfit::ChainCkpt ck{nullptr, a_begin, ctx->chain.shift};
+        gangfit::ChainCkpt ck{nullptr, 0u, ctx->chain.shift};
         if (plan.narrow) {
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
             const int32_t* restore = nullptr;
-            if (run != nullptr && (run->record || a_begin > 0)) {
-                ck.base = ctx->chain.d_ckpt.ptr;
-                if (a_begin > 0) restore = ck.base + (size_t)((a_begin >> ck.shift) - 1u) * ctx->chain.slot_words;
-            }
+            ck = chain_ckpt_args(ctx, run, &restore);
             if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
         }
         // a resumed chain is launched on the tail of the queue: exec_off is absolute, so offset pointers are all it takes

@@ -183,7 +183,7 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
                                      const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                      const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                      uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                     int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream);
+                                     int32_t* d_chain_failed_at, const ChainCkpt& ckpt, ScanStats* d_stats, hipStream_t stream);
 
 // LDS-resident, block-cooperative chain for minimal-fragmentation, plain (zoned = false) or single-AZ
 // (gangfit_fifo_minfrag.inc); same contract as launch_fit_fifo_zoned_lds.
@@ -198,7 +198,7 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
                                        int32_t* d_chain_failed_at, int32_t* d_capmat /* n_shapes x n_slots, nullable */,
                                        int32_t* d_hist /* fifo_minfrag_hist_words, nullable: no histogram path */,
-                                       ScanStats* d_stats /* nullable */, hipStream_t stream);
+                                       const ChainCkpt& ckpt, ScanStats* d_stats /* nullable */, hipStream_t stream);
 
 // ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
 // (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.

@@ -1819,7 +1819,7 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
                                      const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                      const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                      uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                     int32_t* d_chain_failed_at, ScanStats* d_stats, hipStream_t stream) {
+                                     int32_t* d_chain_failed_at, const ChainCkpt& ck, ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     if (zones.n_zones + (az_aware ? 1u : 0u) > 16 || !table.d_identity) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
@@ -1837,7 +1837,7 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
 #define GF_ZL(AZ, NWV)                                                                                                      \
     e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<AZ, NWV>, NWV, lds, stream, table, ntable, zones, d_sched, lds_slots, \
                              n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,      \
-                             d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_stats)
+                             d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, ck, d_stats)
     if (az_aware) {
         if (wg_waves == 4) GF_ZL(true, 4);
         else if (wg_waves == 8) GF_ZL(true, 8);
@@ -1867,8 +1867,8 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                        uint32_t n_apps,
                                        const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                       int32_t* d_chain_failed_at, int32_t* d_capmat, int32_t* d_hist, ScanStats* d_stats,
-                                       hipStream_t stream) {
+                                       int32_t* d_chain_failed_at, int32_t* d_capmat, int32_t* d_hist, const ChainCkpt& ck,
+                                       ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     if ((zoned && zones.n_zones > 16) || !table.d_identity || n_shapes == 0 || n_shapes > kZShapes || n_idx > n_shapes)
         return hipErrorInvalidValue;
@@ -1883,11 +1883,11 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
     if (zoned)
         e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
                                  n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, d_stats);
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats);
     else
         e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<false>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
                                  n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, d_stats);
+                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);

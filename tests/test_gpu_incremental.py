@@ -191,3 +191,78 @@ def test_resume_with_a_global_table_tail(algo):
         ctx.set_orders(D, X)
         for n in (100, 101, 130, 160, 129):
             _check(ctx, algo, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])
+
+
+SAZ, AZA = gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.GF_ALGO_AZ_AWARE_TIGHTLY_PACK
+MF, SAZMF = gangfit.GF_ALGO_MINIMAL_FRAGMENTATION, gangfit.GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION
+O_ALGO = {SAZ: ob.ALGO_SINGLE_AZ_TIGHTLY_PACK, AZA: ob.ALGO_AZ_AWARE_TIGHTLY_PACK, MF: ob.ALGO_MINIMAL_FRAGMENTATION,
+          SAZMF: ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION}
+
+
+def _zcheck(ctx, algo, avail, sched, zone, D, X, drv, exe, k, flags):
+    apps = gangfit.make_apps(drv, exe, k, flags)
+    gpu = ctx.fit_batch(FIFO, algo, apps)
+    ref = ob.fit_fifo_chain(O_ALGO[algo], avail, ob.make_apps(drv, exe, k, flags), D, X, closed_form=True, sched=sched, zone=zone)
+    assert gpu.failed_at == ref.failed_at
+    _assert_same(gpu, ref, apps)
+    assert np.array_equal(ctx.residual(), ref.avail_after)
+    return ref
+
+
+@pytest.mark.parametrize("options", [{}, {"lds_budget": 60000}], ids=["lds-resident", "global-tail"])
+@pytest.mark.parametrize("algo", [SAZ, AZA, MF, SAZMF])
+def test_zone_aware_and_minfrag_chains_resume(algo, options):
+    """The chains of the zone-aware and minimal-fragmentation packers (gangfit_fifo_zoned.inc, gangfit_fifo_minfrag.inc)
+    dump the same checkpoints: growing queues, a divergence in the middle, an aborting driver, a shrinking queue — every
+    answer against the oracle's full replay (efficiency comparisons of chooseBestResult included: they decide the zone)."""
+    from test_gpu_zones import _zoned_problem
+
+    rng = np.random.default_rng(1000 + algo)
+    n_apps = 150
+    avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, 3000, n_apps, False, "merged", 3)
+    exe = np.maximum(exe, 1)
+    exe[:, 0] = np.maximum(exe[:, 0], 250)
+    k = np.minimum(k, 25).astype(np.int32)
+    t = rng.integers(0, 6, size=n_apps)  # a handful of templates, like a real queue
+    drv, exe = drv[t], exe[t]
+    flags = np.ones(n_apps, dtype=np.uint32)
+    with gangfit.Context(0, options=options) as ctx:
+        ctx.set_snapshot(avail, sched)
+        ctx.set_zones(zone)
+        ctx.set_orders(D, X)
+        ctx.chain_cache_stats(reset=True)
+        for n in (40, 41, 64, 65, 66, 97, 130, 150, 150, 149, 96):
+            _zcheck(ctx, algo, avail, sched, zone, D, X, drv[:n], exe[:n], k[:n], flags[:n])
+        st = ctx.chain_cache_stats(reset=True)
+        assert st[0] == 11 and st[1] == 10 and st[3] == 32 + 32 + 32 + 64 + 64 + 96 + 128 + 128 + 128 + 64
+        drv2 = drv.copy()
+        drv2[70, 1] += 1
+        _zcheck(ctx, algo, avail, sched, zone, D, X, drv2, exe, k, flags)
+        assert ctx.chain_cache_stats(reset=True)[3] == 64
+        flags2 = flags.copy()
+        flags2[100] = 0
+        exe2 = exe.copy()
+        exe2[100] = (250 * 10 ** 6, 10 ** 6, 0)  # nothing hosts this executor: failure-earlier-driver at 100
+        for n in (120, 150):
+            ref = _zcheck(ctx, algo, avail, sched, zone, D, X, drv2[:n], exe2[:n], k[:n], flags2[:n])
+            assert ref.failed_at == 100
+        assert ctx.chain_cache_stats(reset=True)[3] == 96 + 96
+
+
+def test_headline_single_az_creation_order_heads():
+    """single-az-tightly-pack — what production and every reference test select — on the headline cluster with three zones in
+    the reference's AZ-major order: consecutive Filters resume, results equal the full replay."""
+    w = wl.headline(10000, 1000)
+    s = w.snapshot
+    zone3 = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+    order = wl.reference_node_order(s.avail, zone3)
+    flags = np.ones(len(w.k), dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(s.avail, s.sched)
+        ctx.set_zones(zone3)
+        ctx.set_orders(order, order)
+        ctx.chain_cache_stats(reset=True)
+        for n in (960, 961, 975, 1000, 1000):
+            _zcheck(ctx, SAZ, s.avail, s.sched, zone3, order, order, w.drv[:n], w.exe[:n], w.k[:n], flags[:n])
+        st = ctx.chain_cache_stats()
+        assert st[1] == 4 and st[3] == 928 + 960 + 960 + 992
