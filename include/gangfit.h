@@ -198,10 +198,21 @@ int gf_snapshot_build_resident(gf_ctx *ctx, uint32_t n_res, const uint32_t *res_
  * gf_snapshot_build_resident with n_res = GF_RESIDENT_USAGE then builds from the resident sums and moves no reservation at
  * all.  Sums of 64-bit integers: the result equals the replay of the full entry list bit for bit, whatever the order of the
  * updates.  Entries on nodes outside the cluster are ignored like the replay ignores them (resources.go:72). */
+/* gf_usage_apply(sign = -1) returns GF_ERR_INVALID and leaves the sums as they were when an entry is removed from a node
+ * that does not carry it (the node's sum would go negative: available above allocatable).  When an update fails half way
+ * on a multi-device context the resident usage is unusable (GF_ERR_STATE) until gf_usage_reset. */
 #define GF_RESIDENT_USAGE 0xFFFFFFFFu
 int gf_usage_reset(gf_ctx *ctx);
 int gf_usage_apply(gf_ctx *ctx, uint32_t n_entries, const uint32_t *res_node, const int64_t *res_cpu_milli,
                    const int64_t *res_mem_bytes, const int64_t *res_gpu, int sign /* +1 add, -1 remove */);
+/* Generations of the state a context keeps between calls, for hosts that decide from them what a Filter must resend:
+ *   out[0]  snapshot epoch: bumped by every call that installs a snapshot, zones or orders (the chain cache and recorded
+ *           graphs are tied to it)
+ *   out[1]  cluster generation: bumped by gf_cluster_set (and gf_snapshot_build, which calls it)
+ *   out[2]  usage generation: bumped by gf_cluster_set, gf_usage_reset and every gf_usage_apply
+ * A host that finds the generations it recorded after its own last call unchanged knows that no other user of the context
+ * touched that state (internal/extender keeps one extender per context, but the UnschedulablePodMarker shares it). */
+int gf_generation(gf_ctx *ctx, uint64_t out[3]);
 /* The installed snapshot, n_nodes x 3 row-major each (either may be NULL). */
 int gf_snapshot_get(gf_ctx *ctx, int64_t *avail_out, int64_t *sched_out);
 
@@ -255,6 +266,8 @@ int gf_fit_batch_dev(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
  * the NULL stream (NULL = the context's own stream, which is fine).  Snapshot, orders and every buffer the recorded calls
  * named must stay as they are until the graph is destroyed; buffers must have reached their final size before recording
  * (run the sequence once eagerly first).  The statistics counters of gf_scan_stats must be off while recording. */
+/* gf_graph_launch returns GF_ERR_STATE when a snapshot, zones or orders were installed after gf_graph_end (the recording
+ * names buffers an install may have replaced): record the sequence again. */
 int gf_graph_begin(gf_ctx *ctx, void *stream);
 int gf_graph_end(gf_ctx *ctx, void *stream, void **graph_out);
 int gf_graph_launch(gf_ctx *ctx, void *graph, void *stream);

@@ -198,7 +198,12 @@ struct gf_ctx {
     DeviceBuf<uint32_t> d_delta_u32;
     __int128 usage_total[3] = {0, 0, 0};  // sum of everything applied: bounds every node's sum
     DeviceBuf<uint32_t> d_cl_u32;  // zone | name_rank | node_flags (n each)
-    std::vector<uint32_t> cl_flags, cl_zone;  // host copies (candidate lists, ctx->zone)
+    std::vector<uint32_t> cl_flags, cl_zone;  // host copies (candidate lists, ctx->zone); cl_flags = the flags of the last build
+    std::vector<uint32_t> cl_default_flags;   // the flags of gf_cluster_set: what node_flags == NULL selects
+    bool d_flags_default = true;              // the device column holds cl_default_flags (not a request's candidate flags)
+    bool usage_ok = true;                     // false after a failed update: the resident sums are unknown until gf_usage_reset
+    uint64_t cluster_gen = 0, usage_gen = 0;  // bumped by gf_cluster_set / gf_usage_reset + gf_usage_apply (gf_generation)
+    DeviceBuf<uint32_t> d_flag32;             // one device word for yes / no answers of small kernels
     uint32_t cl_n = 0, cl_zones = 1;
     bool cl_over = false, have_cluster = false;
     int64_t cl_max_over[3] = {0, 0, 0};
@@ -933,6 +938,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->h_gidx.release();
     ctx->d_napps.release();
     ctx->chain.d_ckpt.release();
+    ctx->d_flag32.release();
     ctx->d_wide_needed.release();
     ctx->d_capmat.release();
     ctx->d_mfhist.release();
@@ -1052,6 +1058,16 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         return fail(ctx, GF_ERR_INVALID, "unknown option '%s'", key);
     }
     ctx->chain.valid = false;
+    return GF_OK;
+}
+
+int gf_generation(gf_ctx* ctx, uint64_t out[3]) {
+    GF_DELEGATE(ctx, gf_generation(ctx, out));
+    if (!ctx || !out) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    out[0] = ctx->snap_epoch;
+    out[1] = ctx->cluster_gen;
+    out[2] = ctx->usage_gen;
     return GF_OK;
 }
 
@@ -1677,6 +1693,15 @@ int gf_graph_begin(gf_ctx* ctx, void* stream) {
     return GF_OK;
 }
 
+namespace {
+// A recorded sequence names device buffers by address: it is only replayable while the snapshot / orders it was recorded
+// on are the installed ones (their buffers may be reallocated by the next install).
+struct RecordedGraph {
+    hipGraphExec_t exec = nullptr;
+    uint64_t epoch = 0;
+};
+}  // namespace
+
 int gf_graph_end(gf_ctx* ctx, void* stream, void** graph_out) {
     GF_DELEGATE(ctx, gf_graph_end(ctx, stream, graph_out));
     if (!ctx || !graph_out) return GF_ERR_INVALID;
@@ -1689,21 +1714,36 @@ int gf_graph_end(gf_ctx* ctx, void* stream, void** graph_out) {
     const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
-    *graph_out = exec;
+    RecordedGraph* rg = new (std::nothrow) RecordedGraph();
+    if (!rg) {
+        (void)hipGraphExecDestroy(exec);
+        return fail(ctx, GF_ERR_HIP, "out of memory");
+    }
+    rg->exec = exec;
+    rg->epoch = ctx->snap_epoch;
+    *graph_out = rg;
     return GF_OK;
 }
 
 int gf_graph_launch(gf_ctx* ctx, void* graph, void* stream) {
     GF_DELEGATE(ctx, gf_graph_launch(ctx, graph, stream));
     if (!ctx || !graph) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const RecordedGraph* rg = static_cast<const RecordedGraph*>(graph);
+    if (rg->epoch != ctx->snap_epoch)
+        return fail(ctx, GF_ERR_STATE, "the snapshot / orders changed since the sequence was recorded: record it again");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    GF_HIP(ctx, hipGraphLaunch(static_cast<hipGraphExec_t>(graph), st));
+    GF_HIP(ctx, hipGraphLaunch(rg->exec, st));
     return GF_OK;
 }
 
 void gf_graph_destroy(gf_ctx* ctx, void* graph) {
     (void)ctx;
-    if (graph) (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph));
+    if (!graph) return;
+    RecordedGraph* rg = static_cast<RecordedGraph*>(graph);
+    if (rg->exec) (void)hipGraphExecDestroy(rg->exec);
+    delete rg;
 }
 
 int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* result, uint32_t* exec_nodes,
@@ -1774,6 +1814,11 @@ int gf_cluster_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli
     for (int j = 0; j < 3; ++j) ctx->usage_total[j] = 0;
     GF_HIP(ctx, gf_wait_stream(st));  // the caller's arrays are free again
     ctx->cl_flags.assign(node_flags, node_flags + n);
+    ctx->cl_default_flags = ctx->cl_flags;
+    ctx->d_flags_default = true;
+    ctx->usage_ok = true;
+    ++ctx->cluster_gen;
+    ++ctx->usage_gen;
     if (zone_of_node)
         ctx->cl_zone.assign(zone_of_node, zone_of_node + n);
     else
@@ -1809,15 +1854,33 @@ int gf_usage_reset(gf_ctx* ctx) {
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, hipMemsetAsync(ctx->d_cl_usage.ptr, 0, (3 * (size_t)ctx->cl_n + 1) * sizeof(int64_t), ctx->stream));
     for (int j = 0; j < 3; ++j) ctx->usage_total[j] = 0;
+    ctx->usage_ok = true;
+    ++ctx->usage_gen;
     return GF_OK;
 }
 
 int gf_usage_apply(gf_ctx* ctx, uint32_t n_entries, const uint32_t* res_node, const int64_t* res_cpu_milli,
                    const int64_t* res_mem_bytes, const int64_t* res_gpu, int sign) {
-    GF_EACH(ctx, gf_usage_apply(ctx, n_entries, res_node, res_cpu_milli, res_mem_bytes, res_gpu, sign));
+    if (ctx != nullptr && !ctx->group.empty()) {
+        // every device keeps the same sums; an update that reaches some devices and fails on another leaves them apart:
+        // the resident usage is then unusable everywhere until gf_usage_reset
+        gf_ctx* const g = ctx;
+        std::lock_guard<std::recursive_mutex> glock(g->mu);
+        for (size_t i = 0; i < g->group.size(); ++i) {
+            const int rc = gf_usage_apply(g->group[i], n_entries, res_node, res_cpu_milli, res_mem_bytes, res_gpu, sign);
+            if (rc != GF_OK) {
+                g->err = g->group[i]->err;
+                if (i > 0)
+                    for (gf_ctx* sub : g->group) sub->usage_ok = false;
+                return rc;
+            }
+        }
+        return GF_OK;
+    }
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_usage_apply");
+    if (!ctx->usage_ok) return fail(ctx, GF_ERR_STATE, "an earlier update failed half way: gf_usage_reset must rebuild the resident usage");
     if (sign != 1 && sign != -1) return fail(ctx, GF_ERR_INVALID, "sign must be +1 or -1");
     if (n_entries == 0) return GF_OK;
     if (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu) return fail(ctx, GF_ERR_INVALID, "entry columns must not be NULL");
@@ -1845,9 +1908,25 @@ int gf_usage_apply(gf_ctx* ctx, uint32_t n_entries, const uint32_t* res_node, co
     for (int j = 0; j < 3; ++j)
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_delta_i64.ptr + j * R, rcols[j], R * sizeof(int64_t), hipMemcpyHostToDevice, st));
     GF_HIP(ctx, hipMemcpyAsync(ctx->d_delta_u32.ptr, res_node, R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    GF_HIP(ctx, ctx->d_flag32.reserve(1));
+    if (sign < 0) GF_HIP(ctx, hipMemsetAsync(ctx->d_flag32.ptr, 0, sizeof(uint32_t), st));
+    ++ctx->usage_gen;
+    ctx->usage_ok = false;  // until the update is known to have been applied in full
     GF_HIP(ctx, gangfit::launch_usage_apply(n_entries, ctx->cl_n, ctx->d_delta_u32.ptr, ctx->d_delta_i64.ptr, sign,
-                                            ctx->d_cl_usage.ptr, st));
+                                            ctx->d_cl_usage.ptr, ctx->d_flag32.ptr, st));
+    if (sign < 0)
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_flag32.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     GF_HIP(ctx, gf_wait_stream(st));  // the caller's arrays are free again
+    if (sign < 0 && ctx->h_failed.ptr[0] != 0) {
+        // an entry was removed from a node that never carried it: the node's sum went negative (the snapshot would report
+        // available > allocatable).  Put the update back and refuse it.
+        GF_HIP(ctx, gangfit::launch_usage_apply(n_entries, ctx->cl_n, ctx->d_delta_u32.ptr, ctx->d_delta_i64.ptr, +1,
+                                                ctx->d_cl_usage.ptr, nullptr, st));
+        GF_HIP(ctx, gf_wait_stream(st));
+        ctx->usage_ok = true;
+        return fail(ctx, GF_ERR_INVALID, "an entry was removed from a node that never carried it (a node's usage went negative)");
+    }
+    ctx->usage_ok = true;
     for (int j = 0; j < 3; ++j) ctx->usage_total[j] = total[j];
     return GF_OK;
 }
@@ -1882,7 +1961,14 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     if (usage_resident) n_res = 0;
     if (n_res > 0 && (!res_node || !res_cpu_milli || !res_mem_bytes || !res_gpu))
         return fail(ctx, GF_ERR_INVALID, "reservation columns must not be NULL");
-    if (node_flags) ctx->cl_flags.assign(node_flags, node_flags + n);  // this request's candidate flags
+    if (usage_resident && !ctx->usage_ok)
+        return fail(ctx, GF_ERR_STATE, "the resident usage is unknown (a failed update): gf_usage_reset must rebuild it");
+    // this request's candidate flags; NULL = the flags of gf_cluster_set (not those of the previous request)
+    if (node_flags)
+        ctx->cl_flags.assign(node_flags, node_flags + n);
+    else
+        ctx->cl_flags = ctx->cl_default_flags;
+    const uint32_t* const flags_upload = node_flags ? node_flags : (ctx->d_flags_default ? nullptr : ctx->cl_default_flags.data());
     const uint32_t* const zone_of_node = ctx->cl_zone.empty() ? nullptr : ctx->cl_zone.data();
     const uint32_t* const flags_host = ctx->cl_flags.data();
     const int64_t* rcols[3] = {res_cpu_milli, res_mem_bytes, res_gpu};
@@ -1954,7 +2040,10 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     for (int j = 0; j < 3 && R; ++j)
         GF_HIP(ctx, hipMemcpyAsync(d_res_req + j * R, rcols[j], R * sizeof(int64_t), hipMemcpyHostToDevice, st));
     if (R) GF_HIP(ctx, hipMemcpyAsync(d_res_node, res_node, R * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    if (node_flags) GF_HIP(ctx, hipMemcpyAsync(d_flags, node_flags, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (flags_upload) {
+        GF_HIP(ctx, hipMemcpyAsync(d_flags, flags_upload, N * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        ctx->d_flags_default = node_flags == nullptr;
+    }
     gangfit::SnapshotBuild b{};
     b.n_nodes = n;
     b.n_res = n_res;

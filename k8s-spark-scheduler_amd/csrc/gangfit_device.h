@@ -283,8 +283,9 @@ struct SnapshotBuild {
 };
 // usage[node] += sign * entry for n_entries reservation entries (columns cpu | memory | gpu of d_req); entries on nodes
 // >= n_nodes are ignored.
+// d_negative (nullable): after a removal (sign < 0) bit 0 is set when a touched node's sum went below zero.
 hipError_t launch_usage_apply(uint32_t n_entries, uint32_t n_nodes, const uint32_t* d_node, const int64_t* d_req, int sign,
-                              int64_t* d_usage, hipStream_t stream);
+                              int64_t* d_usage, uint32_t* d_negative, hipStream_t stream);
 // The slot tables of the merged layout built from the device-resident snapshot columns (what gf_orders_set builds on the
 // host): every node gets the slot of its position in the priority order.
 struct SnapshotFinalize {

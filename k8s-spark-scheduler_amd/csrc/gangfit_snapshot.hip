@@ -35,6 +35,16 @@ __global__ void usage_scatter_kernel(uint32_t n_res, uint32_t n_nodes, const uin
 // zone sums of the available memory / cpu feed the AZ order (nodesorting.go:124-134).
 constexpr uint32_t kZoneLdsMax = 512;  // zones whose sums are first combined in LDS (one global atomic per block and zone)
 
+// After a removal: a node of the update whose sum went negative had an entry removed that was never added there.
+__global__ void usage_negative_kernel(uint32_t n_res, uint32_t n_nodes, const uint32_t* __restrict__ res_node,
+                                      const int64_t* __restrict__ usage, uint32_t* __restrict__ negative) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_res) return;
+    const uint32_t n = res_node[i];
+    if (n >= n_nodes) return;
+    if (usage[n] < 0 || usage[(size_t)n_nodes + n] < 0 || usage[2 * (size_t)n_nodes + n] < 0) atomicOr(negative, 1u);
+}
+
 __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const int64_t* __restrict__ alloc,
                                                        const int64_t* __restrict__ overhead,
                                                        const int64_t* __restrict__ usage, const uint32_t* __restrict__ zone,
@@ -404,11 +414,15 @@ size_t snapshot_sort_temp_bytes(uint32_t n_nodes) {
 }
 
 hipError_t launch_usage_apply(uint32_t n_entries, uint32_t n_nodes, const uint32_t* d_node, const int64_t* d_req, int sign,
-                              int64_t* d_usage, hipStream_t stream) {
+                              int64_t* d_usage, uint32_t* d_negative, hipStream_t stream) {
     if (n_entries == 0 || n_nodes == 0) return hipSuccess;
     hipLaunchKernelGGL(usage_scatter_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, n_entries, n_nodes, d_node,
                        d_req, d_req + n_entries, d_req + 2 * (size_t)n_entries, reinterpret_cast<unsigned long long*>(d_usage),
                        sign < 0 ? -1 : 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || sign > 0 || d_negative == nullptr) return e;
+    hipLaunchKernelGGL(usage_negative_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, n_entries, n_nodes, d_node,
+                       (const int64_t*)d_usage, d_negative);
     return hipGetLastError();
 }
 

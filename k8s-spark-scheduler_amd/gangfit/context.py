@@ -72,6 +72,12 @@ class Context:
     def set_option(self, key: str, value: int):
         self._check(self._lib.gf_set_option(self._h, key.encode(), int(value)))
 
+    def generation(self):
+        """(snapshot epoch, cluster generation, usage generation)"""
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self._lib.gf_generation(self._h, N.ptr(out)))
+        return tuple(int(v) for v in out)
+
     def chain_cache_stats(self, reset: bool = False):
         """(chains with the cache armed, chains resumed from a checkpoint, applications evaluated, applications skipped)"""
         out = np.zeros(4, dtype=np.uint64)

@@ -441,37 +441,56 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
     CtxSequence seq(ctx);
     if (overhead.empty()) {
         // the node-side columns change only when the node set does: they stay on the device (gf_cluster_set), a Filter moves
-        // its reservation entries and its own candidate flags only.  (Another user of the context may have replaced the
-        // resident cluster in between; a host with one extender per context — the reference's shape — never does.)
-        if (resident_cluster_ != cluster.version || cluster.version == 0) {
+        // its reservation entries and its own candidate flags only.  Another user of the context (the UnschedulablePodMarker
+        // shares it) may have replaced the resident cluster or usage in between: the context's generations say so.
+        uint64_t gen[3] = {0, 0, 0};
+        (void)gf_generation(ctx, gen);
+        if (resident_cluster_ != cluster.version || cluster.version == 0 || gen[1] != seen_cluster_gen_) {
             if (gf_cluster_set(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(), nullptr, nullptr,
                                nullptr, cluster.base_flags.data(), cluster.zone.data(), (uint32_t)cluster.zone_labels.size(),
                                cluster.name_rank.data()) != GF_OK)
                 return not_served(std::string("gf_cluster_set: ") + gf_last_error(ctx));
             resident_cluster_ = cluster.version;
             resident_usage_ = 0;  // gf_cluster_set zeroed the resident usage
+            (void)gf_generation(ctx, gen);
+            seen_cluster_gen_ = gen[1];
+            seen_usage_gen_ = gen[2];
         }
         // a caller that keeps its flattened reservations (flat->version != 0) gets the usage sums kept on the device too: they
         // are sent when the list changes, and a Filter between two changes moves no reservation at all.  (A host that tracks
         // its ResourceReservation events would send only the K + 1 entries of the object that changed: gf_usage_apply.)
         const bool keep_usage = flat != &local && flat->version != 0;
-        if (keep_usage && resident_usage_ != flat->version) {
+        if (keep_usage && (resident_usage_ != flat->version || gen[2] != seen_usage_gen_)) {
             resident_usage_ = 0;
             if (gf_usage_reset(ctx) != GF_OK ||
                 gf_usage_apply(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(), rreq[2].data(), +1) != GF_OK)
                 return not_served(std::string("gf_usage_apply: ") + gf_last_error(ctx));
             resident_usage_ = flat->version;
+            (void)gf_generation(ctx, gen);
+            seen_usage_gen_ = gen[2];
         }
-        const int brc = keep_usage
-                            ? gf_snapshot_build_resident(ctx, GF_RESIDENT_USAGE, nullptr, nullptr, nullptr, nullptr, flags.data(),
-                                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)
-                            : gf_snapshot_build_resident(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(), rreq[1].data(),
-                                                         rreq[2].data(), flags.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                         nullptr);
-        if (brc != GF_OK) {
-            resident_cluster_ = 0;
-            resident_usage_ = 0;
-            return not_served(std::string("gf_snapshot_build_resident: ") + gf_last_error(ctx));
+        // nothing changed since this extender's last Filter: the installed snapshot IS this request's snapshot
+        const bool same_snapshot = keep_usage && built_epoch_ != 0 && gen[0] == built_epoch_ && built_cluster_ == cluster.version &&
+                                   built_usage_ == flat->version && built_flags_ == flags;
+        if (!same_snapshot) {
+            built_epoch_ = 0;
+            const int brc = keep_usage
+                                ? gf_snapshot_build_resident(ctx, GF_RESIDENT_USAGE, nullptr, nullptr, nullptr, nullptr, flags.data(),
+                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)
+                                : gf_snapshot_build_resident(ctx, (uint32_t)rnode.size(), rnode.data(), rreq[0].data(),
+                                                             rreq[1].data(), rreq[2].data(), flags.data(), nullptr, nullptr, nullptr,
+                                                             nullptr, nullptr, nullptr);
+            if (brc != GF_OK) {
+                resident_cluster_ = 0;
+                resident_usage_ = 0;
+                return not_served(std::string("gf_snapshot_build_resident: ") + gf_last_error(ctx));
+            }
+            if (keep_usage && gf_generation(ctx, gen) == GF_OK) {
+                built_epoch_ = gen[0];
+                built_cluster_ = cluster.version;
+                built_usage_ = flat->version;
+                built_flags_ = flags;
+            }
         }
     } else if (gf_snapshot_build(ctx, n, cluster.alloc[0].data(), cluster.alloc[1].data(), cluster.alloc[2].data(), over[0].data(),
                                  over[1].data(), over[2].data(), (uint32_t)rnode.size(), rnode.data(), rreq[0].data(),
@@ -482,6 +501,7 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
         return not_served(std::string("gf_snapshot_build: ") + gf_last_error(ctx));
     } else {
         resident_cluster_ = 0;  // gf_snapshot_build replaced the resident cluster (with this request's overhead)
+        built_epoch_ = 0;
     }
     uint64_t total_k = 0;
     for (const gf_app& a : apps) total_k += (uint64_t)a.k;

@@ -104,6 +104,8 @@ public:
     SelectNodeResult selectDriverNodeFlat(const std::string& instanceGroup, const Pod& driver,
                                           const std::vector<std::string>& nodeNames, const FlatCluster& cluster,
                                           const FlatReservations* flat = nullptr);
+    // The next selectDriverNodeFlat rebuilds the snapshot even if nothing changed (host_bench times both).
+    void forgetInstalledSnapshot() { built_epoch_ = 0; }
 
     // unschedulablepods.go:132-166: does the application fit an EMPTY cluster (usage = 0, the given overhead)?
     // nodes are used in lister order for both candidate lists.
@@ -132,6 +134,14 @@ public:
 private:
     uint64_t resident_cluster_ = 0;  // FlatCluster::version whose static columns sit on the device (selectDriverNodeFlat)
     uint64_t resident_usage_ = 0;    // FlatReservations::version whose usage sums sit on the device (for resident_cluster_)
+    // what the context held after this extender's last call (gf_generation): another user of the same gf_ctx that replaces the
+    // cluster, the usage or the snapshot moves these on, and the next Filter sends its own state again
+    uint64_t seen_cluster_gen_ = 0, seen_usage_gen_ = 0;
+    // the snapshot the last Filter installed: while cluster, usage and candidate flags are the same and nobody installed
+    // another one (snapshot epoch), the next Filter neither rebuilds nor re-sorts — and its chain resumes from the previous
+    // chain's checkpoints (include/gangfit.h, "Incremental FIFO chains")
+    uint64_t built_epoch_ = 0, built_cluster_ = 0, built_usage_ = 0;
+    std::vector<uint32_t> built_flags_;
     Binpacker binpacker_;
     NodeSorter sorter_;
     bool isFIFO_;

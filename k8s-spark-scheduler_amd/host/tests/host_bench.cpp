@@ -132,17 +132,54 @@ int main(int argc, char** argv) {
         ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster);
         flat_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
     }
-    for (int i = 0; i < 40; ++i) {  // the reservations kept in flat form next to the host's reservation cache
+    // the reservations kept in flat form next to the host's reservation cache (cluster columns and usage sums resident):
+    //   cached     every Filter rebuilds the snapshot and replays the whole chain (what round 2 measured)
+    //   unchanged  nothing changed since the previous Filter: no rebuild, the chain still replays (chain cache off)
+    //   order      ... and the chain resumes: Filters for the last 64 drivers in creation order, cyclically
+    //   retry      ... the same driver again
+    std::vector<double> unchanged_ms, order_ms, retry_ms;
+    for (int i = 0; i < 40; ++i) {
+        ext.forgetInstalledSnapshot();
         t0 = Clock::now();
         ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster, &flat);
         cached_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
     }
+    gf_set_option(ctx, "chain_cache", 0);
+    for (int i = 0; i < 40; ++i) {
+        t0 = Clock::now();
+        ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster, &flat);
+        unchanged_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+    }
+    gf_set_option(ctx, "chain_cache", 1);
+    const int span = n_pending < 64 ? n_pending : 64;
+    for (int i = 0; i < 3 * span + 4; ++i) {
+        const Pod& d = ext.pods[(size_t)(n_pending - span + i % span)];
+        t0 = Clock::now();
+        ext.selectDriverNodeFlat("batch-medium-priority", d, nodeNames, cluster, &flat);
+        if (i >= 4) order_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+    }
+    for (int i = 0; i < 44; ++i) {
+        t0 = Clock::now();
+        SelectNodeResult r = ext.selectDriverNodeFlat("batch-medium-priority", driver, nodeNames, cluster, &flat);
+        if (i >= 4) retry_ms.push_back(std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
+        if (i == 43) {
+            bool again = r.served && r.outcome == b.outcome && r.node == b.node && r.created.has_value() == b.created.has_value();
+            if (again && r.created)
+                for (const auto& [name, res] : b.created->Reservations)
+                    again = again && r.created->Reservations.count(name) && r.created->Reservations.at(name).Node == res.Node;
+            same = same && again;  // the resumed chain answers what the replayed one answered
+        }
+    }
     std::printf("{\"nodes\": %d, \"pending_drivers\": %d, \"resource_reservations\": %d, \"packer\": \"%s\", "
                 "\"filter_map_route_ms\": {\"p50\": %.3f, \"p99\": %.3f}, \"filter_flat_route_ms\": {\"p50\": %.3f, \"p99\": %.3f}, "
-                "\"filter_flat_route_cached_reservations_ms\": {\"p50\": %.3f, \"p99\": %.3f}, \"reservation_entries\": %zu, "
+                "\"filter_flat_route_cached_reservations_ms\": {\"p50\": %.3f, \"p99\": %.3f}, "
+                "\"filter_unchanged_snapshot_replayed_chain_ms\": {\"p50\": %.3f, \"p99\": %.3f}, "
+                "\"filter_unchanged_snapshot_creation_order_heads_ms\": {\"p50\": %.3f, \"p99\": %.3f}, "
+                "\"filter_unchanged_snapshot_same_head_ms\": {\"p50\": %.3f, \"p99\": %.3f}, \"reservation_entries\": %zu, "
                 "\"flat_cluster_build_ms\": %.3f, \"flat_reservations_build_ms\": %.3f, \"routes_agree\": %s}\n",
                 n_nodes, n_pending, n_rr, packer.c_str(), pct(map_ms, 0.5), pct(map_ms, 0.99), pct(flat_ms, 0.5),
-                pct(flat_ms, 0.99), pct(cached_ms, 0.5), pct(cached_ms, 0.99), flat.node.size(), build_ms, flat_rr_ms,
+                pct(flat_ms, 0.99), pct(cached_ms, 0.5), pct(cached_ms, 0.99), pct(unchanged_ms, 0.5), pct(unchanged_ms, 0.99),
+                pct(order_ms, 0.5), pct(order_ms, 0.99), pct(retry_ms, 0.5), pct(retry_ms, 0.99), flat.node.size(), build_ms, flat_rr_ms,
                 same ? "true" : "false");
     gf_destroy(ctx);
     return same ? 0 : 1;

@@ -637,6 +637,99 @@ static void TestDeviceSnapshotBuildAgainstHostMirror() {
 }
 
 
+// Consecutive Filters on an unchanged cluster (selectDriverNodeFlat with the host's flattened reservations): the snapshot is
+// not rebuilt and the FIFO chain resumes from the previous chain's checkpoints (include/gangfit.h, "Incremental FIFO chains").
+// Every answer must be the one the string-keyed route gives — which installs its own snapshot per call and replays the whole
+// chain, like the reference (resource.go:309-328).
+static void TestIncrementalFilters() {
+    const int n = 500, n_pending = 120;
+    uint64_t rng = 0xF1F0;
+    auto next = [&]() {
+        rng += 0x9E3779B97F4A7C15ull;
+        uint64_t z = rng;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    for (const char* packer : {"tightly-pack", "single-az-tightly-pack", "single-az-minimal-fragmentation"}) {
+        SparkSchedulerExtender ext(SelectBinpacker(packer, g_ctx), NodeSorter(), true, FifoConfig{});
+        const char* zones[] = {"az-a", "az-b", "az-c"};
+        std::vector<std::string> names;
+        for (int i = 0; i < n; ++i) {
+            Node nd;
+            nd.Name = "n" + std::to_string(next() % 100000) + "-" + std::to_string(i);
+            nd.labels[kLabelZoneFailureDomain] = zones[next() % 3];
+            nd.Allocatable = {{kResourceCPU, Quantity::FromInt(16 + 16 * (int64_t)(next() % 3))},
+                              {kResourceMemory, Quantity::FromInt((int64_t)(64 + 64 * (next() % 3)) * Gi)},
+                              {kResourceNvidiaGPU, Quantity::FromInt(0)}};
+            nd.Ready = true;
+            names.push_back(nd.Name);
+            ext.nodes.push_back(nd);
+        }
+        for (int r = 0; r < 60; ++r) {
+            ResourceReservation rr;
+            rr.Name = "running-" + std::to_string(r);
+            rr.Namespace = "namespace";
+            const int k = 1 + (int)(next() % 12);
+            for (int e = 0; e <= k; ++e) {
+                Reservation res;
+                res.Node = ext.nodes[next() % n].Name;
+                res.Resources = {{kResourceCPU, Quantity::FromInt(1 + (int64_t)(next() % 2))},
+                                 {kResourceMemory, Quantity::FromInt((int64_t)(2 + next() % 6) * Gi)},
+                                 {kResourceNvidiaGPU, Quantity::FromInt(0)}};
+                rr.Reservations[e == 0 ? "driver" : executorReservationName(e - 1)] = res;
+            }
+            ext.reservations.push_back(rr);
+        }
+        const char* ecpu[] = {"1", "2", "4"};
+        const char* emem[] = {"4Gi", "8Gi", "16Gi"};
+        for (int p = 0; p < n_pending; ++p) {
+            const int k = 1 + (int)(next() % 30);
+            const char* em = emem[next() % 3];
+            const char* ec = ecpu[next() % 3];
+            Pod pod = Driver(("pending-" + std::to_string(p)).c_str(), StaticAnnotations(k, "2Gi", "1", em, ec), p + 1);
+            pod.Annotations.erase("spark-driver-nvidia.com/gpu");
+            pod.Annotations.erase("spark-executor-nvidia.com/gpu");
+            ext.pods.push_back(pod);
+        }
+        ext.nowNanos = (int64_t)(n_pending + 10) * 1000000000;
+        FlatCluster cluster;
+        FlatReservations flat;
+        std::string err;
+        CHECK(FlatCluster::Build(ext.nodes, &cluster, &err));
+        CHECK(FlatReservations::Build(ext.reservations, ext.softReservationUsage, cluster, &flat, &err));
+        std::vector<SelectNodeResult> want;
+        for (int j = 60; j < n_pending; ++j) want.push_back(ext.selectDriverNode("batch-medium-priority", ext.pods[(size_t)j], names, ext.nodes));
+        uint64_t st0[4], st1[4];
+        gf_chain_cache_stats(g_ctx, 1, st0);
+        bool all_same = true;
+        for (int round = 0; round < 2; ++round)
+            for (int j = 60; j < n_pending; ++j) {
+                if (round == 1 && j == 90) {  // another user of the context in between: its own cluster and snapshot
+                    auto other = NewTestExtender(packer, {NewNode("node1", "zone1"), NewNode("node2", "zone1")});
+                    FlatCluster oc;
+                    CHECK(FlatCluster::Build(other.nodes, &oc, &err));
+                    Pod small = Driver("small", StaticAnnotations(1), 5);
+                    other.pods = {small};
+                    SelectNodeResult o = other.selectDriverNodeFlat("batch-medium-priority", small, {"node1", "node2"}, oc);
+                    CHECK(o.served && o.outcome == std::string(outcome::success));
+                }
+                const SelectNodeResult got = ext.selectDriverNodeFlat("batch-medium-priority", ext.pods[(size_t)j], names, cluster, &flat);
+                const SelectNodeResult& w = want[(size_t)(j - 60)];
+                bool same = got.served && w.served && got.outcome == w.outcome && got.node == w.node &&
+                            got.created.has_value() == w.created.has_value();
+                if (same && got.created)
+                    for (const auto& [name, res] : w.created->Reservations)
+                        same = same && got.created->Reservations.count(name) && got.created->Reservations.at(name).Node == res.Node;
+                all_same = all_same && same;
+            }
+        CHECK(all_same);
+        gf_chain_cache_stats(g_ctx, 0, st1);
+        CHECK(st1[0] == 2u * (n_pending - 60));
+        CHECK(st1[1] >= 2u * (n_pending - 60) - 4u);  // every Filter but the first of a round (and the one behind the intruder) resumes
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ failover: findNodes
 // The loop of internal/extender/failover.go:412-436 on the host mirror's own types (Quantity arithmetic, string-keyed maps):
 // what the device-backed findNodes must reproduce, over-add included.
@@ -865,6 +958,7 @@ int main(int argc, char** argv) {
         TestFifoAndBinpackers();
         TestMinimalFragmentationEdgeCase();
         TestDeviceSnapshotBuildAgainstHostMirror();
+        TestIncrementalFilters();
         TestFindNodes();
         TestTwoThreadsOneContext();
         TestMultiDeviceContext();

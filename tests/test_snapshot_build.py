@@ -205,3 +205,87 @@ def test_resident_usage_with_deltas(gf_ctx):
     assert e.value.code == gangfit._native.GF_ERR_INVALID
     with pytest.raises(gangfit.GangfitError):
         gf_ctx.usage_apply(np.array([0], dtype=np.uint32), np.array([[1, 1, 1]], dtype=np.int64), 2)
+
+
+@pytest.mark.gpu
+def test_null_flags_select_the_cluster_defaults_again(gf_ctx):
+    """gf_snapshot_build_resident(node_flags = NULL) means the flags of gf_cluster_set — also right after a request that
+    brought its own candidate flags (the request's flags must not stick)."""
+    n = 1500
+    c = _cluster(123, n, 200, 2, with_overhead=False, labels=False)
+    gf_ctx.set_cluster(c["alloc"], c["node_flags"], c["name_rank"], zone=c["zone"], n_zones=c["n_zones"])
+    rng = np.random.default_rng(9)
+    other = (c["node_flags"] & ~np.uint32(ps.DRIVER_CANDIDATE)) | np.where(rng.random(n) < 0.3, ps.DRIVER_CANDIDATE, 0).astype(np.uint32)
+    D0, X0 = gf_ctx.build_snapshot_resident(res_node=c["res_node"], res_req=c["res_req"])
+    D1, X1 = gf_ctx.build_snapshot_resident(res_node=c["res_node"], res_req=c["res_req"], node_flags=other)
+    D2, X2 = gf_ctx.build_snapshot_resident(res_node=c["res_node"], res_req=c["res_req"])
+    _, _, rD, rX = ps.build(**c)
+    _, _, oD, oX = ps.build(**dict(c, node_flags=other))
+    assert np.array_equal(D0, rD) and np.array_equal(D1, oD) and not np.array_equal(D1, D0)
+    assert np.array_equal(D2, rD) and np.array_equal(X2, rX)
+
+
+@pytest.mark.gpu
+def test_removing_what_was_never_added_is_refused(gf_ctx):
+    """gf_usage_apply(sign = -1) of an entry its node does not carry would drive that node's sum negative (available above
+    allocatable) although the global total stays positive: GF_ERR_INVALID, and the sums stay as they were."""
+    n = 800
+    c = _cluster(321, n, 100, 1, with_overhead=False, labels=False)
+    gf_ctx.set_cluster(c["alloc"], c["node_flags"], c["name_rank"], zone=c["zone"], n_zones=c["n_zones"])
+    g0 = gf_ctx.generation()
+    node = np.array([1, 1, 2, 5], dtype=np.uint32)
+    req = np.array([[1000, GIB, 0]] * 4, dtype=np.int64)
+    gf_ctx.usage_apply(node, req, +1)
+    assert gf_ctx.generation()[2] > g0[2] and gf_ctx.generation()[1] == g0[1]
+    gf_ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+    before = gf_ctx.snapshot()[0].copy()
+    with pytest.raises(gangfit.GangfitError) as e:
+        gf_ctx.usage_apply(np.array([7], dtype=np.uint32), req[:1], -1)  # node 7 never got anything
+    assert e.value.code == gangfit._native.GF_ERR_INVALID
+    gf_ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+    assert np.array_equal(gf_ctx.snapshot()[0], before)
+    gf_ctx.usage_apply(np.array([1], dtype=np.uint32), req[:1], -1)  # a real removal still works
+    gf_ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+    after = gf_ctx.snapshot()[0]
+    assert after[1, 0] == before[1, 0] + 1000 and after[1, 1] == before[1, 1] + GIB
+
+
+@pytest.mark.gpu
+def test_recorded_sequence_is_refused_after_an_install():
+    """gf_graph_launch replays device addresses: after gf_snapshot_set / gf_orders_set (which may reallocate them) the
+    recording is stale and must be refused (GF_ERR_STATE), not replayed."""
+    import torch
+
+    w = wl.config(2, n_nodes=500, n_apps=64)
+    s = w.snapshot
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(s.avail, s.sched)
+        ctx.set_orders(s.driver_order, s.exec_order)
+        apps, total_k = gangfit.with_offsets(gangfit.make_apps(w.drv, w.exe, w.k))
+        dev = torch.device("cuda", 0)
+        d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
+        d_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
+        d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+
+        def step():
+            ctx.fit_batch_dev(0, 0, len(apps), d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k, stream=0)
+
+        step()
+        torch.cuda.synchronize()
+        ctx.graph_begin(0)
+        step()
+        g = ctx.graph_end(0)
+        ctx.graph_launch(g, 0)
+        torch.cuda.synchronize()
+        first = d_res.cpu().numpy().copy()
+        ctx.set_snapshot(s.avail // 2, s.sched)
+        ctx.set_orders(s.driver_order, s.exec_order)
+        with pytest.raises(gangfit.GangfitError) as e:
+            ctx.graph_launch(g, 0)
+        assert e.value.code == gangfit._native.GF_ERR_STATE
+        ctx.graph_destroy(g)
+        ctx.set_snapshot(s.avail, s.sched)
+        ctx.set_orders(s.driver_order, s.exec_order)
+        step()
+        torch.cuda.synchronize()
+        assert np.array_equal(d_res.cpu().numpy(), first)
