@@ -180,6 +180,65 @@ def cpu_chain_baseline(algo, avail, sched, zone, driver_order, exec_order, drv, 
     return out
 
 
+# ------------------------------------------------------------------------------------------------ BASELINE config 3
+
+L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICROARCH.md)
+
+
+def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
+    """10 000 nodes x 10 000 pending apps, both plain packers, device resident: decisions/s, kernel time, and the roofline in
+    VISITED bytes (in-kernel counters: the scans are lazy like the reference's loops) against the HBM spec peak and against
+    the L2 peak (the 240 KB table is cache resident after first touch), next to the full-scan formula of SURVEY.md 8d."""
+    import gangfit
+    from gangfit import workloads as wl
+
+    IND = gangfit.GF_MODE_INDEPENDENT
+    w3 = wl.config(3)
+    ctx.set_snapshot(w3.snapshot.avail, w3.snapshot.sched)
+    ctx.set_orders(w3.snapshot.driver_order, w3.snapshot.exec_order)
+    apps3, total_k3 = gangfit.with_offsets(gangfit.make_apps(w3.drv, w3.exe, w3.k, w3.flags))
+    d_apps3 = torch.from_numpy(apps3.view(np.uint8).copy()).to(dev)
+    d_res3 = torch.zeros(len(apps3) * 16, dtype=torch.uint8, device=dev)
+    d_exec3 = torch.zeros(total_k3 + 1, dtype=torch.int32, device=dev)
+    alg = wl.algorithmic_bytes(len(w3.snapshot.exec_order), w3.k)
+    pmc = None
+    pmc_path = os.path.join(REPO, "profiles", "pmc_config3.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+        except Exception:
+            pmc = None
+    c3 = {}
+    for name, algo in (("tightly_pack", gangfit.GF_ALGO_TIGHTLY_PACK), ("distribute_evenly", gangfit.GF_ALGO_DISTRIBUTE_EVENLY)):
+        def step3():
+            ctx.fit_batch_dev(IND, algo, len(apps3), d_apps3.data_ptr(), d_res3.data_ptr(), d_exec3.data_ptr(), total_k3,
+                              stream=stream)
+        wall_3, kern_3, _, how3 = timed_graph(step3, steps, 3, 5)
+        ctx.scan_stats(enable=True, reset=True)
+        step3()
+        torch.cuda.synchronize()
+        xv, dv = ctx.scan_stats(enable=False, reset=True)
+        visited = xv * 24 + dv * 28 + len(apps3) * 88 + 4 * int(w3.k.sum())
+        ach = visited / (kern_3 * 1e-3) / 1e9
+        hb = ((pmc or {}).get(name) or {}).get("hbm_bytes")
+        c3[name] = {"decisions_per_s": len(apps3) * steps / wall_3, "kernel_ms": kern_3, "submission": how3,
+                    "roofline": {"bound": "latency", "nominal_bound": "hbm", "kernel": f"fit_independent_kernel<{name}>",
+                                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                                 "frac_of_l2_peak": ach / L2_PEAK_GBPS, "l2_peak": L2_PEAK_GBPS,
+                                 "bytes_counted": "visited (in-kernel counters of this run)",
+                                 "visited_bytes_per_launch": visited, "algorithmic_bytes_per_launch": alg,
+                                 "algorithmic_full_scan_GBps": alg / (kern_3 * 1e-3) / 1e9,
+                                 "traffic": None,
+                                 "traffic_from_profile": ({"tag": pmc.get("tag"), "hbm_bytes_per_launch": hb,
+                                                           "hbm_GBps": hb / (kern_3 * 1e-3) / 1e9 if hb else None,
+                                                           "source": "profiles/pmc_config3.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                                     "passes of `bench.py --config3-only` — a committed profile, not this run"}
+                                                          if pmc else "HBM traffic not measured in this run and no committed profile"),
+                                 "note": "10 000 wavefronts over 1 024 SIMDs: ten per SIMD, bound by the depth of the dependent-miss "
+                                         "chain and the issue slots (DESIGN.md 9), not by bytes"}}
+    return c3
+
+
 # ------------------------------------------------------------------------------------------------ main
 
 def main():
@@ -193,6 +252,12 @@ def main():
     ap.add_argument("--filter-calls", type=int, default=1000, help="FIFO Filter calls (different heads) behind p50/p99")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip everything but the headline, its roofline and the FIFO Filter")
+    ap.add_argument("--fifo-protocols", default="cold,warm,retry",
+                    help="which FIFO Filter protocols run (the profiling passes use `cold`: every fit_fifo_solo_kernel launch of "
+                         "the trace is then a full replay of the headline chain)")
+    ap.add_argument("--config3-only", action="store_true",
+                    help="nothing but BASELINE config 3 (10 000 nodes x 10 000 apps, both plain packers) and its roofline: the "
+                         "counter passes of tools/profile_round.sh use it")
     ap.add_argument("--headline-only", action="store_true",
                     help="nothing but the headline batch and its roofline (the profiling passes use it: every launch of "
                          "fit_independent_kernel in the trace is then a headline launch)")
@@ -307,6 +372,12 @@ def main():
         ctx.graph_destroy(g)
         return _median(walls_), _median(kerns_), walls_, "graph"
 
+    if args.config3_only:
+        c3 = run_config3(ctx, torch, dev, stream, timed_graph)
+        ctx.close()
+        print(json.dumps({"config3_10k_nodes_x_10k_apps": c3}))
+        return
+
     # The K steps of a window are submitted as ONE recorded graph (gf_graph_*: K kernel nodes, the same launches the eager
     # calls make): a 1 000-application batch takes about as long on the device as the host needs to submit one kernel, so
     # eager submission measures the host.  The eager figure (one gf_fit_batch_dev call per step) is reported next to it.
@@ -401,7 +472,10 @@ def main():
         "visited_bytes_per_launch": visited_bytes,
         "algorithmic_bytes_per_launch": alg_bytes,
         "algorithmic_full_scan_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
-        "traffic": None, "traffic_from_profile": traffic_prof,
+        "traffic": None,
+        "traffic_note": (f"HBM traffic: from profile {traffic_prof['tag']} (rocprofv3 PMC passes of this command, committed under "
+                         "profiles/), not measured in this run" if traffic_prof else "HBM traffic not measured in this run"),
+        "traffic_from_profile": traffic_prof,
         "launch_floor_us": floor_us,
         "frac_of_launch_floor": (floor_us / (kern_ms * 1e3)) if floor_us else None,
         "measured_read_stream_GBps": read_peak, "measured_copy_GBps": copy_peak,
@@ -536,14 +610,15 @@ def main():
                         "applications_evaluated_per_call": st_[2] / max(1, st_[0]), "applications_from_cache_per_call": st_[3] / max(1, st_[0])}
 
             warm_n = 5
+            protos = set(args.fifo_protocols.split(","))
             rolled_all = [np.roll(fq, -i) for i in range(args.filter_calls + warm_n)]
             cold, st_cold = protocol([(q, N.ptr(q), n_q) for q in rolled_all])
             failed_cold = int(ffailed.value)
             span = min(256, n_q - 1)
             pq = N.ptr(fq)
             heads = [n_q - span + (i % span) for i in range(args.filter_calls + warm_n)]  # driver index j -> chain of j + 1 applications
-            warm, st_warm = protocol([(fq, pq, j + 1) for j in heads])
-            retry, st_retry = protocol([(fq, pq, n_q)] * (min(args.filter_calls, 200) + warm_n))
+            warm, st_warm = protocol([(fq, pq, j + 1) for j in heads]) if "warm" in protos else (cold, st_cold)
+            retry, st_retry = protocol([(fq, pq, n_q)] * (min(args.filter_calls, 200) + warm_n)) if "retry" in protos else (cold, st_cold)
             ff = {"chain": f"{n_q - 1} earlier drivers + 1, tightly-pack, {args.nodes} nodes, host entry point incl. H2D/D2H",
                   "p50_ms": _percentile(cold[warm_n:], 0.5), "p99_ms": _percentile(cold[warm_n:], 0.99), "max_ms": max(cold[warm_n:]),
                   "calls": len(cold) - warm_n, "heads": "a different head (rotation of the queue) per call: every chain replays from the snapshot",
@@ -553,12 +628,14 @@ def main():
                                                     f"chains of {n_q - span + 1} .. {n_q} applications resumed from the previous chain's checkpoints"),
                   "warm_same_head": summary(retry, st_retry, warm_n)}
             # shader cycles of one cold chain (in-kernel clock of the profiled variant of the same kernel)
-            ctx.set_option("chain_cache", 0)
-            ctx.scan_stats(enable=True, reset=True)
-            chain_call(N.ptr(rolled_all[1]), n_q)
-            ctx.scan_stats(enable=False, reset=False)
-            ctx.set_option("chain_cache", 1)
-            cyc, ticks = ctx.last_fifo_clock
+            cyc = ticks = 0
+            if protos >= {"cold", "warm", "retry"}:  # (left out of the counter passes: their launches are all plain cold chains)
+                ctx.set_option("chain_cache", 0)
+                ctx.scan_stats(enable=True, reset=True)
+                chain_call(N.ptr(rolled_all[1]), n_q)
+                ctx.scan_stats(enable=False, reset=False)
+                ctx.set_option("chain_cache", 1)
+                cyc, ticks = ctx.last_fifo_clock
             pmc = None
             pmc_path2 = os.path.join(REPO, "profiles", "pmc_chain.json")
             if os.path.exists(pmc_path2):
@@ -917,22 +994,7 @@ def main():
                 c5["cpu_baseline_chain"] = cpu_chain_baseline(0, a5, None, None, D5, X5, w5.drv, w5.exe, w5.k, w5.flags, reps=3)
             extras["config5_100k_nodes_fifo"] = c5
             # BASELINE config 3: 10 000 nodes x 10 000 pending apps, both plain packers, device resident
-            w3 = wl.config(3)
-            ctx.set_snapshot(w3.snapshot.avail, w3.snapshot.sched)
-            ctx.set_orders(w3.snapshot.driver_order, w3.snapshot.exec_order)
-            apps3, total_k3 = gangfit.with_offsets(gangfit.make_apps(w3.drv, w3.exe, w3.k, w3.flags))
-            d_apps3 = torch.from_numpy(apps3.view(np.uint8).copy()).to(dev)
-            d_res3 = torch.zeros(len(apps3) * 16, dtype=torch.uint8, device=dev)
-            d_exec3 = torch.zeros(total_k3 + 1, dtype=torch.int32, device=dev)
-            c3 = {}
-            for name, algo in (("tightly_pack", TIGHT), ("distribute_evenly", EVEN)):
-                def step3():
-                    ctx.fit_batch_dev(IND, algo, len(apps3), d_apps3.data_ptr(), d_res3.data_ptr(), d_exec3.data_ptr(), total_k3,
-                                      stream=stream)
-                wall_3, kern_3, _, how3 = timed_graph(step3, 20, 3, 5)
-                c3[name] = {"decisions_per_s": len(apps3) * 20 / wall_3, "kernel_ms": kern_3, "submission": how3,
-                            "algorithmic_full_scan_GBps": wl.algorithmic_bytes(len(w3.snapshot.exec_order), w3.k) / (kern_3 * 1e-3) / 1e9}
-            extras["config3_10k_nodes_x_10k_apps"] = c3
+            extras["config3_10k_nodes_x_10k_apps"] = run_config3(ctx, torch, dev, stream, timed_graph)
         except Exception as e:  # keep what was measured; the headline line must still be printed
             import traceback
 

@@ -211,7 +211,6 @@ struct gf_ctx {
     // gf_snapshot_build
     DeviceBuf<int64_t> d_bi64;   // alloc | overhead | usage | avail | sched (3n each) | keys_a | keys_b (n each) | res_req (3r) | zone_sum
     DeviceBuf<uint32_t> d_bu32;  // zone | name_rank | perm_a | perm_b (n each) | res_node (r) | zone_order | zone_rank
-    DeviceBuf<unsigned char> d_btemp;
     PinnedBuf<int64_t> h_bcols;  // avail | sched (3n each)
     PinnedBuf<uint32_t> h_border;
 
@@ -967,7 +966,6 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_delta_u32.release();
     ctx->d_bi64.release();
     ctx->d_bu32.release();
-    ctx->d_btemp.release();
     ctx->h_bcols.release();
     ctx->h_border.release();
     ctx->d_xexe.release();
@@ -2012,8 +2010,6 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     GF_HIP(ctx, gf_wait_stream(st));  // nothing in flight may still read buffers that are about to grow
     GF_HIP(ctx, ctx->d_bi64.reserve(9 * N + 2 * N + 3 * R + 3 * Z + 6 * NCH + 16));
     GF_HIP(ctx, ctx->d_bu32.reserve(2 * N + R + 5 * Z + 16));
-    const size_t temp = gangfit::snapshot_sort_temp_bytes(n);
-    GF_HIP(ctx, ctx->d_btemp.reserve(temp + 16));
     int64_t* d_alloc = ctx->d_cl_i64.ptr;
     int64_t* d_over = d_alloc + 3 * N;
     int64_t* d_usage = ctx->d_bi64.ptr;
@@ -2065,8 +2061,6 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     b.d_perm_b = d_perm_b;
     b.d_keys_a = d_keys_a;
     b.d_keys_b = d_keys_b;
-    b.d_temp = ctx->d_btemp.ptr;
-    b.temp_bytes = temp;
     GF_HIP(ctx, gangfit::launch_snapshot_build(b, st));
     if (ctx->snapshot_finalize_on_device && !driver_label_rank && !exec_label_rank) {
         // ---- the slot tables on the device too: nothing of size O(n_nodes) returns to the host unless the caller asks

@@ -278,8 +278,6 @@ struct SnapshotBuild {
     uint32_t* d_perm_b;          // n_nodes
     int64_t* d_keys_a;           // n_nodes
     int64_t* d_keys_b;           // n_nodes
-    void* d_temp;                // radix-sort scratch
-    size_t temp_bytes;
 };
 // usage[node] += sign * entry for n_entries reservation entries (columns cpu | memory | gpu of d_req); entries on nodes
 // >= n_nodes are ignored.
@@ -317,7 +315,6 @@ hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t strea
 hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_stream_read(const void* src, size_t bytes, uint32_t* sink, hipStream_t stream);
 hipError_t launch_empty(uint32_t* sink, hipStream_t stream);
-size_t snapshot_sort_temp_bytes(uint32_t n_nodes);
 hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream);
 
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.

@@ -7,10 +7,9 @@
 // zone ids, the lexicographic rank of every node name).  The reservation replay is a scatter-add (64-bit atomics; at
 // 20 k reservations x 13 entries the table is L2 resident), available/schedulable are one fused elementwise pass that
 // also accumulates the per-zone free resources, and the priority order (zone rank, free memory, free cpu, name) is an
-// LSD sequence of three stable radix sorts over a permutation that starts in name order.  The radix sort itself is
-// rocPRIM's (through hipCUB), the way a GEMM would come from rocBLAS; everything else is written here.
+// stable LSD radix sort of ONE composite key per node over a permutation that starts in name order
+// (priority_sort_kernel below: one workgroup, one launch; no sorting library).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include "gangfit_device.h"
 
@@ -114,23 +113,279 @@ __global__ void zone_rank_kernel(uint32_t n_zones, const long long* __restrict__
     for (uint32_t i = 0; i < n_zones; ++i) rank[order[i]] = i;
 }
 
-__global__ void name_order_kernel(uint32_t n_nodes, const uint32_t* __restrict__ name_rank, uint32_t* __restrict__ perm) {
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < n_nodes) perm[name_rank[n]] = n;  // name_rank is a permutation (validated by the host layer)
-}
+// ------------------------------------------------------------------------------------------------ the priority order
+// getNodeNamesInPriorityOrder (internal/sort/nodesorting.go:95-122): nodes by (zone rank, free memory, free cpu, name), all
+// ascending.  One workgroup of sixteen wavefronts, one launch:
+//   1. range of every column (min, max, OR of value - min): a field needs bits(max - min) bits, less its common trailing
+//      zeros (free memory is a multiple of hundreds of MiB on real clusters: 39 bits shrink to about 11);
+//   2. the fields are packed into ONE 64-bit key per node — zone rank | memory | cpu — when they fit (they do unless the
+//      quantities are adversarial: then two or three keys are sorted one after the other, least significant first);
+//   3. stable LSD radix sort of (key, node) pairs, 8 bits per pass, starting from the name order (the final tie-break):
+//      every wavefront owns a contiguous segment, counts its digits with a ballot-built peer mask per 64 elements (no
+//      atomics), the 16 x 256 counts are scanned digit-major, and the scatter ranks every element inside its 64-element
+//      chunk with the same peer mask.  Passes whose digit is zero in every key are skipped.
+// Keys and permutation ping-pong between two global buffers (L2 resident: 1.2 MB at 100 000 nodes); a workgroup shares one
+// L1, so a barrier with vmcnt(0) orders one pass's stores before the next pass's loads.
+constexpr int kSortWaves = 16;
+constexpr int kSortThreads = kSortWaves * 64;
+constexpr int kSortTile = 8;  // 64-element chunks a wavefront has in flight per step (independent loads)
 
-__global__ void gather_i64_kernel(uint32_t n, const uint32_t* __restrict__ perm, const int64_t* __restrict__ col,
-                                  int64_t* __restrict__ keys) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = col[perm[i]];
-}
+struct PrioritySort {
+    uint32_t n, n_zones;
+    const int64_t* cpu;        // free cpu by node
+    const int64_t* mem;        // free memory by node
+    const uint32_t* zone;      // zone id by node
+    const uint32_t* zrank;     // zone id -> rank
+    const uint32_t* name_rank; // node -> rank of its name (a permutation)
+    unsigned long long* keys_a;
+    unsigned long long* keys_b;
+    uint32_t* perm_a;
+    uint32_t* perm_b;          // receives the result: position -> node
+};
 
-__global__ void gather_zone_rank_kernel(uint32_t n, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ zone,
-                                        const uint32_t* __restrict__ zrank, uint32_t n_zones, int64_t* __restrict__ keys) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t z = zone[perm[i]];
-    keys[i] = z < n_zones ? (int64_t)zrank[z] : (int64_t)n_zones;
+struct SortShared {
+    uint32_t hist[kSortWaves][256];  // counts, then running offsets, of (wavefront, digit)
+    unsigned long long red[3][kSortWaves];
+    unsigned long long cmin, mmin, key_or;
+    uint32_t tzc, tzm, wc, wm, wz;
+};
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t bits_of(unsigned long long v) { return v ? 64u - (uint32_t)__clzll(v) : 0u; }
+
+// order-preserving map of a signed quantity to unsigned
+__device__ __forceinline__ unsigned long long biased(int64_t v) { return (unsigned long long)v ^ 0x8000000000000000ull; }
+
+__global__ __launch_bounds__(kSortThreads) void priority_sort_kernel(PrioritySort A) {
+    __shared__ SortShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n = A.n;
+    // ---- 1. column ranges; the permutation starts in name order
+    unsigned long long cmn = ~0ull, cmx = 0ull, mmn = ~0ull, mmx = 0ull;
+    for (uint32_t i = tid; i < n; i += kSortThreads) {
+        const unsigned long long c = biased(A.cpu[i]), m = biased(A.mem[i]);
+        cmn = c < cmn ? c : cmn;
+        cmx = c > cmx ? c : cmx;
+        mmn = m < mmn ? m : mmn;
+        mmx = m > mmx ? m : mmx;
+        A.perm_a[A.name_rank[i]] = i;
+    }
+    cmn = wave_min_u64(cmn);
+    cmx = wave_max_u64(cmx);
+    mmn = wave_min_u64(mmn);
+    mmx = wave_max_u64(mmx);
+    if (lane == 0) {
+        sh.red[0][wave] = cmn;
+        sh.red[1][wave] = cmx;
+        sh.red[2][wave] = mmn;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long a = lane < kSortWaves ? sh.red[0][lane] : ~0ull, b = lane < kSortWaves ? sh.red[1][lane] : 0ull,
+                           c = lane < kSortWaves ? sh.red[2][lane] : ~0ull;
+        a = wave_min_u64(a);
+        b = wave_max_u64(b);
+        c = wave_min_u64(c);
+        if (lane == 0) {
+            sh.cmin = a;
+            sh.mmin = c;
+            sh.red[1][0] = b;
+        }
+    }
+    __syncthreads();
+    const unsigned long long cmin = sh.cmin, mmin = sh.mmin, cmax = sh.red[1][0];
+    __syncthreads();
+    if (lane == 0) sh.red[0][wave] = mmx;
+    unsigned long long cor = 0ull, mor = 0ull;  // common trailing zeros of the offsets
+    for (uint32_t i = tid; i < n; i += kSortThreads) {
+        cor |= biased(A.cpu[i]) - cmin;
+        mor |= biased(A.mem[i]) - mmin;
+    }
+    cor = wave_or_u64(cor);
+    mor = wave_or_u64(mor);
+    if (lane == 0) {
+        sh.red[1][wave] = cor;
+        sh.red[2][wave] = mor;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        unsigned long long a = lane < kSortWaves ? sh.red[0][lane] : 0ull, b = lane < kSortWaves ? sh.red[1][lane] : 0ull,
+                           c = lane < kSortWaves ? sh.red[2][lane] : 0ull;
+        a = wave_max_u64(a);
+        b = wave_or_u64(b);
+        c = wave_or_u64(c);
+        if (lane == 0) {
+            const uint32_t tzc = b ? (uint32_t)__ffsll((long long)b) - 1u : 0u, tzm = c ? (uint32_t)__ffsll((long long)c) - 1u : 0u;
+            sh.tzc = tzc;
+            sh.tzm = tzm;
+            sh.wc = bits_of((cmax - cmin) >> tzc);
+            sh.wm = bits_of((a - mmin) >> tzm);
+            sh.wz = bits_of((unsigned long long)A.n_zones);  // unknown zone ids rank behind every zone (value n_zones)
+        }
+    }
+    __syncthreads();
+    const uint32_t tzc = sh.tzc, tzm = sh.tzm, wc = sh.wc, wm = sh.wm, wz = sh.wz;
+    // ---- 2. key groups, least significant first: {cpu, mem, zone} | {cpu} {mem, zone} | {cpu} {mem} {zone}
+    const uint32_t n_groups = (wc + wm + wz <= 64u) ? 1u : ((wm + wz <= 64u) ? 2u : 3u);
+    unsigned long long* kin = A.keys_a;
+    unsigned long long* kout = A.keys_b;
+    uint32_t* pin = A.perm_a;
+    uint32_t* pout = A.perm_b;
+    const uint32_t seg = ((n + kSortWaves - 1) / kSortWaves + 63u) & ~63u;  // elements per wavefront, whole chunks
+    const uint32_t lo = wave * seg < n ? wave * seg : n, hi = lo + seg < n ? lo + seg : n;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const bool has_c = g == 0, has_m = n_groups == 1 || g == 1, has_z = g + 1 == n_groups;
+        const uint32_t width = (has_c ? wc : 0u) + (has_m ? wm : 0u) + (has_z ? wz : 0u);
+        // keys of this group for the current order
+        __syncthreads();
+        unsigned long long kor = 0ull;
+        for (uint32_t i = tid; i < n; i += kSortThreads) {
+            const uint32_t node = pin[i];
+            unsigned long long key = 0ull;
+            uint32_t sft = 0;
+            if (has_c) {
+                key = (biased(A.cpu[node]) - cmin) >> tzc;
+                sft = wc;
+            }
+            if (has_m) {
+                if (sft < 64u) key |= ((biased(A.mem[node]) - mmin) >> tzm) << sft;
+                sft += wm;
+            }
+            if (has_z) {
+                const uint32_t z = A.zone[node];
+                const unsigned long long zr = z < A.n_zones ? A.zrank[z] : A.n_zones;
+                if (sft < 64u) key |= zr << sft;
+            }
+            kin[i] = key;
+            kor |= key;
+        }
+        kor = wave_or_u64(kor);
+        if (lane == 0) sh.red[0][wave] = kor;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long o = 0ull;
+            for (int w = 0; w < kSortWaves; ++w) o |= sh.red[0][w];
+            sh.key_or = o;
+        }
+        __syncthreads();
+        const unsigned long long key_or = sh.key_or;
+        for (uint32_t shift = 0; shift < width; shift += 8u) {
+            if (((key_or >> shift) & 255ull) == 0ull) continue;  // every key has digit 0 here: the pass is the identity
+            // ---- counts per (wavefront, digit)
+            for (uint32_t i = tid; i < kSortWaves * 256u; i += kSortThreads) (&sh.hist[0][0])[i] = 0u;
+            __syncthreads();
+            for (uint32_t base = lo; base < hi; base += 64u * kSortTile) {
+                unsigned long long k[kSortTile];
+#pragma unroll
+                for (int t = 0; t < kSortTile; ++t) {
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    k[t] = i < hi ? kin[i] : 0ull;
+                }
+#pragma unroll
+                for (int t = 0; t < kSortTile; ++t) {
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    if (base + (uint32_t)t * 64u >= hi) break;  // wave-uniform
+                    const bool valid = i < hi;
+                    const uint32_t d = (uint32_t)(k[t] >> shift) & 255u;
+                    unsigned long long peers = __ballot(valid);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const bool bit = (d >> b) & 1u;
+                        const unsigned long long bal = __ballot(bit);
+                        peers &= bit ? bal : ~bal;
+                    }
+                    if (valid && (peers & lt_mask) == 0ull) sh.hist[wave][d] += (uint32_t)__popcll(peers);  // the peers' leader
+                }
+            }
+            __syncthreads();
+            // ---- digit-major exclusive scan: offset(w, d) = sum over d' < d of all counts + sum over w' < w of count(w', d)
+            uint32_t run = 0, incl = 0;
+            if (tid < 256u) {  // digit tid (wavefronts 0 .. 3)
+                for (int w = 0; w < kSortWaves; ++w) {
+                    const uint32_t c = sh.hist[w][tid];
+                    sh.hist[w][tid] = run;
+                    run += c;
+                }
+                incl = run;  // inclusive scan of the digit totals inside the wavefront
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o, 64);
+                    if ((int)lane >= o) incl += t;
+                }
+                if (lane == 63u) sh.red[1][wave] = incl;
+            }
+            __syncthreads();
+            if (tid < 256u) {
+                uint32_t before = 0;
+                for (uint32_t w = 0; w < wave; ++w) before += (uint32_t)sh.red[1][w];
+                const uint32_t digit_base = before + incl - run;
+                for (int w = 0; w < kSortWaves; ++w) sh.hist[w][tid] += digit_base;
+            }
+            __syncthreads();
+            // ---- stable scatter
+            for (uint32_t base = lo; base < hi; base += 64u * kSortTile) {
+                unsigned long long k[kSortTile];
+                uint32_t v[kSortTile];
+#pragma unroll
+                for (int t = 0; t < kSortTile; ++t) {
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    k[t] = i < hi ? kin[i] : 0ull;
+                    v[t] = i < hi ? pin[i] : 0u;
+                }
+#pragma unroll
+                for (int t = 0; t < kSortTile; ++t) {
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    if (base + (uint32_t)t * 64u >= hi) break;
+                    const bool valid = i < hi;
+                    const uint32_t d = (uint32_t)(k[t] >> shift) & 255u;
+                    unsigned long long peers = __ballot(valid);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const bool bit = (d >> b) & 1u;
+                        const unsigned long long bal = __ballot(bit);
+                        peers &= bit ? bal : ~bal;
+                    }
+                    uint32_t off = 0;
+                    if (valid) off = sh.hist[wave][d];
+                    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+                    // (LDS operations of a wavefront execute in order: every lane has read the offset before the leader moves it on)
+                    if (valid && rank == 0u) sh.hist[wave][d] = off + (uint32_t)__popcll(peers);
+                    if (valid) {
+                        kout[off + rank] = k[t];
+                        pout[off + rank] = v[t];
+                    }
+                }
+            }
+            __syncthreads();  // vmcnt(0) + barrier: the scattered pairs are visible to the whole workgroup
+            unsigned long long* tk = kin;
+            kin = kout;
+            kout = tk;
+            uint32_t* tp = pin;
+            pin = pout;
+            pout = tp;
+        }
+    }
+    // ---- the result belongs in perm_b
+    __syncthreads();
+    if (pin != A.perm_b)
+        for (uint32_t i = tid; i < n; i += kSortThreads) A.perm_b[i] = pin[i];
 }
 
 }  // namespace
@@ -405,14 +660,6 @@ hipError_t launch_empty(uint32_t* sink, hipStream_t stream) {
     return hipGetLastError();
 }
 
-size_t snapshot_sort_temp_bytes(uint32_t n_nodes) {
-    size_t bytes = 0;
-    int64_t* k = nullptr;
-    uint32_t* v = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, v, v, (int)n_nodes, 0, 64, (hipStream_t) nullptr);
-    return bytes;
-}
-
 hipError_t launch_usage_apply(uint32_t n_entries, uint32_t n_nodes, const uint32_t* d_node, const int64_t* d_req, int sign,
                               int64_t* d_usage, uint32_t* d_negative, hipStream_t stream) {
     if (n_entries == 0 || n_nodes == 0) return hipSuccess;
@@ -443,28 +690,12 @@ hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
                        b.d_zone, b.n_zones, b.d_avail, b.d_sched, reinterpret_cast<unsigned long long*>(b.d_zone_sum));
     hipLaunchKernelGGL(zone_rank_kernel, dim3(1), dim3(64), 0, stream, b.n_zones, (const long long*)b.d_zone_sum,
                        b.d_zone_order, b.d_zone_rank);
-    hipLaunchKernelGGL(name_order_kernel, grid, block, 0, stream, n, b.d_name_rank, b.d_perm_a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    // LSD: name order -> stable by cpu -> stable by memory -> stable by zone rank
-    uint32_t* in = b.d_perm_a;
-    uint32_t* out = b.d_perm_b;
-    size_t temp = b.temp_bytes;
-    for (int pass = 0; pass < 3; ++pass) {
-        if (pass < 2)
-            hipLaunchKernelGGL(gather_i64_kernel, grid, block, 0, stream, n, in,
-                               b.d_avail + (size_t)(pass == 0 ? 0 : 1) * n, b.d_keys_a);
-        else
-            hipLaunchKernelGGL(gather_zone_rank_kernel, grid, block, 0, stream, n, in, b.d_zone, b.d_zone_rank, b.n_zones,
-                               b.d_keys_a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        e = hipcub::DeviceRadixSort::SortPairs(b.d_temp, temp, b.d_keys_a, b.d_keys_b, in, out, (int)n, 0,
-                                              pass < 2 ? 64 : 32, stream);
-        if (e != hipSuccess) return e;
-        uint32_t* t = in;
-        in = out;
-        out = t;
-    }
-    // three passes: the result sits in d_perm_b
+    // (zone rank, free memory, free cpu, name): one launch, the result sits in d_perm_b
+    PrioritySort ps{n, b.n_zones, b.d_avail, b.d_avail + n, b.d_zone, b.d_zone_rank, b.d_name_rank,
+                    reinterpret_cast<unsigned long long*>(b.d_keys_a), reinterpret_cast<unsigned long long*>(b.d_keys_b),
+                    b.d_perm_a, b.d_perm_b};
+    hipLaunchKernelGGL(priority_sort_kernel, dim3(1), dim3(kSortThreads), 0, stream, ps);
     return hipGetLastError();
 }
 

@@ -289,3 +289,37 @@ def test_recorded_sequence_is_refused_after_an_install():
         step()
         torch.cuda.synchronize()
         assert np.array_equal(d_res.cpu().numpy(), first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spread", ["two-keys", "three-keys", "all-equal", "ties-by-name"])
+def test_priority_sort_key_groups(gf_ctx, spread):
+    """The hand-written priority sort (gangfit_snapshot.hip, priority_sort_kernel) packs (zone rank, free memory, free cpu)
+    into one 64-bit key when the ranges allow; quantities spread over the whole representable range need two or three keys
+    sorted one after the other.  Same order as the restatement in every case (nodesorting.go:95-122: zone rank, memory, cpu,
+    name — all ascending, negatives included)."""
+    n = 5000
+    rng = np.random.default_rng(len(spread))
+    c = _cluster(900 + len(spread), n, 0, 3, with_overhead=False, labels=False)
+    alloc = c["alloc"].copy()
+    if spread == "two-keys":      # memory needs ~61 bits, cpu ~20: cpu alone, then (zone, memory)
+        alloc[:, 1] = rng.integers(0, 1 << 61, size=n) | 1
+        alloc[:, 0] = rng.integers(0, 1 << 20, size=n)
+    elif spread == "three-keys":  # memory and cpu need ~61 bits each, and 4 000 zones 12 more
+        alloc[:, 1] = rng.integers(0, 1 << 61, size=n) | 1
+        alloc[:, 0] = rng.integers(0, 1 << 61, size=n) | 1
+        c["zone"] = rng.integers(0, 4000, size=n).astype(np.uint32)
+        c["n_zones"] = 4000
+    elif spread == "all-equal":   # no varying bit at all: the order is the name order
+        alloc[:] = alloc[0]
+        c["zone"] = np.zeros(n, dtype=np.uint32)
+        c["n_zones"] = 1
+    else:                         # a handful of distinct values: long runs decided by the name rank
+        alloc[:, 1] = rng.integers(0, 3, size=n) * GIB
+        alloc[:, 0] = rng.integers(0, 2, size=n) * 1000
+    c["alloc"] = alloc
+    c["res_node"], c["res_req"] = np.zeros(0, dtype=np.uint32), np.zeros((0, 3), dtype=np.int64)
+    D, X = gf_ctx.build_snapshot(**c)
+    avail, sched, rD, rX = ps.build(**c)
+    assert np.array_equal(gf_ctx.snapshot()[0], avail)
+    assert np.array_equal(D, rD) and np.array_equal(X, rX)

@@ -29,7 +29,7 @@ def main():
     pmc = collections.OrderedDict()
     for d in sorted(os.listdir(src)):
         f = os.path.join(src, d, "pmc_counter_collection.csv")
-        if not os.path.exists(f):
+        if not os.path.exists(f) or not d.startswith("pmc_"):  # chain_* / c3_* passes: separate commands, summarised below
             continue
         for r in csv.DictReader(open(f)):
             key = (r["Kernel_Name"], r["Counter_Name"])
@@ -89,7 +89,93 @@ def main():
         out.write("\nKernel resources (grid, workgroup, LDS, VGPR, SGPR): " +
                   "; ".join(f"{k}: {v}" for k, v in meta.items() if "fit_" in k) + "\n\n")
         out.write("## HBM traffic per launch\n\n```json\n" + json.dumps(tj, indent=1) + "\n```\n")
+    extra = chain_and_config3(tag, src, dst)
+    with open(os.path.join(dst, f"{tag}_summary.md"), "a") as out:
+        out.write(extra)
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
+
+
+def _bench_json(log):
+    """The one JSON line bench.py printed under rocprofv3 (its stdout is in the pass's .log)."""
+    if not os.path.exists(log):
+        return None
+    for line in reversed(open(log, errors="replace").read().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except Exception:
+                return None
+    return None
+
+
+def _pass(src, d):
+    f = os.path.join(src, d, "pmc_counter_collection.csv")
+    return list(csv.DictReader(open(f))) if os.path.exists(f) else []
+
+
+def chain_and_config3(tag, src, dst):
+    """profiles/pmc_chain.json (instructions per application of the plain FIFO chain: `--fifo-protocols cold`, every launch a
+    full replay of the headline chain) and profiles/pmc_config3.json (HBM bytes / L2 requests per config-3 launch, per packer),
+    plus their sections of the summary."""
+    md = ""
+    # ---- the chain
+    rows = [r for r in _pass(src, "chain_sq") if r["Kernel_Name"].startswith("fit_fifo_solo_kernel")]
+    if rows:
+        per = collections.OrderedDict()
+        for r in rows:
+            per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        mean = {c: sum(v) / len(v) for c, v in per.items()}
+        bj = _bench_json(os.path.join(src, "chain_sq.log")) or {}
+        n_apps = ((bj.get("roofline") or {}).get("fifo_chain") or {}).get("applications_per_chain") or 1000
+        insts = sum(mean.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+        cj = {"tag": tag, "kernel": "fit_fifo_solo_kernel", "launches": len(next(iter(per.values()))),
+              "applications_per_chain": n_apps, "per_launch": mean,
+              "fit_fifo_solo_instructions_per_app": insts / n_apps,
+              "note": "VALU + SALU + LDS + SMEM instructions of ALL sixteen wavefronts per application (the fifteen helpers only run "
+                      "the prologue, the checkpoint dumps and the epilogue); every launch is a full replay of the headline chain "
+                      "(bench.py --fifo-protocols cold)"}
+        kst = os.path.join(src, "stats_chain", "stats_kernel_stats.csv")
+        if os.path.exists(kst):
+            shutil.copy(kst, os.path.join(dst, f"{tag}_kernel_stats_chain.csv"))
+            for r in csv.DictReader(open(kst)):
+                if r["Name"].startswith("fit_fifo_solo_kernel"):
+                    cj["kernel_avg_ns"] = float(r["AverageNs"])
+                    cj["kernel_calls"] = int(r["Calls"])
+        json.dump(cj, open(os.path.join(dst, "pmc_chain.json"), "w"), indent=1)
+        md += ("\n## the plain FIFO chain alone (`--no-extras --fifo-protocols cold`: every launch replays the headline chain)\n\n"
+               "```json\n" + json.dumps(cj, indent=1) + "\n```\n")
+    # ---- config 3: the two packers are two instantiations of fit_independent_kernel (Kernel_Id in launch order)
+    c3 = {"tag": tag, "note": "bytes per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; L2 requests "
+                              "are 128-byte lines"}
+    names = ["tightly_pack", "distribute_evenly"]
+    for d, counters in (("c3_fetch", ["FETCH_SIZE"]), ("c3_write", ["WRITE_SIZE"]), ("c3_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]),
+                        ("c3_sq", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAIT_ANY"])):
+        rows = [r for r in _pass(src, d) if r["Kernel_Name"].startswith("fit_independent_kernel")]
+        ids = []
+        for r in rows:
+            if r["Kernel_Id"] not in ids:
+                ids.append(r["Kernel_Id"])
+        for i, kid in enumerate(ids[:2]):
+            for c in counters:
+                v = [float(r["Counter_Value"]) for r in rows if r["Kernel_Id"] == kid and r["Counter_Name"] == c]
+                if v:
+                    c3.setdefault(names[i], {})[c] = sum(v) / len(v)
+                    c3[names[i]]["launches"] = len(v)
+    for nme in names:
+        t = c3.get(nme)
+        if not t:
+            continue
+        rd, wr = t.get("FETCH_SIZE", 0.0) * 1024, t.get("WRITE_SIZE", 0.0) * 1024
+        t["hbm_bytes"] = 2 * rd + wr
+        t["l2_request_bytes"] = 128 * (t.get("TCC_HIT_sum", 0.0) + t.get("TCC_MISS_sum", 0.0))
+    kst = os.path.join(src, "stats_config3", "stats_kernel_stats.csv")
+    if os.path.exists(kst):
+        shutil.copy(kst, os.path.join(dst, f"{tag}_kernel_stats_config3.csv"))
+    if any(n in c3 for n in names):
+        json.dump(c3, open(os.path.join(dst, "pmc_config3.json"), "w"), indent=1)
+        md += ("\n## BASELINE config 3 alone (`bench.py --config3-only`: 10 000 nodes x 10 000 apps, both packers)\n\n```json\n" +
+               json.dumps(c3, indent=1) + "\n```\n")
+    return md
 
 
 if __name__ == "__main__":
