@@ -204,6 +204,7 @@ struct gf_ctx {
     bool usage_ok = true;                     // false after a failed update: the resident sums are unknown until gf_usage_reset
     uint64_t cluster_gen = 0, usage_gen = 0;  // bumped by gf_cluster_set / gf_usage_reset + gf_usage_apply (gf_generation)
     DeviceBuf<uint32_t> d_flag32;             // one device word for yes / no answers of small kernels
+    DeviceBuf<uint32_t> d_sortwork;           // count tables, grid barrier and scalars of the priority sort (gangfit_snapshot.hip)
     uint32_t cl_n = 0, cl_zones = 1;
     bool cl_over = false, have_cluster = false;
     int64_t cl_max_over[3] = {0, 0, 0};
@@ -938,6 +939,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_napps.release();
     ctx->chain.d_ckpt.release();
     ctx->d_flag32.release();
+    ctx->d_sortwork.release();
     ctx->d_wide_needed.release();
     ctx->d_capmat.release();
     ctx->d_mfhist.release();
@@ -2008,8 +2010,8 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     const size_t N = n, R = n_res, Z = n_zones;
     const size_t NCH = (N + 1 + 63) / 64;  // chunks of the slot space (nodes + sentinel)
     GF_HIP(ctx, gf_wait_stream(st));  // nothing in flight may still read buffers that are about to grow
-    GF_HIP(ctx, ctx->d_bi64.reserve(9 * N + 2 * N + 3 * R + 3 * Z + 6 * NCH + 16));
-    GF_HIP(ctx, ctx->d_bu32.reserve(2 * N + R + 5 * Z + 16));
+    GF_HIP(ctx, ctx->d_bi64.reserve(9 * N + 3 * N + 3 * R + 3 * Z + 6 * NCH + 16));
+    GF_HIP(ctx, ctx->d_bu32.reserve(3 * N + R + 5 * Z + 16));
     int64_t* d_alloc = ctx->d_cl_i64.ptr;
     int64_t* d_over = d_alloc + 3 * N;
     int64_t* d_usage = ctx->d_bi64.ptr;
@@ -2017,14 +2019,16 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     int64_t* d_sched = d_avail + 3 * N;
     int64_t* d_keys_a = d_sched + 3 * N;
     int64_t* d_keys_b = d_keys_a + N;
-    int64_t* d_res_req = d_keys_b + N;
+    int64_t* d_keys_c = d_keys_b + N;
+    int64_t* d_res_req = d_keys_c + N;
     int64_t* d_zone_sum = d_res_req + 3 * R;
     uint32_t* d_zone = ctx->d_cl_u32.ptr;
     uint32_t* d_name_rank = d_zone + N;
     uint32_t* d_flags = d_name_rank + N;
     uint32_t* d_perm_a = ctx->d_bu32.ptr;
     uint32_t* d_perm_b = d_perm_a + N;
-    uint32_t* d_res_node = d_perm_b + N;
+    uint32_t* d_perm_c = d_perm_b + N;
+    uint32_t* d_res_node = d_perm_c + N;
     uint32_t* d_zone_order = d_res_node + R;
     uint32_t* d_zone_rank = d_zone_order + Z;
     uint32_t* d_zfirst = d_zone_rank + Z;
@@ -2061,6 +2065,10 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     b.d_perm_b = d_perm_b;
     b.d_keys_a = d_keys_a;
     b.d_keys_b = d_keys_b;
+    b.d_keys_c = d_keys_c;
+    b.d_perm_c = d_perm_c;
+    GF_HIP(ctx, ctx->d_sortwork.reserve(gangfit::snapshot_sort_work_words()));
+    b.d_sort_work = ctx->d_sortwork.ptr;
     GF_HIP(ctx, gangfit::launch_snapshot_build(b, st));
     if (ctx->snapshot_finalize_on_device && !driver_label_rank && !exec_label_rank) {
         // ---- the slot tables on the device too: nothing of size O(n_nodes) returns to the host unless the caller asks
@@ -2113,7 +2121,10 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         uint32_t* h_scalars = ctx->h_border.ptr;
         GF_HIP(ctx, hipMemcpyAsync(h_units, d_units, 6 * sizeof(long long), hipMemcpyDeviceToHost, st));
         GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        GF_HIP(ctx, hipMemcpyAsync(h_scalars + 4, ctx->d_sortwork.ptr + gangfit::snapshot_sort_error_word(), sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
         GF_HIP(ctx, gf_wait_stream(st));
+        if (h_scalars[4] != 0) return fail(ctx, GF_ERR_HIP, "the priority sort's grid barrier gave up (device oversubscribed?)");
         const uint32_t nz = h_scalars[0];
         for (int j = 0; j < 3; ++j) {
             ctx->unit[j] = (int64_t)h_units[j];
@@ -2160,10 +2171,13 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         return GF_OK;
     }
     GF_HIP(ctx, ctx->h_bcols.reserve(6 * N));
-    GF_HIP(ctx, ctx->h_border.reserve(N));
+    GF_HIP(ctx, ctx->h_border.reserve(N + 8));
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_bcols.ptr, d_avail, 6 * N * sizeof(int64_t), hipMemcpyDeviceToHost, st));  // avail | sched
     GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_sortwork.ptr + gangfit::snapshot_sort_error_word(), sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
     GF_HIP(ctx, gf_wait_stream(st));
+    if (ctx->h_failed.ptr[0] != 0) return fail(ctx, GF_ERR_HIP, "the priority sort's grid barrier gave up (device oversubscribed?)");
     // ---- the two candidate lists (nodesorting.go:47-63) and the optional stable label re-sorts (:161-199)
     const int64_t* h_avail = ctx->h_bcols.ptr;
     const int64_t* h_sched = ctx->h_bcols.ptr + 3 * N;

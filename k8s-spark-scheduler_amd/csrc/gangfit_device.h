@@ -278,6 +278,9 @@ struct SnapshotBuild {
     uint32_t* d_perm_b;          // n_nodes
     int64_t* d_keys_a;           // n_nodes
     int64_t* d_keys_b;           // n_nodes
+    int64_t* d_keys_c;           // n_nodes
+    uint32_t* d_perm_c;          // n_nodes
+    uint32_t* d_sort_work;       // snapshot_sort_work_words() uint32 (8-byte aligned): count tables, barrier, scalars
 };
 // usage[node] += sign * entry for n_entries reservation entries (columns cpu | memory | gpu of d_req); entries on nodes
 // >= n_nodes are ignored.
@@ -315,6 +318,8 @@ hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t strea
 hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_stream_read(const void* src, size_t bytes, uint32_t* sink, hipStream_t stream);
 hipError_t launch_empty(uint32_t* sink, hipStream_t stream);
+size_t snapshot_sort_work_words();     // uint32 words of SnapshotBuild::d_sort_work
+uint32_t snapshot_sort_error_word();   // index of the word that is non-zero when the sort's grid barrier gave up
 hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream);
 
 // Device self-test of the wave primitives (DPP scan, exact clamped division) against plain reference code.

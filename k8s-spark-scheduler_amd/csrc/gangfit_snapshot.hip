@@ -44,12 +44,31 @@ __global__ void usage_negative_kernel(uint32_t n_res, uint32_t n_nodes, const ui
     if (usage[n] < 0 || usage[(size_t)n_nodes + n] < 0 || usage[2 * (size_t)n_nodes + n] < 0) atomicOr(negative, 1u);
 }
 
+// order-preserving map of a signed quantity to unsigned
+__device__ __forceinline__ unsigned long long biased(int64_t v) { return (unsigned long long)v ^ 0x8000000000000000ull; }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Also feeds the priority sort that follows (priority_sort_kernel): the permutation in name order (perm[name_rank[n]] = n) and
+// the ranges of the two sort columns — sort_scal: max ~cpu | max cpu | max ~mem | max mem | OR (cpu - cpu[0]) | OR (mem - mem[0])
+// over the biased free values (all zero at launch).
 __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const int64_t* __restrict__ alloc,
                                                        const int64_t* __restrict__ overhead,
                                                        const int64_t* __restrict__ usage, const uint32_t* __restrict__ zone,
                                                        uint32_t n_zones, int64_t* __restrict__ avail,
                                                        int64_t* __restrict__ sched,
-                                                       unsigned long long* __restrict__ zone_sum) {
+                                                       unsigned long long* __restrict__ zone_sum,
+                                                       const uint32_t* __restrict__ name_rank, uint32_t* __restrict__ name_order,
+                                                       unsigned long long* __restrict__ sort_scal) {
     __shared__ unsigned long long zacc[3 * kZoneLdsMax];  // memory | cpu | population per zone
     const bool in_lds = n_zones <= kZoneLdsMax;
     if (in_lds) {
@@ -57,6 +76,7 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
         __syncthreads();
     }
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ncmn = 0ull, cmx = 0ull, nmmn = 0ull, mmx = 0ull, cor = 0ull, mor = 0ull;
     if (n < n_nodes) {
         int64_t a[3];
         for (int j = 0; j < 3; ++j) {
@@ -65,6 +85,20 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
             a[j] = alloc[k] - (usage[k] + o);
             avail[k] = a[j];
             sched[k] = alloc[k] - o;
+        }
+        {
+            // node 0's free cpu / memory: the reference point of the common trailing zeros (every difference to the minimum
+            // shares the trailing zeros of the differences to ANY one element)
+            const int64_t o0 = overhead != nullptr ? overhead[0] : 0, o1 = overhead != nullptr ? overhead[n_nodes] : 0;
+            const unsigned long long c0 = biased(alloc[0] - (usage[0] + o0)), m0 = biased(alloc[n_nodes] - (usage[n_nodes] + o1));
+            const unsigned long long c = biased(a[0]), m = biased(a[1]);
+            ncmn = ~c;
+            cmx = c;
+            nmmn = ~m;
+            mmx = m;
+            cor = c - c0;
+            mor = m - m0;
+            name_order[name_rank[n]] = n;  // name_rank is a permutation (validated by the host layer)
         }
         const uint32_t z = zone[n];
         if (z < n_zones) {
@@ -78,6 +112,20 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
                 atomicAdd(&zone_sum[2 * (size_t)n_zones + z], 1ull);                // population
             }
         }
+    }
+    ncmn = wave_max_u64(ncmn);
+    cmx = wave_max_u64(cmx);
+    nmmn = wave_max_u64(nmmn);
+    mmx = wave_max_u64(mmx);
+    cor = wave_or_u64(cor);
+    mor = wave_or_u64(mor);
+    if ((threadIdx.x & 63u) == 0 && (n < n_nodes)) {  // lane 0 of a wavefront that holds nodes
+        atomicMax(&sort_scal[0], ncmn);
+        atomicMax(&sort_scal[1], cmx);
+        atomicMax(&sort_scal[2], nmmn);
+        atomicMax(&sort_scal[3], mmx);
+        if (cor) atomicOr(&sort_scal[4], cor);
+        if (mor) atomicOr(&sort_scal[5], mor);
     }
     if (in_lds) {
         __syncthreads();
@@ -115,20 +163,27 @@ __global__ void zone_rank_kernel(uint32_t n_zones, const long long* __restrict__
 
 // ------------------------------------------------------------------------------------------------ the priority order
 // getNodeNamesInPriorityOrder (internal/sort/nodesorting.go:95-122): nodes by (zone rank, free memory, free cpu, name), all
-// ascending.  One workgroup of sixteen wavefronts, one launch:
-//   1. range of every column (min, max, OR of value - min): a field needs bits(max - min) bits, less its common trailing
-//      zeros (free memory is a multiple of hundreds of MiB on real clusters: 39 bits shrink to about 11);
+// ascending.  ONE launch of kSortWG single-wavefront workgroups (cooperative: all resident) that meet at a grid barrier:
+//   1. the range of every column comes from metadata_kernel (min, max, common trailing zeros of the differences): a field
+//      needs bits(max - min) bits, less the trailing zeros every difference shares (free memory is a multiple of hundreds
+//      of MiB on real clusters: 39 bits shrink to about 11);
 //   2. the fields are packed into ONE 64-bit key per node — zone rank | memory | cpu — when they fit (they do unless the
 //      quantities are adversarial: then two or three keys are sorted one after the other, least significant first);
-//   3. stable LSD radix sort of (key, node) pairs, 8 bits per pass, starting from the name order (the final tie-break):
-//      every wavefront owns a contiguous segment, counts its digits with a ballot-built peer mask per 64 elements (no
-//      atomics), the 16 x 256 counts are scanned digit-major, and the scatter ranks every element inside its 64-element
-//      chunk with the same peer mask.  Passes whose digit is zero in every key are skipped.
-// Keys and permutation ping-pong between two global buffers (L2 resident: 1.2 MB at 100 000 nodes); a workgroup shares one
-// L1, so a barrier with vmcnt(0) orders one pass's stores before the next pass's loads.
-constexpr int kSortWaves = 16;
-constexpr int kSortThreads = kSortWaves * 64;
-constexpr int kSortTile = 8;  // 64-element chunks a wavefront has in flight per step (independent loads)
+//   3. stable LSD radix sort of (key, node) pairs, 8 bits per pass, starting from the name order (the final tie-break).
+//      Every wavefront owns a contiguous segment.  A pass: read the 64 x 256 digit counts, derive the segment's 256 output
+//      offsets (digit-major exclusive scan, done redundantly by every wavefront: 64 KB of L2 reads instead of a barrier),
+//      rank each element inside its 64-element chunk with a ballot-built peer mask (stable, no atomics on the offsets),
+//      scatter — and count the NEXT pass's digit into the destination segment's row while the key is in a register
+//      (order-free atomic adds).  A pass therefore costs ONE grid barrier, the key build (which counts the first digit) one,
+//      and the last pass none: three rotating buffers are walked so that it lands in the output array.
+// A wavefront alone on its SIMD issues at its full rate; 64 of them sort 100 000 nodes in a fraction of the millisecond one
+// workgroup needed (860 us measured) and of the two dozen launches of a sorting library.  What is left is the barrier: the
+// XCDs' L2s are not coherent with each other, so each one is a write-back, an invalidate and a round trip to memory.
+constexpr uint32_t kSortWG = 64;          // workgroups = wavefronts
+constexpr int kSortTile = 8;              // 64-element chunks a wavefront has in flight per step (independent loads)
+constexpr uint32_t kSortHistWords = 3u * kSortWG * 256u;  // three rotating count tables [segment][digit]
+constexpr uint32_t kSortStateWords = 4u;  // barrier count | barrier generation | error | spare
+constexpr uint32_t kSortScalars = 16u;    // 64-bit words behind the state (the first six: metadata_kernel's ranges)
 
 struct PrioritySort {
     uint32_t n, n_zones;
@@ -136,210 +191,181 @@ struct PrioritySort {
     const int64_t* mem;        // free memory by node
     const uint32_t* zone;      // zone id by node
     const uint32_t* zrank;     // zone id -> rank
-    const uint32_t* name_rank; // node -> rank of its name (a permutation)
-    unsigned long long* keys_a;
-    unsigned long long* keys_b;
-    uint32_t* perm_a;
-    uint32_t* perm_b;          // receives the result: position -> node
+    unsigned long long* keys[3];
+    uint32_t* perm[3];         // [0] holds the name order at launch, [1] receives the result: position -> node
+    uint32_t* work;            // kSortHistWords + kSortStateWords uint32 + kSortScalars uint64; zero at launch but the ranges
 };
 
-struct SortShared {
-    uint32_t hist[kSortWaves][256];  // counts, then running offsets, of (wavefront, digit)
-    unsigned long long red[3][kSortWaves];
-    unsigned long long cmin, mmin, key_or;
-    uint32_t tzc, tzm, wc, wm, wz;
-};
-
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ uint32_t bits_of(unsigned long long v) { return v ? 64u - (uint32_t)__clzll(v) : 0u; }
 
-// order-preserving map of a signed quantity to unsigned
-__device__ __forceinline__ unsigned long long biased(int64_t v) { return (unsigned long long)v ^ 0x8000000000000000ull; }
+// Grid barrier of the kSortWG single-wavefront workgroups (sense by generation).  Everything a wavefront wrote before is
+// visible to every wavefront behind it (agent-scope release / acquire: the XCDs' L2s are written back and invalidated).
+// false = the others did not arrive (never expected with a cooperative launch): the caller flags the error and leaves.
+__device__ __forceinline__ bool sort_grid_sync(uint32_t* state, int lane) {
+    int ok = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+        const uint32_t gen = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t arrived = __hip_atomic_fetch_add(&state[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == kSortWG - 1u) {
+            __hip_atomic_store(&state[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&state[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&state[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) {
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+    }
+    ok = __shfl(ok, 0, 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok != 0;
+}
 
-__global__ __launch_bounds__(kSortThreads) void priority_sort_kernel(PrioritySort A) {
-    __shared__ SortShared sh;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+// the peers of a lane: the valid lanes of the chunk that hold the same digit (eight ballots)
+__device__ __forceinline__ unsigned long long digit_peers(uint32_t d, bool valid) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+__global__ __launch_bounds__(64) void priority_sort_kernel(PrioritySort A) {
+    __shared__ uint32_t off[256];  // this segment's next output position per digit
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
     const uint32_t n = A.n;
-    // ---- 1. column ranges; the permutation starts in name order
-    unsigned long long cmn = ~0ull, cmx = 0ull, mmn = ~0ull, mmx = 0ull;
-    for (uint32_t i = tid; i < n; i += kSortThreads) {
-        const unsigned long long c = biased(A.cpu[i]), m = biased(A.mem[i]);
-        cmn = c < cmn ? c : cmn;
-        cmx = c > cmx ? c : cmx;
-        mmn = m < mmn ? m : mmn;
-        mmx = m > mmx ? m : mmx;
-        A.perm_a[A.name_rank[i]] = i;
+    uint32_t* const hist = A.work;
+    uint32_t* const state = A.work + kSortHistWords;
+    const unsigned long long* const scal = reinterpret_cast<const unsigned long long*>(A.work + kSortHistWords + kSortStateWords);
+#define GF_SORT_SYNC()                                            \
+    if (!sort_grid_sync(state, (int)lane)) {                      \
+        if (lane == 0) atomicOr(&state[2], 1u);                   \
+        return;                                                   \
     }
-    cmn = wave_min_u64(cmn);
-    cmx = wave_max_u64(cmx);
-    mmn = wave_min_u64(mmn);
-    mmx = wave_max_u64(mmx);
-    if (lane == 0) {
-        sh.red[0][wave] = cmn;
-        sh.red[1][wave] = cmx;
-        sh.red[2][wave] = mmn;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long a = lane < kSortWaves ? sh.red[0][lane] : ~0ull, b = lane < kSortWaves ? sh.red[1][lane] : 0ull,
-                           c = lane < kSortWaves ? sh.red[2][lane] : ~0ull;
-        a = wave_min_u64(a);
-        b = wave_max_u64(b);
-        c = wave_min_u64(c);
-        if (lane == 0) {
-            sh.cmin = a;
-            sh.mmin = c;
-            sh.red[1][0] = b;
-        }
-    }
-    __syncthreads();
-    const unsigned long long cmin = sh.cmin, mmin = sh.mmin, cmax = sh.red[1][0];
-    __syncthreads();
-    if (lane == 0) sh.red[0][wave] = mmx;
-    unsigned long long cor = 0ull, mor = 0ull;  // common trailing zeros of the offsets
-    for (uint32_t i = tid; i < n; i += kSortThreads) {
-        cor |= biased(A.cpu[i]) - cmin;
-        mor |= biased(A.mem[i]) - mmin;
-    }
-    cor = wave_or_u64(cor);
-    mor = wave_or_u64(mor);
-    if (lane == 0) {
-        sh.red[1][wave] = cor;
-        sh.red[2][wave] = mor;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        unsigned long long a = lane < kSortWaves ? sh.red[0][lane] : 0ull, b = lane < kSortWaves ? sh.red[1][lane] : 0ull,
-                           c = lane < kSortWaves ? sh.red[2][lane] : 0ull;
-        a = wave_max_u64(a);
-        b = wave_or_u64(b);
-        c = wave_or_u64(c);
-        if (lane == 0) {
-            const uint32_t tzc = b ? (uint32_t)__ffsll((long long)b) - 1u : 0u, tzm = c ? (uint32_t)__ffsll((long long)c) - 1u : 0u;
-            sh.tzc = tzc;
-            sh.tzm = tzm;
-            sh.wc = bits_of((cmax - cmin) >> tzc);
-            sh.wm = bits_of((a - mmin) >> tzm);
-            sh.wz = bits_of((unsigned long long)A.n_zones);  // unknown zone ids rank behind every zone (value n_zones)
-        }
-    }
-    __syncthreads();
-    const uint32_t tzc = sh.tzc, tzm = sh.tzm, wc = sh.wc, wm = sh.wm, wz = sh.wz;
+    // ---- 1. field widths from the column ranges
+    const unsigned long long cmin = ~scal[0], cmax = scal[1], mmin = ~scal[2], mmax = scal[3];
+    const uint32_t tzc = scal[4] ? (uint32_t)__ffsll((long long)scal[4]) - 1u : 0u;
+    const uint32_t tzm = scal[5] ? (uint32_t)__ffsll((long long)scal[5]) - 1u : 0u;
+    const uint32_t wc = bits_of((cmax - cmin) >> tzc), wm = bits_of((mmax - mmin) >> tzm);
+    const uint32_t wz = bits_of((unsigned long long)A.n_zones);  // unknown zone ids rank behind every zone (value n_zones)
     // ---- 2. key groups, least significant first: {cpu, mem, zone} | {cpu} {mem, zone} | {cpu} {mem} {zone}
     const uint32_t n_groups = (wc + wm + wz <= 64u) ? 1u : ((wm + wz <= 64u) ? 2u : 3u);
-    unsigned long long* kin = A.keys_a;
-    unsigned long long* kout = A.keys_b;
-    uint32_t* pin = A.perm_a;
-    uint32_t* pout = A.perm_b;
-    const uint32_t seg = ((n + kSortWaves - 1) / kSortWaves + 63u) & ~63u;  // elements per wavefront, whole chunks
-    const uint32_t lo = wave * seg < n ? wave * seg : n, hi = lo + seg < n ? lo + seg : n;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t gw[3] = {0, 0, 0}, total_passes = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
         const bool has_c = g == 0, has_m = n_groups == 1 || g == 1, has_z = g + 1 == n_groups;
-        const uint32_t width = (has_c ? wc : 0u) + (has_m ? wm : 0u) + (has_z ? wz : 0u);
-        // keys of this group for the current order
-        __syncthreads();
-        unsigned long long kor = 0ull;
-        for (uint32_t i = tid; i < n; i += kSortThreads) {
-            const uint32_t node = pin[i];
-            unsigned long long key = 0ull;
-            uint32_t sft = 0;
-            if (has_c) {
-                key = (biased(A.cpu[node]) - cmin) >> tzc;
-                sft = wc;
-            }
-            if (has_m) {
-                if (sft < 64u) key |= ((biased(A.mem[node]) - mmin) >> tzm) << sft;
-                sft += wm;
-            }
-            if (has_z) {
-                const uint32_t z = A.zone[node];
-                const unsigned long long zr = z < A.n_zones ? A.zrank[z] : A.n_zones;
-                if (sft < 64u) key |= zr << sft;
-            }
-            kin[i] = key;
-            kor |= key;
-        }
-        kor = wave_or_u64(kor);
-        if (lane == 0) sh.red[0][wave] = kor;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long o = 0ull;
-            for (int w = 0; w < kSortWaves; ++w) o |= sh.red[0][w];
-            sh.key_or = o;
-        }
-        __syncthreads();
-        const unsigned long long key_or = sh.key_or;
-        for (uint32_t shift = 0; shift < width; shift += 8u) {
-            if (((key_or >> shift) & 255ull) == 0ull) continue;  // every key has digit 0 here: the pass is the identity
-            // ---- counts per (wavefront, digit)
-            for (uint32_t i = tid; i < kSortWaves * 256u; i += kSortThreads) (&sh.hist[0][0])[i] = 0u;
-            __syncthreads();
-            for (uint32_t base = lo; base < hi; base += 64u * kSortTile) {
-                unsigned long long k[kSortTile];
-#pragma unroll
-                for (int t = 0; t < kSortTile; ++t) {
-                    const uint32_t i = base + (uint32_t)t * 64u + lane;
-                    k[t] = i < hi ? kin[i] : 0ull;
-                }
-#pragma unroll
-                for (int t = 0; t < kSortTile; ++t) {
-                    const uint32_t i = base + (uint32_t)t * 64u + lane;
-                    if (base + (uint32_t)t * 64u >= hi) break;  // wave-uniform
-                    const bool valid = i < hi;
-                    const uint32_t d = (uint32_t)(k[t] >> shift) & 255u;
-                    unsigned long long peers = __ballot(valid);
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const bool bit = (d >> b) & 1u;
-                        const unsigned long long bal = __ballot(bit);
-                        peers &= bit ? bal : ~bal;
+        gw[g] = (has_c ? wc : 0u) + (has_m ? wm : 0u) + (has_z ? wz : 0u);
+        total_passes += (gw[g] + 7u) / 8u;
+    }
+    // segments: a power of two of elements (whole chunks) so that the segment of an output position is a shift
+    uint32_t seg_log = 6;
+    while (((uint64_t)kSortWG << seg_log) < n) ++seg_log;
+    const uint32_t seg = 1u << seg_log;
+    const uint32_t n_seg = (n + seg - 1u) >> seg_log;  // segments that hold elements (<= kSortWG)
+    const uint32_t lo = ((uint64_t)wave << seg_log) < n ? wave << seg_log : n, hi = lo + seg < n ? lo + seg : n;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t src = 0;  // buffer that holds the current order
+    uint32_t P = 0;    // passes done so far (all groups): pass P reads count table P % 3, feeds (P + 1) % 3, clears (P + 2) % 3
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const bool has_c = g == 0, has_m = n_groups == 1 || g == 1, has_z = g + 1 == n_groups;
+        const uint32_t width = gw[g];
+        if (width == 0) continue;  // every key of the group equal: the order stands (uniform over the grid)
+        // ---- keys of this group in the current order (this wavefront's segment) + the counts of their first digit
+        {
+            unsigned long long* kin = A.keys[src];
+            const uint32_t* pin = A.perm[src];
+            for (uint32_t d = lane; d < 256u; d += 64u) off[d] = 0u;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            for (uint32_t base = lo; base < hi; base += 64u) {
+                const uint32_t i = base + lane;
+                const bool valid = i < hi;
+                unsigned long long key = 0ull;
+                if (valid) {
+                    const uint32_t node = pin[i];
+                    uint32_t sft = 0;
+                    if (has_c) {
+                        key = (biased(A.cpu[node]) - cmin) >> tzc;
+                        sft = wc;
                     }
-                    if (valid && (peers & lt_mask) == 0ull) sh.hist[wave][d] += (uint32_t)__popcll(peers);  // the peers' leader
+                    if (has_m) {
+                        if (sft < 64u) key |= ((biased(A.mem[node]) - mmin) >> tzm) << sft;
+                        sft += wm;
+                    }
+                    if (has_z) {
+                        const uint32_t z = A.zone[node];
+                        const unsigned long long zr = z < A.n_zones ? A.zrank[z] : A.n_zones;
+                        if (sft < 64u) key |= zr << sft;
+                    }
+                    kin[i] = key;
                 }
+                const uint32_t d = (uint32_t)key & 255u;
+                const unsigned long long peers = digit_peers(d, valid);
+                if (valid && (peers & lt_mask) == 0ull) off[d] += (uint32_t)__popcll(peers);  // the peers' leader
             }
-            __syncthreads();
-            // ---- digit-major exclusive scan: offset(w, d) = sum over d' < d of all counts + sum over w' < w of count(w', d)
-            uint32_t run = 0, incl = 0;
-            if (tid < 256u) {  // digit tid (wavefronts 0 .. 3)
-                for (int w = 0; w < kSortWaves; ++w) {
-                    const uint32_t c = sh.hist[w][tid];
-                    sh.hist[w][tid] = run;
-                    run += c;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            uint32_t* row = hist + ((size_t)(P % 3u) * kSortWG + wave) * 256u;
+            for (uint32_t d = lane; d < 256u; d += 64u) row[d] = off[d];
+        }
+        GF_SORT_SYNC()
+        for (uint32_t shift = 0; shift < width; shift += 8u) {
+            const uint32_t next = shift + 8u;
+            const bool feeds = next < width;
+            const uint32_t remaining = total_passes - P;  // passes left, this one included: the last one must land in buffer 1
+            const uint32_t dst_buf = (remaining & 1u) ? 1u : (src == 2u ? 0u : 2u);
+            const unsigned long long* kin = A.keys[src];
+            const uint32_t* pin = A.perm[src];
+            unsigned long long* kout = A.keys[dst_buf];
+            uint32_t* pout = A.perm[dst_buf];
+            const uint32_t* cur = hist + (size_t)(P % 3u) * kSortWG * 256u;
+            uint32_t* nxt = hist + (size_t)((P + 1u) % 3u) * kSortWG * 256u;
+            uint32_t* clr = hist + ((size_t)((P + 2u) % 3u) * kSortWG + wave) * 256u;
+            // ---- this segment's output offsets: digit-major exclusive scan over (digit, segment); lane l owns digits 4l .. 4l+3
+            {
+                uint32_t tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+                for (uint32_t r0 = 0; r0 < n_seg; r0 += 8u) {
+                    uint4 rows[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        rows[t] = (r0 + (uint32_t)t < n_seg) ? reinterpret_cast<const uint4*>(cur + (size_t)(r0 + t) * 256u)[lane]
+                                                             : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const bool before = r0 + (uint32_t)t < wave;
+                        tot[0] += rows[t].x;
+                        tot[1] += rows[t].y;
+                        tot[2] += rows[t].z;
+                        tot[3] += rows[t].w;
+                        pre[0] += before ? rows[t].x : 0u;
+                        pre[1] += before ? rows[t].y : 0u;
+                        pre[2] += before ? rows[t].z : 0u;
+                        pre[3] += before ? rows[t].w : 0u;
+                    }
                 }
-                incl = run;  // inclusive scan of the digit totals inside the wavefront
+                const uint32_t mine = tot[0] + tot[1] + tot[2] + tot[3];
+                uint32_t incl = mine;
                 for (int o = 1; o < 64; o <<= 1) {
                     const uint32_t t = __shfl_up(incl, o, 64);
                     if ((int)lane >= o) incl += t;
                 }
-                if (lane == 63u) sh.red[1][wave] = incl;
+                uint32_t base = incl - mine;
+                off[4 * lane + 0] = base + pre[0];
+                base += tot[0];
+                off[4 * lane + 1] = base + pre[1];
+                base += tot[1];
+                off[4 * lane + 2] = base + pre[2];
+                base += tot[2];
+                off[4 * lane + 3] = base + pre[3];
+                reinterpret_cast<uint4*>(clr)[lane] = make_uint4(0, 0, 0, 0);  // nobody touches this table during this pass
+                __builtin_amdgcn_s_waitcnt(0xC07F);
             }
-            __syncthreads();
-            if (tid < 256u) {
-                uint32_t before = 0;
-                for (uint32_t w = 0; w < wave; ++w) before += (uint32_t)sh.red[1][w];
-                const uint32_t digit_base = before + incl - run;
-                for (int w = 0; w < kSortWaves; ++w) sh.hist[w][tid] += digit_base;
-            }
-            __syncthreads();
-            // ---- stable scatter
+            // ---- stable scatter; the next pass's digit is counted into the destination segment's row
             for (uint32_t base = lo; base < hi; base += 64u * kSortTile) {
                 unsigned long long k[kSortTile];
                 uint32_t v[kSortTile];
@@ -352,40 +378,32 @@ __global__ __launch_bounds__(kSortThreads) void priority_sort_kernel(PrioritySor
 #pragma unroll
                 for (int t = 0; t < kSortTile; ++t) {
                     const uint32_t i = base + (uint32_t)t * 64u + lane;
-                    if (base + (uint32_t)t * 64u >= hi) break;
+                    if (base + (uint32_t)t * 64u >= hi) break;  // wave-uniform
                     const bool valid = i < hi;
                     const uint32_t d = (uint32_t)(k[t] >> shift) & 255u;
-                    unsigned long long peers = __ballot(valid);
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const bool bit = (d >> b) & 1u;
-                        const unsigned long long bal = __ballot(bit);
-                        peers &= bit ? bal : ~bal;
-                    }
-                    uint32_t off = 0;
-                    if (valid) off = sh.hist[wave][d];
+                    const unsigned long long peers = digit_peers(d, valid);
+                    uint32_t o = 0;
+                    if (valid) o = off[d];
                     const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-                    // (LDS operations of a wavefront execute in order: every lane has read the offset before the leader moves it on)
-                    if (valid && rank == 0u) sh.hist[wave][d] = off + (uint32_t)__popcll(peers);
+                    // (LDS operations of a wavefront execute in order: every lane has read the offset before its leader moves it on)
+                    if (valid && rank == 0u) off[d] = o + (uint32_t)__popcll(peers);
                     if (valid) {
-                        kout[off + rank] = k[t];
-                        pout[off + rank] = v[t];
+                        const uint32_t dst = o + rank;
+                        kout[dst] = k[t];
+                        pout[dst] = v[t];
+                        if (feeds) atomicAdd(&nxt[(size_t)(dst >> seg_log) * 256u + ((uint32_t)(k[t] >> next) & 255u)], 1u);
                     }
                 }
             }
-            __syncthreads();  // vmcnt(0) + barrier: the scattered pairs are visible to the whole workgroup
-            unsigned long long* tk = kin;
-            kin = kout;
-            kout = tk;
-            uint32_t* tp = pin;
-            pin = pout;
-            pout = tp;
+            src = dst_buf;
+            ++P;
+            if (P < total_passes) GF_SORT_SYNC()  // nothing follows the last pass: it wrote the output array
         }
     }
-    // ---- the result belongs in perm_b
-    __syncthreads();
-    if (pin != A.perm_b)
-        for (uint32_t i = tid; i < n; i += kSortThreads) A.perm_b[i] = pin[i];
+#undef GF_SORT_SYNC
+    // ---- no pass at all (every key equal): the name order is the result
+    if (total_passes == 0)
+        for (uint32_t i = lo + lane; i < hi; i += 64u) A.perm[1][i] = A.perm[0][i];
 }
 
 }  // namespace
@@ -685,18 +703,27 @@ hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
         hipLaunchKernelGGL(usage_scatter_kernel, dim3((b.n_res + 255) / 256), block, 0, stream, b.n_res, n, b.d_res_node,
                            b.d_res_req, b.d_res_req + b.n_res, b.d_res_req + 2 * (size_t)b.n_res,
                            reinterpret_cast<unsigned long long*>(b.d_usage), 1);
+    // the priority sort's work area: count tables, barrier and scalars start at zero; metadata_kernel leaves the column ranges
+    const size_t work_bytes = (size_t)(kSortHistWords + kSortStateWords) * sizeof(uint32_t) + kSortScalars * sizeof(unsigned long long);
+    if ((e = hipMemsetAsync(b.d_sort_work, 0, work_bytes, stream)) != hipSuccess) return e;
+    unsigned long long* sort_scal = reinterpret_cast<unsigned long long*>(b.d_sort_work + kSortHistWords + kSortStateWords);
     const dim3 grid((n + 255) / 256);
     hipLaunchKernelGGL(metadata_kernel, grid, block, 0, stream, n, b.d_alloc, b.d_overhead, (const int64_t*)b.d_usage,
-                       b.d_zone, b.n_zones, b.d_avail, b.d_sched, reinterpret_cast<unsigned long long*>(b.d_zone_sum));
+                       b.d_zone, b.n_zones, b.d_avail, b.d_sched, reinterpret_cast<unsigned long long*>(b.d_zone_sum),
+                       b.d_name_rank, b.d_perm_a, sort_scal);
     hipLaunchKernelGGL(zone_rank_kernel, dim3(1), dim3(64), 0, stream, b.n_zones, (const long long*)b.d_zone_sum,
                        b.d_zone_order, b.d_zone_rank);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    // (zone rank, free memory, free cpu, name): one launch, the result sits in d_perm_b
-    PrioritySort ps{n, b.n_zones, b.d_avail, b.d_avail + n, b.d_zone, b.d_zone_rank, b.d_name_rank,
-                    reinterpret_cast<unsigned long long*>(b.d_keys_a), reinterpret_cast<unsigned long long*>(b.d_keys_b),
-                    b.d_perm_a, b.d_perm_b};
-    hipLaunchKernelGGL(priority_sort_kernel, dim3(1), dim3(kSortThreads), 0, stream, ps);
-    return hipGetLastError();
+    // (zone rank, free memory, free cpu, name): one cooperative launch, the result sits in d_perm_b
+    PrioritySort ps{n, b.n_zones, b.d_avail, b.d_avail + n, b.d_zone, b.d_zone_rank,
+                    {reinterpret_cast<unsigned long long*>(b.d_keys_a), reinterpret_cast<unsigned long long*>(b.d_keys_b),
+                     reinterpret_cast<unsigned long long*>(b.d_keys_c)},
+                    {b.d_perm_a, b.d_perm_b, b.d_perm_c}, b.d_sort_work};
+    void* args[] = {&ps};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(priority_sort_kernel), dim3(kSortWG), dim3(64), args, 0, stream);
 }
+
+size_t snapshot_sort_work_words() { return kSortHistWords + kSortStateWords + 2u * kSortScalars; }
+uint32_t snapshot_sort_error_word() { return kSortHistWords + 2u; }
 
 }  // namespace gangfit

@@ -31,3 +31,13 @@ for n_nodes, n_rr in ((10000, 2000), (100000, 20000)):
         t0 = time.perf_counter(); g(); ts.append((time.perf_counter() - t0) * 1e3)
     ts.sort()
     print(n_nodes, "nodes: resident cluster + reservations only p50 %.3f ms p99 %.3f ms" % (ts[50], ts[98]))
+    ctx.usage_reset()
+    rcols = [np.ascontiguousarray(rreq[:, j]) for j in range(3)]
+    ctx.usage_apply(rnode, res_cols=rcols, sign=+1)
+    h = lambda: ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+    for _ in range(5): h()
+    ts = []
+    for _ in range(100):
+        t0 = time.perf_counter(); h(); ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    print(n_nodes, "nodes: resident cluster + resident usage p50 %.3f ms p99 %.3f ms" % (ts[50], ts[98]))
