@@ -117,8 +117,20 @@ int gf_version(void);
  *     one device, bit for bit.  Everything else (FIFO chains — each commit must be visible to the next scan —, zone-aware
  *     and minimal-fragmentation packers, orders that do not merge into one, single executors, findNodes, efficiencies, the
  *     *_dev entry points) runs on the first device.  A device id may repeat (several shards on one GPU): that is how the
- *     path is tested on a one-GPU box; GF_ERR_UNSUPPORTED when two distinct devices cannot access each other's memory. */
+ *     path is tested on a one-GPU box.  When two distinct devices cannot access each other's memory the context DEGRADES
+ *     to the first device (GF_OK; gf_shard_count returns 1, gf_last_error says why): a host must not lose the accelerator
+ *     because a topology lacks peer access.  The exchange buffers live in fine-grained memory.  Self-check: the first
+ *     sharded batch on every newly installed snapshot is also answered by the first device alone; on a mismatch the
+ *     context stops sharding (gf_shard_count 1, gf_last_error set) and serves the first device's answer — a wrong exchange
+ *     never decides a Filter.  gf_set_option(ctx, "group_exchange", 1) moves the three exchanges onto RCCL collectives
+ *     (librccl bound at run time, ncclCommInitAll over the context's devices: two all-gathers and one reduce per batch, each
+ *     a grouped call over every device's stream); GF_ERR_UNSUPPORTED when the library is missing or refuses the device list
+ *     (a repeated id), the peer-store exchange then stays in place.  Test switches of a multi-device context:
+ *     "group_verify" (0 skips the self-check), "group_fault" (1 / 2 drop an exchange), "group_shard_off". */
 int gf_init(const int *device_ids, int n_dev, gf_ctx **out);
+/* Number of node-range shards independent batches are split into right now: the device count of gf_init, or 1 for a
+ * single-device context, a degraded one, or one whose self-check failed. */
+int gf_shard_count(gf_ctx *ctx);
 void gf_destroy(gf_ctx *ctx);
 
 /* Sequence lock of a context: gf_ctx_lock blocks until no other caller holds it.  Unlike the internal per-call mutex it may
@@ -139,6 +151,7 @@ const char *gf_last_error(gf_ctx *ctx);
  *   "minfrag_matrix", "minfrag_hist", "sparse_gpu", "zero_copy"   0 disables the respective structure
  *   "snapshot_finalize_host" 1: gf_snapshot_build* builds the slot tables through gf_orders_set on the host
  *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
+ *   "rccl_selftest"          n: binds librccl at run time and checks a one-rank all-gather + reduce of n words on this device
  * GF_ERR_INVALID for an unknown key or a value out of range.  The only environment variables the library reads are
  * GANGFIT_WAIT=block (completion waits park the thread instead of polling) and GANGFIT_CHAIN_CACHE=0. */
 int gf_set_option(gf_ctx *ctx, const char *key, int64_t value);

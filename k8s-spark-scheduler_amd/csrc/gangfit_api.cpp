@@ -3,6 +3,7 @@
 // Host side only: builds the slot-ordered node table the kernels scan (gangfit_device.h), moves app records and
 // results through pinned staging buffers and serialises callers per context.  No CPU fallback lives here: when the
 // device path cannot serve a call the function returns < 0 and the caller (the Go shim) decides what to do.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -68,12 +69,14 @@ template <typename T>
 struct DeviceBuf {
     T* ptr = nullptr;
     size_t cap = 0;  // elements
+    bool fine = false;  // fine-grained (device-coherent) memory: buffers other devices store into / read from
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
         size_t want = cap ? cap : 256;
         while (want < n) want *= 2;
         T* fresh = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T));
+        hipError_t e = fine ? hipExtMallocWithFlags(reinterpret_cast<void**>(&fresh), want * sizeof(T), hipDeviceMallocFinegrained)
+                            : hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(T));
         if (e != hipSuccess) return e;
         if (ptr) (void)hipFree(ptr);
         ptr = fresh;
@@ -109,6 +112,45 @@ struct PinnedBuf {
         cap = 0;
     }
 };
+
+// The collective library, bound at run time (a host without librccl still loads libgangfit): the in-process exchange of a
+// multi-device context can run on RCCL (ncclCommInitAll: one communicator per device of THIS process, collectives grouped
+// per step) instead of the peer stores of gangfit_shard.inc.  Only the handful of entry points used; constants as in rccl.h.
+struct Rccl {
+    typedef void* comm_t;
+    void* lib = nullptr;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    static constexpr int kChar = 0, kUint32 = 3, kSum = 0;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        Reduce = reinterpret_cast<decltype(Reduce)>(dlsym(lib, "ncclReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (CommInitAll && CommDestroy && AllGather && Reduce && GroupStart && GroupEnd) return true;
+        dlclose(lib);
+        lib = nullptr;
+        return false;
+    }
+};
+Rccl& rccl() {
+    static Rccl r;
+    return r;
+}
 
 }  // namespace
 
@@ -226,6 +268,13 @@ struct gf_ctx {
     DeviceBuf<gf_shard_driver> g_drv_loc, g_drv_all;
     DeviceBuf<uint32_t> g_exec2;                         // 2 * half: placements (node + 1) | capacities
     hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};    // behind partials+push | drivers+push | emit
+    // ... and these in the routing object
+    uint64_t g_verified_epoch = 0;  // snapshot epoch whose first sharded batch agreed with the first device's own answer
+    bool g_verify = true;           // option "group_verify"
+    bool g_shard_off = false;       // a sharded batch disagreed: every batch is served by the first device from then on
+    int g_fault = 0;                // option "group_fault" (tests): 1 = the placement reduction is skipped, 2 = the driver exchange
+    std::vector<void*> g_comms;     // option "group_exchange" = 1: one RCCL communicator per sub-context (ncclCommInitAll)
+    std::vector<int> g_devices;     // the device ids gf_init was given
 
     // findNodes requests (gf_find_nodes)
     DeviceBuf<int32_t> d_fk;
@@ -839,7 +888,11 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
             }
             sub->shard = (uint32_t)i;
             sub->n_shards = (uint32_t)n_dev;
+            // what the other devices store into / read from lives in fine-grained memory: a posted peer store must not depend
+            // on what a kernel boundary does to this device's caches
+            sub->g_part_all.fine = sub->g_drv_all.fine = sub->g_exec2.fine = true;
             g->group.push_back(sub);
+            g->g_devices.push_back(device_ids[i]);
             bool ok = hipSetDevice(sub->device) == hipSuccess;
             for (hipEvent_t& e : sub->g_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
             if (!ok) {
@@ -847,22 +900,28 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
                 return GF_ERR_HIP;
             }
         }
-        for (int i = 0; i < n_dev; ++i)  // every shard's kernels write into / read from every other shard's buffers
-            for (int j = 0; j < n_dev; ++j) {
+        bool peers = std::getenv("GANGFIT_TEST_NO_PEER") == nullptr;  // (fault injection of host_test: "no device can reach another")
+        for (int i = 0; i < n_dev && peers; ++i)  // every shard's kernels write into / read from every other shard's buffers
+            for (int j = 0; j < n_dev && peers; ++j) {
                 if (device_ids[i] == device_ids[j]) continue;
                 int can = 0;
                 if (hipSetDevice(device_ids[i]) != hipSuccess ||
                     hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) != hipSuccess || !can) {
-                    gf_destroy(g);
-                    return GF_ERR_UNSUPPORTED;
+                    peers = false;
+                    break;
                 }
                 const hipError_t e = hipDeviceEnablePeerAccess(device_ids[j], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                    gf_destroy(g);
-                    return GF_ERR_HIP;
-                }
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peers = false;
                 (void)hipGetLastError();
             }
+        if (!peers) {
+            // The devices cannot reach each other's memory: serve everything from the first device instead of refusing the
+            // whole context (the Go host would otherwise run every Filter on the CPU).  gf_shard_count says so.
+            gf_destroy(g);
+            const int rc = gf_init(&device_ids[0], 1, out);
+            if (rc == GF_OK) (*out)->err = "peer access between the requested devices is unavailable: serving from the first device only";
+            return rc;
+        }
         g->info = g->group[0]->info;
         *out = g;
         return GF_OK;
@@ -911,6 +970,9 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
 void gf_destroy(gf_ctx* ctx) {
     if (!ctx) return;
     if (!ctx->group.empty()) {
+        for (void* c : ctx->g_comms)
+            if (c) (void)rccl().CommDestroy(c);
+        ctx->g_comms.clear();
         for (gf_ctx* s : ctx->group) gf_destroy(s);
         ctx->group.clear();
         (void)hipSetDevice(ctx->device);
@@ -1026,6 +1088,36 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return GF_ERR_INVALID;
     if (!ctx->group.empty()) {
         std::lock_guard<std::recursive_mutex> glock(ctx->mu);
+        const std::string gk(key);
+        if (gk == "group_verify") {
+            ctx->g_verify = value != 0;
+            return GF_OK;
+        }
+        if (gk == "group_fault") {
+            ctx->g_fault = (int)value;
+            ctx->g_verified_epoch = 0;
+            return GF_OK;
+        }
+        if (gk == "group_shard_off") {  // read-back for tests: 1 sets, 0 clears (and re-arms the self-check)
+            ctx->g_shard_off = value != 0;
+            ctx->g_verified_epoch = 0;
+            return GF_OK;
+        }
+        if (gk == "group_exchange") {
+            for (void* c : ctx->g_comms)
+                if (c) (void)rccl().CommDestroy(c);
+            ctx->g_comms.clear();
+            ctx->g_verified_epoch = 0;  // the other exchange proves itself on its first batch
+            if (value == 0) return GF_OK;
+            if (!rccl().load()) return fail(ctx, GF_ERR_UNSUPPORTED, "librccl.so cannot be loaded");
+            std::vector<void*> comms(ctx->group.size(), nullptr);
+            const int rc = rccl().CommInitAll(comms.data(), (int)comms.size(), ctx->g_devices.data());
+            if (rc != 0)  // e.g. a device id that repeats: RCCL wants one rank per physical device
+                return fail(ctx, GF_ERR_UNSUPPORTED, "ncclCommInitAll failed: %s",
+                            rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+            ctx->g_comms = comms;
+            return GF_OK;
+        }
         for (gf_ctx* sub : ctx->group)
             if (const int rc = gf_set_option(sub, key, value); rc != GF_OK) {
                 ctx->err = sub->err;
@@ -1054,11 +1146,42 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->force_general_layout = value != 0;
     } else if (k == "chain_cache") {
         ctx->chain_cache_on = value != 0;
+    } else if (k == "rccl_selftest") {
+        // the run-time binding of the collective library, exercised with a one-rank communicator on this device: an
+        // all-gather and a reduction of `value` words must reproduce their input
+        if (!rccl().load()) return fail(ctx, GF_ERR_UNSUPPORTED, "librccl.so cannot be loaded");
+        if (value <= 0 || value > (1 << 20)) return fail(ctx, GF_ERR_INVALID, "rccl_selftest wants a word count in (0, 2^20]");
+        GF_HIP(ctx, hipSetDevice(ctx->device));
+        void* comm = nullptr;
+        int rc = rccl().CommInitAll(&comm, 1, &ctx->device);
+        if (rc != 0) return fail(ctx, GF_ERR_UNSUPPORTED, "ncclCommInitAll failed: %s", rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+        const size_t n = (size_t)value;
+        std::vector<uint32_t> h(n), back(2 * n, 0u);
+        for (size_t i = 0; i < n; ++i) h[i] = (uint32_t)(i * 2654435761u + 7u);
+        uint32_t* d = nullptr;
+        bool ok = hipMalloc(reinterpret_cast<void**>(&d), 3 * n * sizeof(uint32_t)) == hipSuccess &&
+                  hipMemcpy(d, h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && rccl().AllGather(d, d + n, n * sizeof(uint32_t), Rccl::kChar, comm, ctx->stream) == 0 &&
+             rccl().Reduce(d, d + 2 * n, n, Rccl::kUint32, Rccl::kSum, 0, comm, ctx->stream) == 0 &&
+             gf_wait_stream(ctx->stream) == hipSuccess &&
+             hipMemcpy(back.data(), d + n, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        if (d) (void)hipFree(d);
+        (void)rccl().CommDestroy(comm);
+        for (size_t i = 0; i < n && ok; ++i) ok = back[i] == h[i] && back[n + i] == h[i];
+        if (!ok) return fail(ctx, GF_ERR_HIP, "the one-rank all-gather / reduce did not reproduce its input");
+        return GF_OK;
     } else {
         return fail(ctx, GF_ERR_INVALID, "unknown option '%s'", key);
     }
     ctx->chain.valid = false;
     return GF_OK;
+}
+
+int gf_shard_count(gf_ctx* ctx) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (ctx->group.empty() || ctx->g_shard_off) return 1;
+    return (int)ctx->group.size();
 }
 
 int gf_generation(gf_ctx* ctx, uint64_t out[3]) {
@@ -2593,7 +2716,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
                     uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at) {
     std::lock_guard<std::recursive_mutex> glock(g->mu);
     gf_ctx* const first = g->group[0];
-    bool sharded = mode == GF_MODE_INDEPENDENT && (algo == GF_ALGO_TIGHTLY_PACK || algo == GF_ALGO_DISTRIBUTE_EVENLY) && n_apps > 0;
+    bool sharded = mode == GF_MODE_INDEPENDENT && (algo == GF_ALGO_TIGHTLY_PACK || algo == GF_ALGO_DISTRIBUTE_EVENLY) && n_apps > 0 &&
+                   !g->g_shard_off;
     for (gf_ctx* s : g->group) sharded = sharded && s->have_orders && s->merged;
     if (!sharded) {
         const int rc = gf_fit_batch(first, mode, algo, n_apps, apps, results, exec_nodes, exec_nodes_cap, chain_failed_at);
@@ -2646,6 +2770,19 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         if (s > 0) exec_others.p[exec_others.n++] = c->g_exec2.ptr;
     }
     part_all.n = drv_all.n = S;
+    const bool use_rccl = g->g_comms.size() == S;
+    // RCCL exchange: every device's collective is enqueued on its own stream inside one group call; the library orders the
+    // streams against each other, so the event fan-out of the peer-store path is not needed
+    auto rccl_all_gather = [&](auto loc, auto all, size_t bytes_each) -> int {
+        if (rccl().GroupStart() != 0) return -1;
+        int bad = 0;
+        for (uint32_t s2 = 0; s2 < S; ++s2) {
+            gf_ctx* c = g->group[s2];
+            if (hipSetDevice(c->device) != hipSuccess) bad = 1;
+            bad |= rccl().AllGather(loc(c), all(c), bytes_each, Rccl::kChar, g->g_comms[s2], c->stream);
+        }
+        return rccl().GroupEnd() | bad;
+    };
     auto everyone_waits = [&](int which) -> hipError_t {  // stream t continues only behind event `which` of every other shard
         // (S (S - 1) stream waits; joining the events on one stream first — 2 S + 1 calls — measured slower with eight shards on
         //  one device: the extra hop costs more than the calls it saves)
@@ -2662,21 +2799,39 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         gf_ctx* c = g->group[s];
         GF_HIP(g, hipSetDevice(c->device));
         GF_HIP(g, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_loc.ptr, c->stream));
+        if (use_rccl) continue;
         GF_HIP(g, gangfit::launch_shard_push(c->g_part_loc.ptr, part_all, (size_t)s * n_apps * sizeof(gf_shard_partial),
                                              (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
         GF_HIP(g, hipEventRecord(c->g_ev[0], c->stream));
     }
-    GF_HIP(g, everyone_waits(0));
+    if (use_rccl) {
+        if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_part_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_part_all.ptr; },
+                            (size_t)n_apps * sizeof(gf_shard_partial)) != 0)
+            return fail(g, GF_ERR_HIP, "ncclAllGather of the capacity sums failed");
+    } else {
+        GF_HIP(g, everyone_waits(0));
+    }
     // ---- step 2: first feasible driver of each range, gathered everywhere
     for (uint32_t s = 0; s < S; ++s) {
         gf_ctx* c = g->group[s];
         GF_HIP(g, hipSetDevice(c->device));
         GF_HIP(g, gangfit::launch_shard_drivers(make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr, c->g_drv_loc.ptr, c->stream));
+        if (use_rccl) continue;
+        if (g->g_fault == 2 && s > 0) {  // fault injection: this shard's driver records never reach the others
+            GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
+            continue;
+        }
         GF_HIP(g, gangfit::launch_shard_push(c->g_drv_loc.ptr, drv_all, (size_t)s * n_apps * sizeof(gf_shard_driver),
                                              (size_t)n_apps * sizeof(gf_shard_driver), c->stream));
         GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
     }
-    GF_HIP(g, everyone_waits(1));
+    if (use_rccl) {
+        if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_drv_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_drv_all.ptr; },
+                            (size_t)n_apps * sizeof(gf_shard_driver)) != 0)
+            return fail(g, GF_ERR_HIP, "ncclAllGather of the driver records failed");
+    } else {
+        GF_HIP(g, everyone_waits(1));
+    }
     // ---- step 3: every shard emits its slice of the placements
     for (uint32_t s = 0; s < S; ++s) {
         gf_ctx* c = g->group[s];
@@ -2686,9 +2841,22 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         GF_HIP(g, hipEventRecord(c->g_ev[2], c->stream));
     }
     // ---- step 4 on the first device only: sum of the slices (each entry written by exactly one shard), finish, D2H
-    GF_HIP(g, hipSetDevice(first->device));
-    for (uint32_t s = 1; s < S; ++s) GF_HIP(g, hipStreamWaitEvent(first->stream, g->group[s]->g_ev[2], 0));
-    GF_HIP(g, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream));
+    if (use_rccl) {  // the reduction north_star names: sum of the placement slices onto the first device, over xGMI
+        if (rccl().GroupStart() != 0) return fail(g, GF_ERR_HIP, "ncclGroupStart failed");
+        int bad = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            gf_ctx* c = g->group[s];
+            GF_HIP(g, hipSetDevice(c->device));
+            bad |= rccl().Reduce(c->g_exec2.ptr, first->g_exec2.ptr, (size_t)(2 * half), Rccl::kUint32, Rccl::kSum, 0, g->g_comms[s], c->stream);
+        }
+        if ((rccl().GroupEnd() | bad) != 0) return fail(g, GF_ERR_HIP, "ncclReduce of the placements failed");
+        GF_HIP(g, hipSetDevice(first->device));
+    } else {
+        GF_HIP(g, hipSetDevice(first->device));
+        for (uint32_t s = 1; s < S; ++s) GF_HIP(g, hipStreamWaitEvent(first->stream, g->group[s]->g_ev[2], 0));
+        if (g->g_fault != 1)  // fault injection: the other shards' placement slices never arrive
+            GF_HIP(g, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream));
+    }
     GF_HIP(g, gangfit::launch_shard_finish(algo, S, n_apps, first->d_apps.ptr, first->g_part_all.ptr, first->g_drv_all.ptr,
                                            first->d_results.ptr, first->g_exec2.ptr, half, first->stream));
     GF_HIP(g, hipMemcpyAsync(g->h_results.ptr, first->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, first->stream));
@@ -2697,6 +2865,31 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
     GF_HIP(g, gf_wait_stream(first->stream));
     std::memcpy(results, g->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
     if (total_k) std::memcpy(exec_nodes, g->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
+    // ---- self-check: the first sharded batch on every newly installed snapshot is also answered by the first device alone.
+    //      A wrong exchange (peer stores that did not land, a collective that reduced something else) must not decide a
+    //      Filter: on a mismatch the context stops sharding, says why, and serves the first device's answer.
+    if (g->g_verify && first->snap_epoch != g->g_verified_epoch) {
+        std::vector<gf_result> ref_res(n_apps);
+        std::vector<uint32_t> ref_exec((size_t)total_k + 1);
+        const int rc = gf_fit_batch(first, mode, algo, n_apps, apps, ref_res.data(), ref_exec.data(), total_k, nullptr);
+        if (rc != GF_OK) {
+            g->err = first->err;
+            return rc;
+        }
+        bool same = std::memcmp(ref_res.data(), results, (size_t)n_apps * sizeof(gf_result)) == 0;
+        for (uint32_t a = 0; a < n_apps && same; ++a)
+            if (ref_res[a].has_capacity)
+                same = std::memcmp(ref_exec.data() + g->h_apps.ptr[a].exec_off, exec_nodes + g->h_apps.ptr[a].exec_off,
+                                   (size_t)ref_res[a].exec_len * sizeof(uint32_t)) == 0;
+        if (same) {
+            g->g_verified_epoch = first->snap_epoch;
+        } else {
+            g->g_shard_off = true;
+            g->err = "the node-range sharded batch disagreed with the first device's own answer: sharding is off for this context";
+            std::memcpy(results, ref_res.data(), (size_t)n_apps * sizeof(gf_result));
+            if (total_k) std::memcpy(exec_nodes, ref_exec.data(), (size_t)total_k * sizeof(uint32_t));
+        }
+    }
     return GF_OK;
 }
 

@@ -72,6 +72,13 @@ class Context:
     def set_option(self, key: str, value: int):
         self._check(self._lib.gf_set_option(self._h, key.encode(), int(value)))
 
+    def shard_count(self) -> int:
+        return int(self._lib.gf_shard_count(self._h))
+
+    def last_error(self) -> str:
+        msg = self._lib.gf_last_error(self._h)
+        return msg.decode() if msg else ""
+
     def generation(self):
         """(snapshot epoch, cluster generation, usage generation)"""
         out = np.zeros(3, dtype=np.uint64)

@@ -109,3 +109,68 @@ def test_group_argument_errors():
     assert lib.gf_init(ids, 17, C.byref(h)) == gangfit._native.GF_ERR_INVALID  # more than 16 devices
     ids = (C.c_int * 2)(0, 999)
     assert lib.gf_init(ids, 2, C.byref(h)) == gangfit._native.GF_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("fault", [1, 2])
+def test_a_wrong_exchange_is_caught_and_sharding_switched_off(fault):
+    """Self-check of a multi-device context: the first sharded batch on a newly installed snapshot is also answered by the
+    first device alone.  With an exchange made to fail (option "group_fault": 1 = the placement reduction never runs, 2 = the
+    other shards' driver records never arrive) the answers must still be the right ones, the context must say so and stop
+    sharding; without the fault it keeps sharding."""
+    rng = np.random.default_rng(700 + fault)
+    avail, D, X, drv, exe, k = _random_problem(rng, 1000, 150, False, "merged")
+    apps = gangfit.make_apps(drv, exe, k)
+    ref = ob.fit_independent(0, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True)
+    with gangfit.Context(devices=[0] * 4) as g:
+        g.set_snapshot(avail)
+        g.set_orders(D, X)
+        _assert_same(g.fit_batch(IND, 0, apps), ref, apps)
+        assert g.shard_count() == 4
+        g.set_option("group_fault", fault)  # re-arms the self-check
+        _assert_same(g.fit_batch(IND, 0, apps), ref, apps)
+        assert g.shard_count() == 1 and "disagreed" in g.last_error()
+        _assert_same(g.fit_batch(IND, 0, apps), ref, apps)  # served by the first device from now on
+        g.set_option("group_fault", 0)
+        g.set_option("group_shard_off", 0)
+        _assert_same(g.fit_batch(IND, 0, apps), ref, apps)
+        assert g.shard_count() == 4
+        # the check runs once per installed snapshot: with it switched off a faulty exchange would go unnoticed
+        g.set_option("group_verify", 0)
+        g.set_option("group_fault", fault)
+        out = g.fit_batch(IND, 0, apps)
+        assert not (np.array_equal(out.results, ref.results) and all(
+            np.array_equal(out.placement(int(a))[2], ref.placement(int(a))[2]) for a in np.nonzero(ref.results["has_capacity"])[0]))
+
+
+def test_no_peer_access_degrades_to_the_first_device(monkeypatch):
+    """Devices that cannot reach each other's memory: gf_init returns a working single-device context (GF_OK), not an error
+    for the whole context — the host would otherwise fall back to the CPU for every Filter."""
+    monkeypatch.setenv("GANGFIT_TEST_NO_PEER", "1")
+    rng = np.random.default_rng(31)
+    avail, D, X, drv, exe, k = _random_problem(rng, 500, 80, False, "merged")
+    with gangfit.Context(devices=[0, 0, 0]) as g:
+        assert g.shard_count() == 1 and "peer access" in g.last_error()
+        g.set_snapshot(avail)
+        g.set_orders(D, X)
+        apps = gangfit.make_apps(drv, exe, k)
+        _assert_same(g.fit_batch(IND, 1, apps), ob.fit_independent(1, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True), apps)
+
+
+def test_rccl_binding_and_exchange_selection():
+    """The collective library is bound at run time.  One GPU cannot host two ranks of one communicator, so: (a) the binding
+    itself is exercised with a one-rank communicator (all-gather + reduce must reproduce their input); (b) asking a context
+    whose device id repeats for the RCCL exchange is refused (GF_ERR_UNSUPPORTED) and leaves the peer-store exchange in place."""
+    with gangfit.Context(0) as one:
+        one.set_option("rccl_selftest", 4096)
+    rng = np.random.default_rng(32)
+    avail, D, X, drv, exe, k = _random_problem(rng, 400, 60, False, "merged")
+    apps = gangfit.make_apps(drv, exe, k)
+    ref = ob.fit_independent(0, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True)
+    with gangfit.Context(devices=[0, 0]) as g:
+        with pytest.raises(gangfit.GangfitError) as e:
+            g.set_option("group_exchange", 1)
+        assert e.value.code == gangfit._native.GF_ERR_UNSUPPORTED
+        g.set_snapshot(avail)
+        g.set_orders(D, X)
+        _assert_same(g.fit_batch(IND, 0, apps), ref, apps)
+        assert g.shard_count() == 2
