@@ -126,7 +126,7 @@ int gf_version(void);
  *     (librccl bound at run time, ncclCommInitAll over the context's devices: two all-gathers and one reduce per batch, each
  *     a grouped call over every device's stream); GF_ERR_UNSUPPORTED when the library is missing or refuses the device list
  *     (a repeated id), the peer-store exchange then stays in place.  Test switches of a multi-device context:
- *     "group_verify" (0 skips the self-check), "group_fault" (1 / 2 drop an exchange), "group_shard_off". */
+ *     "group_verify" (0 skips the self-check), "group_fault" (1 drops the placement reduction, 2 zeroes the other shards' capacity sums), "group_shard_off". */
 int gf_init(const int *device_ids, int n_dev, gf_ctx **out);
 /* Number of node-range shards independent batches are split into right now: the device count of gf_init, or 1 for a
  * single-device context, a degraded one, or one whose self-check failed. */

@@ -272,7 +272,7 @@ struct gf_ctx {
     uint64_t g_verified_epoch = 0;  // snapshot epoch whose first sharded batch agreed with the first device's own answer
     bool g_verify = true;           // option "group_verify"
     bool g_shard_off = false;       // a sharded batch disagreed: every batch is served by the first device from then on
-    int g_fault = 0;                // option "group_fault" (tests): 1 = the placement reduction is skipped, 2 = the driver exchange
+    int g_fault = 0;                // option "group_fault" (tests): 1 = the placement reduction is skipped, 2 = zeroed capacity sums
     std::vector<void*> g_comms;     // option "group_exchange" = 1: one RCCL communicator per sub-context (ncclCommInitAll)
     std::vector<int> g_devices;     // the device ids gf_init was given
 
@@ -2799,6 +2799,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         gf_ctx* c = g->group[s];
         GF_HIP(g, hipSetDevice(c->device));
         GF_HIP(g, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_loc.ptr, c->stream));
+        if (g->g_fault == 2 && s > 0)  // fault injection: this shard's capacity sums arrive as zeros
+            GF_HIP(g, hipMemsetAsync(c->g_part_loc.ptr, 0, (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
         if (use_rccl) continue;
         GF_HIP(g, gangfit::launch_shard_push(c->g_part_loc.ptr, part_all, (size_t)s * n_apps * sizeof(gf_shard_partial),
                                              (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
@@ -2817,10 +2819,6 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         GF_HIP(g, hipSetDevice(c->device));
         GF_HIP(g, gangfit::launch_shard_drivers(make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr, c->g_drv_loc.ptr, c->stream));
         if (use_rccl) continue;
-        if (g->g_fault == 2 && s > 0) {  // fault injection: this shard's driver records never reach the others
-            GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
-            continue;
-        }
         GF_HIP(g, gangfit::launch_shard_push(c->g_drv_loc.ptr, drv_all, (size_t)s * n_apps * sizeof(gf_shard_driver),
                                              (size_t)n_apps * sizeof(gf_shard_driver), c->stream));
         GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));

@@ -115,7 +115,7 @@ def test_group_argument_errors():
 def test_a_wrong_exchange_is_caught_and_sharding_switched_off(fault):
     """Self-check of a multi-device context: the first sharded batch on a newly installed snapshot is also answered by the
     first device alone.  With an exchange made to fail (option "group_fault": 1 = the placement reduction never runs, 2 = the
-    other shards' driver records never arrive) the answers must still be the right ones, the context must say so and stop
+    other shards' capacity sums arrive as zeros) the answers must still be the right ones, the context must say so and stop
     sharding; without the fault it keeps sharding."""
     rng = np.random.default_rng(700 + fault)
     avail, D, X, drv, exe, k = _random_problem(rng, 1000, 150, False, "merged")
