@@ -70,6 +70,9 @@ type Context struct {
 	mu    sync.Mutex // snapshot+zones+orders+fit must not interleave between goroutines (Predicate vs UnschedulablePodMarker)
 	ctx   *C.gf_ctx
 	names []string // node order of the last ClusterSet (resident flow)
+	// the snapshot the last FilterResident installed (gf_generation right after it) and the flags it was built with
+	builtEpoch, builtCluster, builtUsage uint64
+	builtFlags                          []uint32
 }
 
 func New(devices ...int) (*Context, error) {
@@ -484,9 +487,14 @@ func (c *Context) ClusterSet(cl *Cluster) error {
 
 // SnapshotBuildResident builds and installs this request's snapshot from the resident state
 // (gf_snapshot_build_resident with n_res = GF_RESIDENT_USAGE); requestFlags may be nil (the cluster's defaults).
+// NOT atomic with a following fit: a Filter must use FilterResident, which holds the lock across both.
 func (c *Context) SnapshotBuildResident(requestFlags []uint32) error {
 	c.mu.Lock()
 	defer c.mu.Unlock()
+	return c.buildResidentLocked(requestFlags)
+}
+
+func (c *Context) buildResidentLocked(requestFlags []uint32) error {
 	if rc := C.gf_snapshot_build_resident(c.ctx, C.uint32_t(ResidentUsage), nil, nil, nil, nil, p32(requestFlags), nil, nil,
 		nil, nil, nil, nil); rc != C.GF_OK {
 		return c.err(rc)
@@ -494,21 +502,64 @@ func (c *Context) SnapshotBuildResident(requestFlags []uint32) error {
 	return nil
 }
 
-// FitBatchOnInstalledSnapshot is FitBatch without the snapshot upload: node names come from the last ClusterSet.
-func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (results []Result, failedAt int, err error) {
+// FilterResident is one driver Filter of the resident flow: build this request's snapshot from the resident cluster and
+// usage, then run the FIFO chain (or an independent batch) on it — under ONE hold of the context lock, so that a FitBatch,
+// FindNodes or ClusterSet of another goroutine (the UnschedulablePodMarker runs next to Predicate, cmd/server.go:230) can
+// neither replace the snapshot between the two steps nor change the name table the answer is mapped through.
+//
+// When nothing changed since this context's previous FilterResident — same cluster and usage generations (gf_generation),
+// same candidate flags, nobody installed another snapshot — the rebuild is skipped, and the chain of
+// gf_fit_batch(GF_MODE_FIFO_CHAIN) resumes from the previous chain's checkpoints (include/gangfit.h, "Incremental FIFO
+// chains"): the Filter of driver j + 1 after the Filter of driver j costs a few dozen applications instead of all of them.
+func (c *Context) FilterResident(requestFlags []uint32, fifo bool, algo int, apps []App) (results []Result, failedAt int, err error) {
+	capps, total, err := flattenApps(apps)
+	if err != nil {
+		return nil, -1, err
+	}
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var gen [3]C.uint64_t
+	C.gf_generation(c.ctx, &gen[0])
+	same := c.builtEpoch != 0 && uint64(gen[0]) == c.builtEpoch && uint64(gen[1]) == c.builtCluster &&
+		uint64(gen[2]) == c.builtUsage && equalFlags(c.builtFlags, requestFlags)
+	if !same {
+		c.builtEpoch = 0
+		if err := c.buildResidentLocked(requestFlags); err != nil {
+			return nil, -1, err
+		}
+		C.gf_generation(c.ctx, &gen[0])
+		c.builtEpoch, c.builtCluster, c.builtUsage = uint64(gen[0]), uint64(gen[1]), uint64(gen[2])
+		c.builtFlags = append(c.builtFlags[:0], requestFlags...)
+	}
+	return c.fitLocked(fifo, algo, apps, capps, total, c.names)
+}
+
+func equalFlags(a, b []uint32) bool {
+	if len(a) != len(b) {
+		return false
+	}
+	for i := range a {
+		if a[i] != b[i] {
+			return false
+		}
+	}
+	return true
+}
+
+func flattenApps(apps []App) ([]C.gf_app, int, error) {
 	capps := make([]C.gf_app, len(apps))
 	total := 0
 	for i, a := range apps {
 		d, err := canonical(a.Driver)
 		if err != nil {
-			return nil, -1, err
+			return nil, 0, err
 		}
 		e, err := canonical(a.Executor)
 		if err != nil {
-			return nil, -1, err
+			return nil, 0, err
 		}
 		if a.ExecutorCount < 0 || a.ExecutorCount > C.GF_MAX_K {
-			return nil, -1, ErrNotRepresentable
+			return nil, 0, ErrNotRepresentable
 		}
 		for j := 0; j < 3; j++ {
 			capps[i].drv[j], capps[i].exe[j] = C.int64_t(d[j]), C.int64_t(e[j])
@@ -519,6 +570,11 @@ func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (
 		}
 		total += a.ExecutorCount
 	}
+	return capps, total, nil
+}
+
+// fitLocked runs gf_fit_batch on the installed snapshot and maps node indices through `names`; c.mu is held.
+func (c *Context) fitLocked(fifo bool, algo int, apps []App, capps []C.gf_app, total int, names []string) ([]Result, int, error) {
 	cres := make([]C.gf_result, len(apps))
 	execNodes := make([]uint32, total+1)
 	var failed C.int32_t = -1
@@ -526,8 +582,6 @@ func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (
 	if fifo {
 		mode = C.GF_MODE_FIFO_CHAIN
 	}
-	c.mu.Lock()
-	defer c.mu.Unlock()
 	var pa *C.gf_app
 	var pr *C.gf_result
 	if len(apps) > 0 {
@@ -537,7 +591,7 @@ func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (
 		C.uint64_t(total), &failed); rc != C.GF_OK {
 		return nil, -1, c.err(rc)
 	}
-	results = make([]Result, len(apps))
+	results := make([]Result, len(apps))
 	off := 0
 	for i := range apps {
 		r := &results[i]
@@ -545,12 +599,30 @@ func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (
 		r.HasCapacity = cres[i].has_capacity != 0
 		r.ExecutorNodes = make([]string, 0, int(cres[i].exec_len))
 		if r.HasCapacity {
-			r.DriverNode = c.names[cres[i].driver_node]
+			if int(cres[i].driver_node) >= len(names) {
+				return nil, -1, fmt.Errorf("gangfit: node index %d outside the %d names of the installed cluster", int(cres[i].driver_node), len(names))
+			}
+			r.DriverNode = names[cres[i].driver_node]
 			for _, ix := range execNodes[off : off+int(cres[i].exec_len)] {
-				r.ExecutorNodes = append(r.ExecutorNodes, c.names[ix])
+				if int(ix) >= len(names) {
+					return nil, -1, fmt.Errorf("gangfit: node index %d outside the %d names of the installed cluster", int(ix), len(names))
+				}
+				r.ExecutorNodes = append(r.ExecutorNodes, names[ix])
 			}
 		}
 		off += apps[i].ExecutorCount
 	}
 	return results, int(failed), nil
+}
+
+// FitBatchOnInstalledSnapshot is FitBatch without the snapshot upload: node names come from the last ClusterSet.  For a
+// caller that brackets the install and the fit with its own mutual exclusion; a Filter should call FilterResident.
+func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (results []Result, failedAt int, err error) {
+	capps, total, err := flattenApps(apps)
+	if err != nil {
+		return nil, -1, err
+	}
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	return c.fitLocked(fifo, algo, apps, capps, total, c.names)
 }
