@@ -133,6 +133,18 @@ int gf_init(const int *device_ids, int n_dev, gf_ctx **out);
 int gf_shard_count(gf_ctx *ctx);
 void gf_destroy(gf_ctx *ctx);
 
+/* A VIEW of a context: a context of its own (own stream, own working tables, own chain cache, own mutex) that fits on the
+ * snapshot installed in `parent`, without a copy of it.  Predicate and the UnschedulablePodMarker run concurrently in the
+ * reference (cmd/server.go:230), and so do Filters of different queues on one instance group's snapshot: N views run N FIFO
+ * chains at the same time on N compute units of the one GPU, after ONE install.
+ *   - a view serves the entry points that read the snapshot (gf_fit_batch[_dev], gf_spark_binpack, gf_residual_get,
+ *     gf_snapshot_get, gf_executor_fit, gf_find_nodes, the efficiencies); the ones that install (gf_snapshot_set,
+ *     gf_zones_set, gf_orders_set, gf_cluster_set, gf_snapshot_build*, gf_usage_*) return GF_ERR_STATE on it;
+ *   - an install on the parent waits for the views' calls in flight and blocks new ones while it runs; the next call of a
+ *     view then sees the new snapshot (and starts with an empty chain cache);
+ *   - destroy the views before the parent.  GF_ERR_UNSUPPORTED for a multi-device parent. */
+int gf_ctx_view(gf_ctx *parent, gf_ctx **out);
+
 /* Sequence lock of a context: gf_ctx_lock blocks until no other caller holds it.  Unlike the internal per-call mutex it may
  * be released from a different OS thread than the one that took it (a goroutine can migrate between two cgo calls).  Not
  * re-entrant.  Every other entry point may be called with or without holding it. */

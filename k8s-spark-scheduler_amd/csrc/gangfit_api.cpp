@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -70,8 +71,16 @@ struct DeviceBuf {
     T* ptr = nullptr;
     size_t cap = 0;  // elements
     bool fine = false;  // fine-grained (device-coherent) memory: buffers other devices store into / read from
+    bool borrowed = false;  // a view's alias of its parent's buffer (gf_ctx_view): never grown, never freed here
+    void alias(const DeviceBuf& o) {
+        if (!borrowed) release();
+        ptr = o.ptr;
+        cap = o.cap;
+        borrowed = true;
+    }
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
+        if (borrowed) return hipErrorInvalidValue;
         size_t want = cap ? cap : 256;
         while (want < n) want *= 2;
         T* fresh = nullptr;
@@ -84,9 +93,10 @@ struct DeviceBuf {
         return hipSuccess;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr && !borrowed) (void)hipFree(ptr);
         ptr = nullptr;
         cap = 0;
+        borrowed = false;
     }
 };
 
@@ -295,6 +305,15 @@ struct gf_ctx {
     PinnedBuf<int32_t> h_failed;
     bool stats_on = false;
 
+    // ---- views (gf_ctx_view): contexts that fit on THIS context's installed snapshot with buffers and a stream of their own.
+    //      A view aliases the read-only tables of the snapshot; installs on the parent wait for the views' calls in flight
+    //      (views_mu: shared by a view's call, exclusive by an install), and a view re-aliases when the epoch has moved on.
+    gf_ctx* view_of = nullptr;
+    uint64_t view_epoch = 0;     // parent snap_epoch the aliases were taken at
+    std::shared_mutex views_mu;  // (in the parent)
+    int install_depth = 0;       // (in the parent, under mu) nested installs take views_mu once
+    int n_views = 0;             // (in the parent, under mu) live views
+
     // ---- incremental FIFO chains (gf_fit_batch, GF_MODE_FIFO_CHAIN).  The reference replays every earlier driver on every
     //      Filter (resource.go:309-328); with an unchanged snapshot driver j + 1's chain is driver j's chain plus one
     //      application.  The chain kernels therefore dump their working table every 2^shift applications (ChainCkpt), the
@@ -333,6 +352,33 @@ int fail(gf_ctx* ctx, int code, const char* fmt, ...) {
     if (ctx) ctx->err = buf;
     return code;
 }
+
+// An install on a context that has views: exclusive against the views' calls in flight (taken once per outermost install;
+// ctx->mu is held, so the depth counter needs no further protection).
+struct InstallGuard {
+    gf_ctx* c;
+    explicit InstallGuard(gf_ctx* ctx) : c(ctx) {
+        if (c->install_depth++ == 0) c->views_mu.lock();
+    }
+    ~InstallGuard() {
+        if (--c->install_depth == 0) c->views_mu.unlock();
+    }
+    InstallGuard(const InstallGuard&) = delete;
+    InstallGuard& operator=(const InstallGuard&) = delete;
+};
+
+int view_refresh(gf_ctx* v);
+
+// At the top of every entry point that READS the installed snapshot (after ctx->mu): a view holds its parent's views_mu
+// shared for the whole call and re-aliases the parent's tables when a new snapshot has been installed since.
+#define GF_VIEW_ENTER(ctx)                                                               \
+    std::shared_lock<std::shared_mutex> view_lock__;                                     \
+    if ((ctx)->view_of != nullptr) {                                                     \
+        view_lock__ = std::shared_lock<std::shared_mutex>((ctx)->view_of->views_mu);     \
+        if (const int vrc__ = view_refresh(ctx); vrc__ != GF_OK) return vrc__;           \
+    }
+#define GF_NOT_ON_A_VIEW(ctx) \
+    if ((ctx)->view_of != nullptr) return fail((ctx), GF_ERR_STATE, "a view fits on its parent's snapshot: it does not install one")
 
 #define GF_HIP(ctx, call)                                                                                    \
     do {                                                                                                     \
@@ -863,6 +909,61 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     return GF_OK;
 }
 
+// Point a view at the snapshot its parent holds now (the caller holds the parent's views_mu shared: no install is running).
+int view_refresh(gf_ctx* v) {
+    const gf_ctx* p = v->view_of;
+    if (v->view_epoch == p->snap_epoch) return GF_OK;
+    GF_HIP(v, hipSetDevice(v->device));
+    GF_HIP(v, gf_wait_stream(v->stream));
+    v->n_nodes = p->n_nodes;
+    v->have_snapshot = p->have_snapshot;
+    v->have_sched = p->have_sched;
+    v->have_orders = p->have_orders;
+    v->n_x = p->n_x;
+    v->n_d = p->n_d;
+    v->n_slots = p->n_slots;
+    v->n_chunks = p->n_chunks;
+    v->d_identity = p->d_identity;
+    v->merged = p->merged;
+    v->n_g = p->n_g;
+    v->n_gpad = p->n_gpad;
+    v->narrow_ok = p->narrow_ok;
+    for (int j = 0; j < 3; ++j) {
+        v->unit[j] = p->unit[j];
+        v->nmax[j] = p->nmax[j];
+    }
+    v->n_zones = p->n_zones;
+    v->zstride = p->zstride;
+    v->zd_row0 = p->zd_row0;
+    v->d_snap.alias(p->d_snap);
+    v->d_slot_node.alias(p->d_slot_node);
+    v->d_dslot.alias(p->d_dslot);
+    v->d_node_slot.alias(p->d_node_slot);
+    v->d_cmax.alias(p->d_cmax);
+    v->d_masks.alias(p->d_masks);
+    v->d_gtab.alias(p->d_gtab);
+    v->d_gcmax.alias(p->d_gcmax);
+    v->d_gidx.alias(p->d_gidx);
+    v->d_gmask.alias(p->d_gmask);
+    v->d_nsnap.alias(p->d_nsnap);
+    v->d_ncmax.alias(p->d_ncmax);
+    v->d_sched.alias(p->d_sched);
+    v->d_node_tab.alias(p->d_node_tab);
+    v->d_zmasks.alias(p->d_zmasks);
+    // the working copies are the view's own
+    if (v->have_orders) {
+        GF_HIP(v, v->d_work.reserve(3 * (size_t)v->n_slots));
+        if (v->narrow_ok) GF_HIP(v, v->d_nwork.reserve(3 * (size_t)v->n_slots));
+    }
+    v->work_valid = false;
+    v->host_stale = true;  // host mirrors (residuals, efficiencies) are fetched from the aliased device tables when asked for
+    v->cnt_slots = 0;      // the multiplicity scratch is sized by n_slots
+    v->cnt_rows = 0;
+    ++v->snap_epoch;       // drops the view's chain cache and recorded graphs
+    v->view_epoch = p->snap_epoch;
+    return GF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -967,6 +1068,29 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     return GF_OK;
 }
 
+int gf_ctx_view(gf_ctx* parent, gf_ctx** out) {
+    if (!parent || !out) return GF_ERR_INVALID;
+    *out = nullptr;
+    if (!parent->group.empty()) return fail(parent, GF_ERR_UNSUPPORTED, "views of a multi-device context are not served");
+    if (parent->view_of != nullptr) parent = parent->view_of;  // a view of a view is a view of the same parent
+    gf_ctx* v = nullptr;
+    const int rc = gf_init(&parent->device, 1, &v);
+    if (rc != GF_OK) return rc;
+    {
+        std::lock_guard<std::recursive_mutex> lock(parent->mu);
+        ++parent->n_views;
+        v->lds_budget = parent->lds_budget;
+        v->fifo_generic = parent->fifo_generic;
+        v->fifo_minfrag_matrix = parent->fifo_minfrag_matrix;
+        v->fifo_minfrag_hist = parent->fifo_minfrag_hist;
+        v->chain_cache_on = parent->chain_cache_on;
+        v->zero_copy = parent->zero_copy;
+    }
+    v->view_of = parent;
+    *out = v;
+    return GF_OK;
+}
+
 void gf_destroy(gf_ctx* ctx) {
     if (!ctx) return;
     if (!ctx->group.empty()) {
@@ -984,6 +1108,10 @@ void gf_destroy(gf_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)gf_wait_stream(ctx->stream);
+    if (ctx->view_of != nullptr) {
+        std::lock_guard<std::recursive_mutex> plock(ctx->view_of->mu);
+        --ctx->view_of->n_views;
+    }
     ctx->d_snap.release();
     ctx->d_work.release();
     ctx->d_slot_node.release();
@@ -1304,6 +1432,8 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
     GF_EACH(ctx, gf_snapshot_set(ctx, n_nodes, avail_cpu_milli, avail_mem_bytes, avail_gpu, sched_cpu_milli, sched_mem_bytes, sched_gpu));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
+    InstallGuard install_guard(ctx);
     if (n_nodes > 0 && (!avail_cpu_milli || !avail_mem_bytes || !avail_gpu))
         return fail(ctx, GF_ERR_INVALID, "available arrays must not be NULL");
     if (n_nodes >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "too many nodes");
@@ -1351,6 +1481,8 @@ int gf_zones_set(gf_ctx* ctx, const uint32_t* zone_of_node) {
     GF_EACH(ctx, gf_zones_set(ctx, zone_of_node));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
+    InstallGuard install_guard(ctx);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_zones_set");
     if (ctx->n_nodes > 0 && !zone_of_node) return fail(ctx, GF_ERR_INVALID, "zone array must not be NULL");
     ctx->zone.assign(zone_of_node, zone_of_node + ctx->n_nodes);
@@ -1363,6 +1495,8 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     GF_EACH(ctx, gf_orders_set(ctx, driver_order, n_d, exec_order, n_x));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
+    InstallGuard install_guard(ctx);
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set must precede gf_orders_set");
     if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     if ((n_d > 0 && !driver_order) || (n_x > 0 && !exec_order))
@@ -1710,6 +1844,7 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         return group_fit_batch(ctx, mode, algo, n_apps, apps, results, exec_nodes, exec_nodes_cap, chain_failed_at);
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (n_apps > 0 && (!apps || !results)) return fail(ctx, GF_ERR_INVALID, "apps/results must not be NULL");
     if (chain_failed_at) *chain_failed_at = -1;
     if (n_apps == 0) return GF_OK;
@@ -1798,7 +1933,8 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
                      void* stream) {
     GF_DELEGATE(ctx, gf_fit_batch_dev(ctx, mode, algo, n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, stream));
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);  // launch() grows buffers and flips state flags
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)  // launch() grows buffers and flips state flags
     if (n_apps > 0 && (!d_apps || !d_results)) return fail(ctx, GF_ERR_INVALID, "device apps/results must not be NULL");
     if (mode == GF_MODE_FIFO_CHAIN && !d_chain_failed_at) d_chain_failed_at = ctx->d_failed.ptr;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
@@ -1882,6 +2018,7 @@ int gf_cluster_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_milli
                                 over_gpu, node_flags, zone_of_node, n_zones, name_rank));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
     ctx->have_cluster = false;
     const uint32_t n = n_nodes;
     if (n >= GF_NO_NODE) return fail(ctx, GF_ERR_INVALID, "too many nodes");
@@ -1961,7 +2098,8 @@ int gf_snapshot_build(gf_ctx* ctx, uint32_t n_nodes, const int64_t* alloc_cpu_mi
                       const uint32_t* driver_label_rank, const uint32_t* exec_label_rank, uint32_t* driver_order_out,
                       uint32_t* n_d_out, uint32_t* exec_order_out, uint32_t* n_x_out) {
     if (!ctx) return GF_ERR_INVALID;
-    std::lock_guard<std::recursive_mutex> lock(ctx->mu);  // cluster + build are one sequence
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);  // cluster + build are one sequence
     const int rc = gf_cluster_set(ctx, n_nodes, alloc_cpu_milli, alloc_mem_bytes, alloc_gpu, over_cpu_milli, over_mem_bytes,
                                   over_gpu, node_flags, zone_of_node, n_zones, name_rank);
     if (rc != GF_OK) return rc;
@@ -1973,6 +2111,7 @@ int gf_usage_reset(gf_ctx* ctx) {
     GF_EACH(ctx, gf_usage_reset(ctx));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
     if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_usage_reset");
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, hipMemsetAsync(ctx->d_cl_usage.ptr, 0, (3 * (size_t)ctx->cl_n + 1) * sizeof(int64_t), ctx->stream));
@@ -2002,6 +2141,7 @@ int gf_usage_apply(gf_ctx* ctx, uint32_t n_entries, const uint32_t* res_node, co
     }
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
     if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_usage_apply");
     if (!ctx->usage_ok) return fail(ctx, GF_ERR_STATE, "an earlier update failed half way: gf_usage_reset must rebuild the resident usage");
     if (sign != 1 && sign != -1) return fail(ctx, GF_ERR_INVALID, "sign must be +1 or -1");
@@ -2076,6 +2216,8 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     }
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
+    InstallGuard install_guard(ctx);
     if (!ctx->have_cluster) return fail(ctx, GF_ERR_STATE, "gf_cluster_set must precede gf_snapshot_build_resident");
     const uint32_t n = ctx->cl_n;
     const uint32_t n_zones = ctx->cl_zones;
@@ -2336,6 +2478,7 @@ int gf_snapshot_get(gf_ctx* ctx, int64_t* avail_out, int64_t* sched_out) {
     GF_DELEGATE(ctx, gf_snapshot_get(ctx, avail_out, sched_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (!ctx->have_snapshot) return fail(ctx, GF_ERR_STATE, "no snapshot");
     if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     for (uint32_t i = 0; i < ctx->n_nodes; ++i)
@@ -2351,6 +2494,7 @@ int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, cons
     GF_DELEGATE(ctx, gf_executor_fit(ctx, minimal_fragmentation, n_req, exe, reserved, hosts_app, node_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (n_req == 0) return GF_OK;
     if (!exe || !node_out) return fail(ctx, GF_ERR_INVALID, "exe/node_out must not be NULL");
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede gf_executor_fit");
@@ -2389,6 +2533,7 @@ int gf_find_nodes(gf_ctx* ctx, int chained, uint32_t n_req, const int64_t* exe, 
     GF_DELEGATE(ctx, gf_find_nodes(ctx, chained, n_req, exe, k, results, exec_nodes, exec_nodes_cap, reserved_adds));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (n_req == 0) return GF_OK;
     if (!exe || !k || !results) return fail(ctx, GF_ERR_INVALID, "exe/k/results must not be NULL");
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede gf_find_nodes");
@@ -2461,6 +2606,7 @@ int gf_shard_set(gf_ctx* ctx, uint32_t shard, uint32_t n_shards) {
         return fail(ctx, GF_ERR_UNSUPPORTED, "a multi-device context runs the shard steps and their exchanges itself (gf_fit_batch)");
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_NOT_ON_A_VIEW(ctx);
     if (n_shards == 0 || shard >= n_shards || n_shards > 1024)
         return fail(ctx, GF_ERR_INVALID, "shard %u of %u", shard, n_shards);
     ctx->shard = shard;
@@ -2536,6 +2682,7 @@ int gf_avg_packing_efficiency(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const 
     GF_DELEGATE(ctx, gf_avg_packing_efficiency(ctx, algo, n_apps, apps, results, exec_nodes, exec_nodes_len, out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (n_apps > 0 && (!apps || !results || !out)) return fail(ctx, GF_ERR_INVALID, "apps/results/out must not be NULL");
     if (n_apps == 0) return GF_OK;
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede");
@@ -2594,6 +2741,7 @@ int gf_packing_efficiencies(gf_ctx* ctx, gf_algo algo, const gf_app* app, const 
     GF_DELEGATE(ctx, gf_packing_efficiencies(ctx, algo, app, result, exec_nodes, eff_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (!app || !result || !eff_out) return fail(ctx, GF_ERR_INVALID, "app/result/eff_out must not be NULL");
     if (!ctx->have_snapshot || !ctx->have_sched)
         return fail(ctx, GF_ERR_STATE, "efficiencies need gf_snapshot_set with the schedulable columns");
@@ -2632,6 +2780,7 @@ int gf_residual_get(gf_ctx* ctx, int64_t* avail_out) {
     GF_DELEGATE(ctx, gf_residual_get(ctx, avail_out));
     if (!ctx || !avail_out) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
     if (!ctx->have_orders || !ctx->work_valid) return fail(ctx, GF_ERR_STATE, "no FIFO chain has run on the current orders");
     if (int mrc = materialize_host(ctx); mrc != GF_OK) return mrc;
     GF_HIP(ctx, hipSetDevice(ctx->device));

@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
     "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
-    "gf_usage_reset", "gf_usage_apply", "gf_set_option", "gf_chain_cache_stats", "gf_generation", "gf_shard_count",
+    "gf_usage_reset", "gf_usage_apply", "gf_set_option", "gf_chain_cache_stats", "gf_generation", "gf_shard_count", "gf_ctx_view",
 ]
 
 
@@ -168,6 +168,8 @@ def load() -> C.CDLL:
     L.gf_device_info_get.argtypes = [p, C.POINTER(DeviceInfo)]
     L.gf_set_option.restype = i32
     L.gf_set_option.argtypes = [p, C.c_char_p, C.c_int64]
+    L.gf_ctx_view.restype = i32
+    L.gf_ctx_view.argtypes = [p, C.POINTER(p)]
     L.gf_shard_count.restype = i32
     L.gf_shard_count.argtypes = [p]
     L.gf_generation.restype = i32

@@ -69,6 +69,14 @@ class Context:
         for key, value in (options or {}).items():
             self.set_option(key, value)
 
+    def view(self) -> "Context":
+        """gf_ctx_view: a context with its own stream and working tables that fits on THIS context's installed snapshot."""
+        h = C.c_void_p()
+        self._check(self._lib.gf_ctx_view(self._h, C.byref(h)))
+        v = _View.__new__(_View)
+        v._lib, v._h, v._parent = self._lib, h, self
+        return v
+
     def set_option(self, key: str, value: int):
         self._check(self._lib.gf_set_option(self._h, key.encode(), int(value)))
 
@@ -380,3 +388,15 @@ class Context:
         return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
                 "lds_bytes_per_cu": info.lds_bytes_per_cu, "wavefront_size": info.wavefront_size,
                 "clock_khz": info.clock_khz, "hbm_bytes": info.hbm_bytes}
+
+
+class _View(Context):
+    """A gf_ctx_view handle: same calls, the node count is the parent's."""
+
+    @property
+    def n_nodes(self):
+        return self._parent.n_nodes
+
+    @n_nodes.setter
+    def n_nodes(self, value):
+        raise AttributeError("a view does not install snapshots")

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <set>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -855,6 +856,133 @@ static void TestTwoThreadsOneContext() {
     CHECK(bad_scan.load() == 0);
 }
 
+// ------------------------------------------------------------------------------------------------ views: concurrent chains
+// gf_ctx_view (include/gangfit.h): eight views of one context run eight 999 + 1 FIFO chains (different heads of one queue) at
+// the same time.  Each chain is one workgroup, so eight of them occupy eight compute units: they must finish in about the time
+// of one, every view's results and residual table must be the ones it gets when it runs alone (no cross-talk), and the parent
+// keeps answering an independent batch in between.
+static void TestConcurrentViews() {
+    const uint32_t n = 10000, n_apps = 1000, n_views = 8;
+    uint64_t rng = 0xC0FFEE;
+    auto next = [&]() {
+        rng += 0x9E3779B97F4A7C15ull;
+        uint64_t z = rng;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    std::vector<int64_t> cpu(n), mem(n), gpu(n, 0);
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        cpu[i] = (int64_t)(4 + next() % 60) * 1000;
+        mem[i] = (int64_t)(8 + next() % 248) * Gi;
+        order[i] = i;
+    }
+    gf_ctx* parent = nullptr;
+    CHECK(gf_init(nullptr, 0, &parent) == GF_OK);
+    if (!parent) return;
+    CHECK(gf_set_option(parent, "chain_cache", 0) == GF_OK);  // every chain replays: what is timed is eight full chains
+    CHECK(gf_snapshot_set(parent, n, cpu.data(), mem.data(), gpu.data(), nullptr, nullptr, nullptr) == GF_OK);
+    CHECK(gf_orders_set(parent, order.data(), n, order.data(), n) == GF_OK);
+    std::vector<gf_app> queue(n_apps);
+    uint64_t total_k = 0;
+    for (gf_app& a : queue) {
+        a = gf_app{};
+        a.drv[0] = 1000 * (int64_t)(1 + next() % 3);
+        a.drv[1] = (int64_t)(2 << (next() % 3)) * Gi;
+        a.exe[0] = 1000 * (int64_t)(1 << (next() % 4));
+        a.exe[1] = (int64_t)(4 << (next() % 4)) * Gi;
+        a.k = 1 + (int32_t)(next() % 24);
+        a.flags = GF_APP_SKIPPABLE;
+        total_k += (uint64_t)a.k;
+    }
+    struct Run {
+        gf_ctx* v = nullptr;
+        std::vector<gf_app> apps;
+        std::vector<gf_result> res, want_res;
+        std::vector<uint32_t> exec, want_exec;
+        std::vector<int64_t> resid, want_resid;
+        int32_t failed = -1;
+    };
+    std::vector<Run> runs(n_views);
+    bool ok = true;
+    for (uint32_t i = 0; i < n_views; ++i) {
+        Run& r = runs[i];
+        ok = ok && gf_ctx_view(parent, &r.v) == GF_OK;
+        r.apps.assign(queue.begin() + i, queue.end());
+        r.apps.insert(r.apps.end(), queue.begin(), queue.begin() + i);  // another head
+        uint64_t off = 0;
+        for (gf_app& a : r.apps) {  // (gf_fit_batch fills exec_off in its own copy; the comparison below needs it here)
+            a.exec_off = off;
+            off += (uint64_t)a.k;
+        }
+        r.res.resize(n_apps);
+        r.want_res.resize(n_apps);
+        r.exec.resize(total_k + 1);
+        r.want_exec.resize(total_k + 1);
+        r.resid.resize(3 * (size_t)n);
+        r.want_resid.resize(3 * (size_t)n);
+    }
+    CHECK(ok);
+    if (!ok) return;
+    auto chain = [&](Run& r, std::vector<gf_result>& res, std::vector<uint32_t>& exec) {
+        return gf_fit_batch(r.v, GF_MODE_FIFO_CHAIN, GF_ALGO_TIGHTLY_PACK, n_apps, r.apps.data(), res.data(), exec.data(), total_k, &r.failed);
+    };
+    for (Run& r : runs) {  // alone: the answers to reproduce (and warm buffers)
+        ok = ok && chain(r, r.want_res, r.want_exec) == GF_OK && gf_residual_get(r.v, r.want_resid.data()) == GF_OK;
+    }
+    CHECK(ok);
+    using Clock = std::chrono::steady_clock;
+    const int reps = 10;
+    auto t0 = Clock::now();
+    for (int i = 0; i < reps; ++i) ok = ok && chain(runs[0], runs[0].res, runs[0].exec) == GF_OK;
+    const double one_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / reps;
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    t0 = Clock::now();
+    for (uint32_t i = 0; i < n_views; ++i)
+        th.emplace_back([&, i] {
+            Run& r = runs[i];
+            for (int it = 0; it < reps; ++it) {
+                if (chain(r, r.res, r.exec) != GF_OK || gf_residual_get(r.v, r.resid.data()) != GF_OK) ++bad;
+                if (std::memcmp(r.res.data(), r.want_res.data(), n_apps * sizeof(gf_result)) != 0 || r.resid != r.want_resid) ++bad;
+                for (uint32_t a = 0; a < n_apps; ++a)
+                    if (r.want_res[a].has_capacity &&
+                        std::memcmp(&r.exec[r.apps[a].exec_off], &r.want_exec[r.apps[a].exec_off], r.want_res[a].exec_len * 4u) != 0) {
+                        ++bad;
+                        break;
+                    }
+            }
+        });
+    // the parent answers an independent batch while the views walk their chains
+    std::vector<gf_result> pres(n_apps);
+    std::vector<uint32_t> pexec(total_k + 1);
+    bool parent_ok = true;
+    for (int it = 0; it < 20; ++it)
+        parent_ok = parent_ok && gf_fit_batch(parent, GF_MODE_INDEPENDENT, GF_ALGO_TIGHTLY_PACK, n_apps, queue.data(), pres.data(),
+                                              pexec.data(), total_k, nullptr) == GF_OK;
+    for (std::thread& t : th) t.join();
+    const double eight_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / reps;
+    CHECK(parent_ok);
+    CHECK(bad.load() == 0);
+    std::printf("   one chain %.3f ms; eight concurrent chains (+ residual reads) %.3f ms per round = %.2fx\n", one_ms, eight_ms,
+                eight_ms / one_ms);
+    CHECK(eight_ms < 1.6 * one_ms);  // (each round also fetches the 240 KB residual table; the chains themselves overlap)
+    // the residuals of different heads differ: the views really worked on tables of their own
+    CHECK(runs[0].want_resid != runs[1].want_resid);
+    // installs are refused on a view; a new snapshot on the parent is what the views see next
+    CHECK(gf_orders_set(runs[0].v, order.data(), n, order.data(), n) == GF_ERR_STATE);
+    for (uint32_t i = 0; i < 200; ++i) cpu[i] = 0;
+    CHECK(gf_snapshot_set(parent, n, cpu.data(), mem.data(), gpu.data(), nullptr, nullptr, nullptr) == GF_OK);
+    CHECK(gf_orders_set(parent, order.data(), n, order.data(), n) == GF_OK);
+    CHECK(chain(runs[0], runs[0].res, runs[0].exec) == GF_OK);
+    CHECK(std::memcmp(runs[0].res.data(), runs[0].want_res.data(), n_apps * sizeof(gf_result)) != 0);
+    std::vector<int64_t> snap(3 * (size_t)n);
+    CHECK(gf_snapshot_get(runs[0].v, snap.data(), nullptr) == GF_OK && snap[0] == 0 && snap[3 * 199] == 0 && snap[3 * 200] == cpu[200]);
+    for (Run& r : runs) gf_destroy(r.v);
+    gf_destroy(parent);
+}
+
 // ------------------------------------------------------------------------------------------------ one context, several devices
 // gf_init with n_dev > 1 (include/gangfit.h): the Go shim reaches node-range sharding by passing more device ids, nothing
 // else changes.  Driven here through gangfit.h only (no torch, no Python): the sharded batch must equal the one-device one.
@@ -961,6 +1089,7 @@ int main(int argc, char** argv) {
         TestIncrementalFilters();
         TestFindNodes();
         TestTwoThreadsOneContext();
+        TestConcurrentViews();
         TestMultiDeviceContext();
         gf_destroy(g_ctx);
     }
