@@ -973,6 +973,14 @@ int gf_version(void) { return GF_VERSION; }
 int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (!out) return GF_ERR_INVALID;
     *out = nullptr;
+    // The HIP runtime multiplexes streams over a few hardware queues (four by default), and two FIFO chains whose streams
+    // share a queue run one after the other: eight views took 3.1x one chain's time with four queues, 1.1x with sixteen
+    // (host_test gpu, TestConcurrentViews).  The variable is read when the runtime initialises — normally the first HIP call
+    // below — and a value the host already set is left alone.
+    {
+        static std::once_flag once;
+        std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); });
+    }
     if (n_dev > 1) {
         // One context over several devices: sub-context i owns range i of n_dev of the priority order.  A device id may
         // repeat (several shards on one GPU: how the path is exercised on a one-GPU box).
@@ -1903,13 +1911,35 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         ctx->chain.valid = false;
         return rc;
     }
-    GF_HIP(ctx, hipMemcpyAsync(ctx->h_results.ptr + a0, ctx->d_results.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_result),
-                               hipMemcpyDeviceToHost, st));
-    if (total_k > k0)
-        GF_HIP(ctx, hipMemcpyAsync(ctx->h_exec.ptr + k0, ctx->d_exec.ptr + k0, (size_t)(total_k - k0) * sizeof(uint32_t),
+    // The answers travel to the pinned host buffers by ONE kernel (posted writes) when the buffers are device-mapped: three
+    // copy-engine transfers behind the last kernel are three hand-overs between the compute queue and a copy engine — a
+    // visible part of a resumed chain, and what keeps chains on different streams from overlapping.
+    void *dr = nullptr, *de = nullptr, *df = nullptr;
+    const bool mapped = ctx->zero_copy && hipHostGetDevicePointer(&dr, ctx->h_results.ptr, 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&de, ctx->h_exec.ptr, 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&df, ctx->h_failed.ptr, 0) == hipSuccess;
+    if (mapped) {
+        gangfit::CopyOut co{};
+        co.src[0] = reinterpret_cast<const uint32_t*>(ctx->d_results.ptr + a0);
+        co.dst[0] = reinterpret_cast<uint32_t*>(static_cast<gf_result*>(dr) + a0);
+        co.words[0] = (size_t)(n_apps - a0) * (sizeof(gf_result) / 4);
+        co.src[1] = ctx->d_exec.ptr + k0;
+        co.dst[1] = static_cast<uint32_t*>(de) + k0;
+        co.words[1] = (size_t)(total_k - k0);
+        co.src[2] = reinterpret_cast<const uint32_t*>(ctx->d_failed.ptr);
+        co.dst[2] = static_cast<uint32_t*>(df);
+        co.words[2] = mode == GF_MODE_FIFO_CHAIN ? 1 : 0;
+        GF_HIP(ctx, gangfit::launch_copy_out(co, st));
+    } else {
+        (void)hipGetLastError();
+        GF_HIP(ctx, hipMemcpyAsync(ctx->h_results.ptr + a0, ctx->d_results.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_result),
                                    hipMemcpyDeviceToHost, st));
-    if (mode == GF_MODE_FIFO_CHAIN)
-        GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_failed.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (total_k > k0)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->h_exec.ptr + k0, ctx->d_exec.ptr + k0, (size_t)(total_k - k0) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, st));
+        if (mode == GF_MODE_FIFO_CHAIN)
+            GF_HIP(ctx, hipMemcpyAsync(ctx->h_failed.ptr, ctx->d_failed.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
     const hipError_t we = gf_wait_stream(st);
     if (we != hipSuccess) {
         ctx->chain.valid = false;

@@ -315,6 +315,12 @@ struct SnapshotFinalize {
     int32_t* d_ncmax;           // 3 * n_chunks
 };
 hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t stream);
+struct CopyOut {  // three ranges of 32-bit words, any of them empty
+    const uint32_t* src[3];
+    uint32_t* dst[3];
+    size_t words[3];
+};
+hipError_t launch_copy_out(const CopyOut& c, hipStream_t stream);
 hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_stream_read(const void* src, size_t bytes, uint32_t* sink, hipStream_t stream);
 hipError_t launch_empty(uint32_t* sink, hipStream_t stream);

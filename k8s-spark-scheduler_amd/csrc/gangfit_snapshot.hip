@@ -661,6 +661,25 @@ __global__ __launch_bounds__(64) void empty_kernel(uint32_t* __restrict__ sink) 
     if (sink != nullptr && threadIdx.x == 1234567u) *sink = 0;
 }
 
+// Up to three word ranges copied by ONE kernel — the way a blocking entry point hands its answers to pinned host memory
+// (posted PCIe writes, visible when the kernel has completed) without leaving the compute queue for a copy engine.
+__global__ __launch_bounds__(256) void copy_out_kernel(CopyOut c) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        for (size_t i = t; i < c.words[r]; i += stride) c.dst[r][i] = c.src[r][i];
+}
+
+hipError_t launch_copy_out(const CopyOut& c, hipStream_t stream) {
+    const size_t total = c.words[0] + c.words[1] + c.words[2];
+    if (total == 0) return hipSuccess;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(copy_out_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, c);
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_copy(const void* src, void* dst, size_t bytes, hipStream_t stream) {
     const size_t n16 = bytes / 16;
     hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 32), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, n16);
