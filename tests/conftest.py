@@ -11,6 +11,7 @@ for p in (REPO, os.path.join(REPO, "k8s-spark-scheduler_amd"), os.path.join(REPO
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_stress: the randomised parity stress (a subset of -m gpu; GANGFIT_STRESS_SEEDS widens it)")
 
 
 def _gpu_present() -> bool:

@@ -8,7 +8,7 @@ import test_gpu_parity as T
 
 n, algo, layout = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 rng = np.random.default_rng(77 * (algo + 1) + n + 7 * len(layout))
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 for rep in range(3):
     a = 120
     avail, D, X, drv, exe, k = T._random_problem(rng, n, a, tight_cluster=(rep == 2), layout=layout)

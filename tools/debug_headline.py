@@ -7,7 +7,7 @@ from gangfit import workloads as wl
 from oracle import binding as ob
 algo = int(sys.argv[1]); congested = sys.argv[2] == "1"; n_apps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 w = wl.headline(congested=congested); s = w.snapshot
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 ctx.set_snapshot(s.avail, s.sched); ctx.set_orders(s.driver_order, s.exec_order)
 apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))[:n_apps]
 oapps = ob.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))[:n_apps]

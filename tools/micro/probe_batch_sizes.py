@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 out = []
 for name, w in (("headline", wl.headline(10000, 1000)), ("config3", wl.config(3)), ("config4", wl.config(4)), ("congested", wl.headline(10000, 1000, congested=True))):
     s = w.snapshot
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})
     ctx.set_snapshot(s.avail, s.sched)
     ctx.set_orders(s.driver_order, s.exec_order)
     for algo in (0, 1):

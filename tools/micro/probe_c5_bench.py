@@ -16,7 +16,7 @@ flags5 = np.full(n5, 2 | 4, dtype=np.uint32)
 ranks5 = np.arange(n5, dtype=np.uint32)
 alloc5 = w5.snapshot.sched + 0
 q5 = gangfit.make_apps(w5.drv, w5.exe, w5.k, w5.flags)
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 ctx.build_snapshot(alloc5, flags5, ranks5, res_node=rnode, res_req=rreq, want_orders=False)
 for n_apps in (1, 100, 1000):
     apps = q5[:n_apps]

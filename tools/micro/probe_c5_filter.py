@@ -16,7 +16,7 @@ flags5 = np.full(n5, 2 | 4, dtype=np.uint32)
 ranks5 = np.arange(n5, dtype=np.uint32)
 alloc5 = w5.snapshot.sched + 0
 q5 = gangfit.make_apps(w5.drv, w5.exe, w5.k, w5.flags)
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 rcols = [np.ascontiguousarray(rreq[:, j]) for j in range(3)]
 def p50(f, n=40):
     for _ in range(3): f()

@@ -8,7 +8,7 @@ from gangfit import workloads as wl
 for n_nodes in (10000, 100000):
     w = wl.config(5, n_nodes=n_nodes)
     s = w.snapshot
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})
     ctx.set_snapshot(s.avail, s.sched)
     ctx.set_orders(s.driver_order, s.exec_order)
     out = []

@@ -8,7 +8,7 @@ import gangfit
 from gangfit import workloads as wl
 w = wl.headline(10000, 1000)
 s = w.snapshot
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 ctx.set_snapshot(s.avail, s.sched)
 ctx.set_orders(s.driver_order, s.exec_order)
 rng = np.random.default_rng(1)

@@ -9,7 +9,7 @@ w = wl.headline(10000, 1000)
 s = w.snapshot
 zone3 = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
 apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})  # every chain replays: these probes time the kernels
 ctx.set_snapshot(s.avail, s.sched)
 ctx.set_zones(zone3)
 ctx.set_orders(s.driver_order, s.exec_order)

@@ -10,7 +10,7 @@ from gangfit import workloads as wl
 dev = torch.device("cuda:0")
 w = wl.config(3)
 s = w.snapshot
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 ctx.set_snapshot(s.avail, s.sched)
 ctx.set_orders(s.driver_order, s.exec_order)
 def run(label, drv, exe, k):

@@ -10,7 +10,7 @@ from gangfit import workloads as wl
 w = wl.headline(10000, 1000)
 s = w.snapshot
 dev = torch.device("cuda:0")
-with gangfit.Context(0) as ctx:
+with gangfit.Context(0, options={"chain_cache": 0}) as ctx:
     ctx.set_snapshot(s.avail, s.sched)
     ctx.set_orders(s.driver_order, s.exec_order)
     stream = torch.cuda.current_stream().cuda_stream

@@ -7,7 +7,7 @@ from gangfit import workloads as wl
 for n_nodes in (20000, 40000, 100000):
     w = wl.headline(n_nodes, 1000)
     s = w.snapshot
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})
     ctx.set_snapshot(s.avail, s.sched)
     zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(3)).astype(np.uint32)
     ctx.set_zones(zone)

@@ -13,7 +13,7 @@ w = {"headline": lambda: wl.headline(10000, 1000), "config3": lambda: wl.config(
      "congested": lambda: wl.headline(10000, 1000, congested=True)}[name]()
 dev = torch.device("cuda:0")
 s = w.snapshot
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 ctx.set_snapshot(s.avail, s.sched)
 ctx.set_orders(s.driver_order, s.exec_order)
 a2, tk = gangfit.with_offsets(gangfit.make_apps(w.drv, w.exe, w.k, w.flags))

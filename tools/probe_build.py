@@ -4,7 +4,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "k8s-spark-scheduler_amd")]
 import gangfit
 from gangfit import workloads as wl
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 for n_nodes, n_rr in ((10000, 2000), (100000, 20000)):
     rng = np.random.default_rng(n_nodes)
     shape = rng.integers(0, 4, size=n_nodes)

@@ -16,7 +16,7 @@ def t(f, n=5):
 for n_nodes in (10000, 100000):
     w = wl.config(5, n_nodes=n_nodes)
     s = w.snapshot
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})
     print(n_nodes, "set_snapshot ms", t(lambda: ctx.set_snapshot(s.avail, s.sched)))
     print(n_nodes, "set_orders   ms", t(lambda: ctx.set_orders(s.driver_order, s.exec_order)))
     t0 = time.perf_counter(); o = wl.reference_node_order(s.avail); print(n_nodes, "numpy lexsort ms", (time.perf_counter() - t0) * 1e3)

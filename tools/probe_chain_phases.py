@@ -10,7 +10,7 @@ s = w.snapshot
 zone3 = (wl.splitmix64(0xA3, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
 apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
 for nz in (1, 3):
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})
     ctx.set_snapshot(s.avail, s.sched)
     ctx.set_zones(zone3 if nz == 3 else np.zeros(len(s.avail), dtype=np.uint32))
     ctx.set_orders(s.driver_order, s.exec_order)

@@ -10,7 +10,7 @@ azmajor = len(sys.argv) > 1 and sys.argv[1] == "azmajor"
 for n_nodes, nz in ((10000, 1), (10000, 3), (100000, 3)):
     w = wl.headline(n_nodes, 1000)
     s = w.snapshot
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})
     ctx.set_snapshot(s.avail, s.sched)
     zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32)
     ctx.set_zones(zone)

@@ -9,7 +9,7 @@ from gangfit import workloads as wl
 
 def prof(name, w, algo=0):
     s = w.snapshot
-    ctx = gangfit.Context(0)
+    ctx = gangfit.Context(0, options={"chain_cache": 0})  # every chain replays: these probes time the kernels
     ctx.set_snapshot(s.avail, s.sched)
     ctx.set_orders(s.driver_order, s.exec_order)
     apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)

@@ -9,7 +9,7 @@ n_nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 nz = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 w = wl.headline(n_nodes, 1000)
 s = w.snapshot
-ctx = gangfit.Context(0)
+ctx = gangfit.Context(0, options={"chain_cache": 0})
 ctx.set_snapshot(s.avail, s.sched)
 zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32)
 ctx.set_zones(zone)
