@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = [pytest.mark.gpu, pytest.mark.gpu_stress]
 
-SEEDS = int(os.environ.get("GANGFIT_STRESS_SEEDS", "160"))
+SEEDS = int(os.environ.get("GANGFIT_STRESS_SEEDS", "100"))
 CHUNK = 20
 
 
