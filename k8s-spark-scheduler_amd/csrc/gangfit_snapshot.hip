@@ -163,7 +163,7 @@ __global__ void zone_rank_kernel(uint32_t n_zones, const long long* __restrict__
 
 // ------------------------------------------------------------------------------------------------ the priority order
 // getNodeNamesInPriorityOrder (internal/sort/nodesorting.go:95-122): nodes by (zone rank, free memory, free cpu, name), all
-// ascending.  ONE launch of kSortWG single-wavefront workgroups (cooperative: all resident) that meet at a grid barrier:
+// ascending.  ONE launch of kSortWG single-wavefront workgroups that meet at a grid barrier:
 //   1. the range of every column comes from metadata_kernel (min, max, common trailing zeros of the differences): a field
 //      needs bits(max - min) bits, less the trailing zeros every difference shares (free memory is a multiple of hundreds
 //      of MiB on real clusters: 39 bits shrink to about 11);
@@ -200,7 +200,8 @@ __device__ __forceinline__ uint32_t bits_of(unsigned long long v) { return v ? 6
 
 // Grid barrier of the kSortWG single-wavefront workgroups (sense by generation).  Everything a wavefront wrote before is
 // visible to every wavefront behind it (agent-scope release / acquire: the XCDs' L2s are written back and invalidated).
-// false = the others did not arrive (never expected with a cooperative launch): the caller flags the error and leaves.
+// false = the others did not arrive in about half a second (a device saturated by someone else's endless kernel): the caller
+// flags the error and leaves.
 __device__ __forceinline__ bool sort_grid_sync(uint32_t* state, int lane) {
     int ok = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -738,8 +739,12 @@ hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
                     {reinterpret_cast<unsigned long long*>(b.d_keys_a), reinterpret_cast<unsigned long long*>(b.d_keys_b),
                      reinterpret_cast<unsigned long long*>(b.d_keys_c)},
                     {b.d_perm_a, b.d_perm_b, b.d_perm_c}, b.d_sort_work};
-    void* args[] = {&ps};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(priority_sort_kernel), dim3(kSortWG), dim3(64), args, 0, stream);
+    // An ordinary launch: sixty-four one-wavefront workgroups become resident as soon as sixty-four wave slots are free (every
+    // other kernel of this library terminates on its own), and the grid barrier gives up with an error flag instead of
+    // spinning forever.  (hipLaunchCooperativeKernel would also promise residency, but rocprofv3 crashes at process exit
+    // behind a cooperative launch.)
+    hipLaunchKernelGGL(priority_sort_kernel, dim3(kSortWG), dim3(64), 0, stream, ps);
+    return hipGetLastError();
 }
 
 size_t snapshot_sort_work_words() { return kSortHistWords + kSortStateWords + 2u * kSortScalars; }
