@@ -335,8 +335,10 @@ struct gf_ctx {
         std::vector<gf_app> apps;     // the queue of the last chain (with exec_off)
         std::vector<gf_result> results;
         std::vector<uint32_t> exec;
-        DeviceBuf<int32_t> d_ckpt;    // [n][3 * n_slots]
-        size_t slot_words = 0;        // 3 * n_slots of the snapshot the buffer was laid out for
+        DeviceBuf<int32_t> d_ckpt;    // [n][slot_words]
+        size_t slot_words = 0;        // chain_ckpt_stride of the snapshot the buffer was laid out for
+        bool dirty_format = false;    // the checkpoints hold only the chunks that differ from the snapshot + their mask (the solo
+                                      // kernel on a table with a global tail): restored by a kernel instead of a copy
     } chain;
     uint64_t chain_stat[4] = {0, 0, 0, 0};  // chains | resumed chains | applications evaluated | applications skipped
 };
@@ -540,7 +542,7 @@ void narrow_units(const gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, int6
 // restore (nullable): a checkpoint of an earlier chain in the SAME units — the working copy starts from it instead of the
 // snapshot (incremental chains).
 int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t stream, gangfit::NarrowTable* nt,
-                 const int32_t* restore = nullptr) {
+                 const int32_t* restore = nullptr, bool restore_dirty_chunks = false) {
     int64_t eff[3];
     int32_t factor[3];
     narrow_units(ctx, h_apps, n_apps, eff, factor, nullptr);
@@ -549,16 +551,20 @@ int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t
     nt->gpu = nt->mem + ctx->n_slots;
     for (int j = 0; j < 3; ++j) nt->unit[j] = eff[j];
     const size_t table_bytes = 3 * (size_t)ctx->n_slots * sizeof(int32_t);
+    const bool whole = restore != nullptr && !restore_dirty_chunks;  // the checkpoint is the whole table
     if (factor[0] == 1 && factor[1] == 1 && factor[2] == 1) {
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, restore ? restore : ctx->d_nsnap.ptr, table_bytes, hipMemcpyDeviceToDevice, stream));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, whole ? restore : ctx->d_nsnap.ptr, table_bytes, hipMemcpyDeviceToDevice, stream));
         nt->cmax = ctx->d_ncmax.ptr;
-        return GF_OK;
+    } else {
+        GF_HIP(ctx, ctx->d_ncmax_w.reserve(3 * (size_t)ctx->n_chunks));
+        GF_HIP(ctx, gangfit::launch_narrow_rescale(ctx->d_nsnap.ptr, ctx->d_nwork.ptr, ctx->n_slots, ctx->d_ncmax.ptr,
+                                                   ctx->d_ncmax_w.ptr, ctx->n_chunks, factor, stream));
+        if (whole) GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, restore, table_bytes, hipMemcpyDeviceToDevice, stream));
+        nt->cmax = ctx->d_ncmax_w.ptr;
     }
-    GF_HIP(ctx, ctx->d_ncmax_w.reserve(3 * (size_t)ctx->n_chunks));
-    GF_HIP(ctx, gangfit::launch_narrow_rescale(ctx->d_nsnap.ptr, ctx->d_nwork.ptr, ctx->n_slots, ctx->d_ncmax.ptr,
-                                               ctx->d_ncmax_w.ptr, ctx->n_chunks, factor, stream));
-    if (restore) GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, restore, table_bytes, hipMemcpyDeviceToDevice, stream));
-    nt->cmax = ctx->d_ncmax_w.ptr;
+    // ... or only the chunks that differ from the snapshot (in the chain's units), laid over it
+    if (restore != nullptr && restore_dirty_chunks)
+        GF_HIP(ctx, gangfit::launch_ckpt_restore(ctx->d_nwork.ptr, restore, ctx->n_slots, ctx->n_chunks, stream));
     return GF_OK;
 }
 
@@ -571,13 +577,26 @@ struct ChainRun {
 
 // The checkpoint arguments of a chain kernel and the table it starts from.
 gangfit::ChainCkpt chain_ckpt_args(gf_ctx* ctx, const ChainRun* run, const int32_t** restore) {
-    gangfit::ChainCkpt ck{nullptr, run ? run->a_begin : 0u, ctx->chain.shift};
+    gangfit::ChainCkpt ck{nullptr, run ? run->a_begin : 0u, ctx->chain.shift, ctx->chain.slot_words, nullptr};
     *restore = nullptr;
     if (run != nullptr && (run->record || run->a_begin > 0)) {
         ck.base = ctx->chain.d_ckpt.ptr;
-        if (run->a_begin > 0) *restore = ck.base + (size_t)((run->a_begin >> ck.shift) - 1u) * ctx->chain.slot_words;
+        if (run->a_begin > 0) {
+            *restore = ck.base + (size_t)((run->a_begin >> ck.shift) - 1u) * ctx->chain.slot_words;
+            if (ctx->chain.dirty_format)
+                ck.resume_mask = reinterpret_cast<const unsigned long long*>(*restore + 3 * (size_t)ctx->n_slots + (ctx->n_slots & 1u));
+        }
     }
     return ck;
+}
+
+// Table slots the solo chain kernel keeps in LDS (whole 64-slot chunk blocks of 784 bytes next to its fixed tables).
+uint32_t solo_lds_slots(const gf_ctx* ctx) {
+    const size_t fixed = gangfit::fifo_solo_lds_bytes(0, ctx->n_chunks);
+    const size_t per_chunk = gangfit::fifo_solo_lds_bytes(64, ctx->n_chunks) - fixed;
+    const size_t fit = ctx->lds_budget > fixed ? (ctx->lds_budget - fixed) / per_chunk : 0;
+    const size_t whole = (ctx->n_slots + 63u) / 64u;
+    return (uint32_t)((fit < whole ? fit : whole) * 64u);
 }
 
 // Geometry of the LDS-resident chains of the zone-aware tightly-pack packers (gangfit_fifo_zoned.inc) and of the
@@ -730,12 +749,16 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
     gf_ctx::ChainCache& C = ctx->chain;
     if (mode != GF_MODE_FIFO_CHAIN || !ctx->chain_cache_on || ctx->stats_on || !ctx->have_orders) return false;
     if (!(ctx->merged && ctx->narrow_ok) || ctx->fifo_generic) return false;
+    bool solo = false, table_in_lds = false;
     {  // the LDS-resident chain kernel of this packer must be the one that serves (they dump and restore the checkpoints)
         uint32_t g0 = 0, g1 = 0;
         bool lds_chain = false;
         switch (algo) {
         case GF_ALGO_TIGHTLY_PACK:
-        case GF_ALGO_DISTRIBUTE_EVENLY: lds_chain = true; break;
+        case GF_ALGO_DISTRIBUTE_EVENLY:
+            lds_chain = solo = true;
+            g1 = solo_lds_slots(ctx);
+            break;
         case GF_ALGO_SINGLE_AZ_TIGHTLY_PACK: lds_chain = ctx->have_sched && zoned_lds_geometry(ctx, false, &g0, &g1); break;
         case GF_ALGO_AZ_AWARE_TIGHTLY_PACK: lds_chain = ctx->have_sched && zoned_lds_geometry(ctx, true, &g0, &g1); break;
         case GF_ALGO_MINIMAL_FRAGMENTATION: lds_chain = minfrag_lds_geometry(ctx, false, &g0, &g1); break;
@@ -743,20 +766,24 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
         default: break;
         }
         if (!lds_chain) return false;
+        table_in_lds = g1 >= ctx->n_slots;
     }
     int64_t eff[3];
     int32_t factor[3];
     bool proven = false;
     narrow_units(ctx, h_apps, n_apps, eff, factor, &proven);
     if (!proven) return false;
-    // checkpoint interval: 32 applications, wider when 128 dumps of this table would not fit 2 GiB
-    const size_t slot_words = 3 * (size_t)ctx->n_slots;
-    uint32_t shift = 5;
+    // checkpoint interval: 32 applications while a dump is cheap — the whole table from LDS, or (solo kernel, table with a
+    // global tail) only the chunks that differ from the snapshot; 128 where a dump copies a table that lives in global memory
+    // (the zone-aware and minimal-fragmentation chains beyond their LDS front); wider when 128 dumps would not fit 2 GiB
+    const size_t slot_words = gangfit::chain_ckpt_stride(ctx->n_slots, ctx->n_chunks);
+    const bool dirty_format = solo && !table_in_lds;
+    uint32_t shift = (table_in_lds || solo) ? 5 : 7;
     while (shift < 12 && (size_t)(4096u >> shift) * slot_words * sizeof(int32_t) > (UINT64_C(2) << 30)) ++shift;
     const size_t n_ck = (size_t)((n_apps - 1) >> shift);
     if (n_ck * slot_words * sizeof(int32_t) > (UINT64_C(4) << 30)) return false;
     uint32_t a_begin = 0;
-    const bool same = C.valid && C.epoch == ctx->snap_epoch && C.algo == (int)algo && C.shift == shift &&
+    const bool same = C.valid && C.epoch == ctx->snap_epoch && C.algo == (int)algo && C.shift == shift && C.dirty_format == dirty_format &&
                       C.slot_words == slot_words && C.unit[0] == eff[0] && C.unit[1] == eff[1] && C.unit[2] == eff[2];
     if (same) {
         // longest common prefix of the two queues, the last application of either excluded (nothing is committed behind
@@ -792,6 +819,7 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
     if (!same) C.valid = false;
     C.shift = shift;
     C.slot_words = slot_words;
+    C.dirty_format = dirty_format;
     for (int j = 0; j < 3; ++j) C.unit[j] = eff[j];
     run->a_begin = a_begin;
     run->record = true;
@@ -883,20 +911,14 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         };
         plan.lds_slots_v2 = front(gangfit::fifo_v2_lds_bytes(0, ctx->n_chunks), 24, 64);
         if (plan.lds_slots_v2 > ctx->n_slots) plan.lds_slots_v2 = ctx->n_slots;
-        {  // whole 64-slot chunk blocks (784 bytes each: three dimensions + the two candidate masks)
-            const size_t fixed = gangfit::fifo_solo_lds_bytes(0, ctx->n_chunks);
-            const size_t per_chunk = gangfit::fifo_solo_lds_bytes(64, ctx->n_chunks) - fixed;
-            const size_t fit = ctx->lds_budget > fixed ? (ctx->lds_budget - fixed) / per_chunk : 0;
-            const size_t whole = (ctx->n_slots + 63u) / 64u;
-            plan.lds_slots_solo = (uint32_t)((fit < whole ? fit : whole) * 64u);
-        }
+        plan.lds_slots_solo = solo_lds_slots(ctx);
         gangfit::NarrowTable nt{};
         gangfit::ChainCkpt ck{nullptr, 0u, ctx->chain.shift};
         if (plan.narrow) {
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
             const int32_t* restore = nullptr;
             ck = chain_ckpt_args(ctx, run, &restore);
-            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
+            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore, ctx->chain.dirty_format); nrc != GF_OK) return nrc;
         }
         // a resumed chain is launched on the tail of the queue: exec_off is absolute, so offset pointers are all it takes
         const uint64_t heads_lo = a_begin > 0 ? h_apps[a_begin].exec_off : 0;

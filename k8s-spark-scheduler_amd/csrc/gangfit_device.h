@@ -136,7 +136,18 @@ struct ChainCkpt {
     int32_t* base;
     uint32_t a_base;
     uint32_t shift;
+    size_t stride;                          // int32 words between two checkpoints (>= 3 * n_slots; chain_ckpt_stride)
+    const unsigned long long* resume_mask;  // solo kernel with a global table tail: the dirty-chunk mask of the checkpoint
+                                            // this launch resumes from (nullptr: from the snapshot)
 };
+// Checkpoint layout: cpu | mem | gpu (n_slots int32 each), then — 8-byte aligned — one bit per 64-slot chunk ("dirty":
+// the chunk differs from the snapshot; written by the solo kernel when the table has a global tail, where only those
+// chunks are dumped).
+inline size_t chain_ckpt_stride(uint32_t n_slots, uint32_t n_chunks) {
+    return 3 * (size_t)n_slots + (n_slots & 1u) + 2 * (size_t)((n_chunks + 63u) / 64u);
+}
+// d_work (an already initialised narrow working table: the snapshot in the chain's units) gets the dirty chunks of a checkpoint
+hipError_t launch_ckpt_restore(int32_t* d_work, const int32_t* d_ckpt, uint32_t n_slots, uint32_t n_chunks, hipStream_t stream);
 size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 // heads_lo: first entry of d_scratch this launch may write run heads to (the placements of a resumed chain start there)

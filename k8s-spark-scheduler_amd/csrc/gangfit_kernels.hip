@@ -1616,7 +1616,7 @@ size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
     const size_t nw = (n_chunks + 63u) / 64u, nwp = nw < 4 ? 4 : nw;
     size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nwp +
-                 8 * (size_t)n_chunks;
+                 8 * (size_t)n_chunks + 8 * nw;
     off = (off + 15) & ~(size_t)15;
     off += sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 + 4 * kMaxShapes +
            4 * (size_t)n_chunks + 12 * (size_t)n_chunks;
@@ -1715,6 +1715,12 @@ hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& 
     return launch_fifo_algo<GF_ALGO_DISTRIBUTE_EVENLY>(plan, table, ntable, n_apps, d_apps, d_napps, d_wide_needed, d_results,
                                                        d_exec_nodes, d_scratch, scratch_half, heads_lo, d_chain_failed_at, ckpt,
                                                        d_stats, stream);
+}
+
+hipError_t launch_ckpt_restore(int32_t* d_work, const int32_t* d_ckpt, uint32_t n_slots, uint32_t n_chunks, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(ckpt_restore_kernel, dim3((n_chunks + 3u) / 4u), dim3(256), 0, stream, d_work, d_ckpt, n_slots, n_chunks);
+    return hipGetLastError();
 }
 
 hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, const NodeTable& table,

@@ -10,7 +10,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "extender.hpp"
@@ -43,7 +46,9 @@ int main(int argc, char** argv) {
         std::printf("no gfx950 device (there is no CPU fallback)\n");
         return 2;
     }
-    SparkSchedulerExtender ext(SelectBinpacker(packer, ctx), NodeSorter(), true, FifoConfig{});
+    const Binpacker chosen = SelectBinpacker(packer, ctx);
+    const gf_algo ext_algo = chosen.Algo;
+    SparkSchedulerExtender ext(chosen, NodeSorter(), true, FifoConfig{});
     const char* zones[] = {"az-a", "az-b", "az-c"};
     const int cpus[] = {16, 32, 64, 96}, mems[] = {64, 128, 256, 384};
     std::vector<std::string> nodeNames;
@@ -181,6 +186,56 @@ int main(int argc, char** argv) {
                 pct(flat_ms, 0.99), pct(cached_ms, 0.5), pct(cached_ms, 0.99), pct(unchanged_ms, 0.5), pct(unchanged_ms, 0.99),
                 pct(order_ms, 0.5), pct(order_ms, 0.99), pct(retry_ms, 0.5), pct(retry_ms, 0.99), flat.node.size(), build_ms, flat_rr_ms,
                 same ? "true" : "false");
+    // ---- eight Filters' chains at once: eight views of the context (gf_ctx_view) walk the pending queue from eight different
+    //      heads on the snapshot the last Filter installed, one thread each — against one of them alone
+    {
+        std::vector<gf_app> q;
+        for (const Pod& p : ext.pods) {
+            auto r = sparkResources(p, nullptr);
+            gf_app a{};
+            if (!r || !r->DriverResources.canonical(a.drv) || !r->ExecutorResources.canonical(a.exe)) continue;
+            a.k = r->MinExecutorCount;
+            a.flags = GF_APP_SKIPPABLE;
+            q.push_back(a);
+        }
+        uint64_t total_k = 0;
+        for (const gf_app& a : q) total_k += (uint64_t)a.k;
+        const int n_views = 8, reps = 10;
+        gf_set_option(ctx, "chain_cache", 0);  // full replays: the chains themselves are what is timed
+        std::vector<gf_ctx*> views(n_views, nullptr);
+        std::vector<std::vector<gf_app>> qs(n_views);
+        bool ok = true;
+        for (int i = 0; i < n_views; ++i) {
+            ok = ok && gf_ctx_view(ctx, &views[i]) == GF_OK;
+            qs[i].assign(q.begin() + i, q.end());
+            qs[i].insert(qs[i].end(), q.begin(), q.begin() + i);
+        }
+        const gf_algo algo = ext_algo;
+        auto chain = [&](int i) {
+            std::vector<gf_result> res(q.size());
+            std::vector<uint32_t> exec(total_k + 1);
+            int32_t failed = -1;
+            return gf_fit_batch(views[i], GF_MODE_FIFO_CHAIN, algo, (uint32_t)q.size(), qs[i].data(), res.data(), exec.data(), total_k, &failed);
+        };
+        for (int i = 0; i < n_views && ok; ++i) ok = chain(i) == GF_OK;
+        t0 = Clock::now();
+        for (int r = 0; r < reps && ok; ++r) ok = chain(0) == GF_OK;
+        const double one_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / reps;
+        std::atomic<int> bad{0};
+        std::vector<std::thread> th;
+        t0 = Clock::now();
+        for (int i = 0; i < n_views; ++i)
+            th.emplace_back([&, i] {
+                for (int r = 0; r < reps; ++r)
+                    if (chain(i) != GF_OK) ++bad;
+            });
+        for (std::thread& t : th) t.join();
+        const double eight_ms = std::chrono::duration<double, std::milli>(Clock::now() - t0).count() / reps;
+        std::printf("{\"concurrent_views\": {\"views\": %d, \"chain_apps\": %zu, \"one_chain_ms\": %.3f, \"eight_concurrent_chains_ms\": %.3f, "
+                    "\"ratio\": %.2f, \"ok\": %s}}\n", n_views, q.size(), one_ms, eight_ms, eight_ms / one_ms, ok && bad.load() == 0 ? "true" : "false");
+        for (gf_ctx* v : views)
+            if (v) gf_destroy(v);
+    }
     gf_destroy(ctx);
     return same ? 0 : 1;
 }
