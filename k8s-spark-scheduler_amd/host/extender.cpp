@@ -406,9 +406,22 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
             for (int j = 0; j < 3; ++j) over[j][it->second] = v[j];
         }
     }
-    std::vector<uint32_t> flags = cluster.base_flags;
-    for (const std::string& name : nodeNames)
-        if (auto it = cluster.index.find(name); it != cluster.index.end()) flags[it->second] |= GF_NODE_DRIVER_CANDIDATE;
+    // the request's NodeNames as candidate flags: the same list for every Filter of an instance group until the node set
+    // changes, so the 10 000 map lookups are done once per (cluster version, list)
+    uint64_t names_hash = 1469598103934665603ull;
+    for (const std::string& name : nodeNames) {
+        for (const char ch : name) names_hash = (names_hash ^ (unsigned char)ch) * 1099511628211ull;
+        names_hash = (names_hash ^ 0xFFu) * 1099511628211ull;
+    }
+    if (cluster.version == 0 || flags_cluster_ != cluster.version || flags_hash_ != names_hash || flags_names_ != nodeNames.size()) {
+        flags_cache_ = cluster.base_flags;
+        for (const std::string& name : nodeNames)
+            if (auto it = cluster.index.find(name); it != cluster.index.end()) flags_cache_[it->second] |= GF_NODE_DRIVER_CANDIDATE;
+        flags_cluster_ = cluster.version;
+        flags_hash_ = names_hash;
+        flags_names_ = nodeNames.size();
+    }
+    const std::vector<uint32_t>& flags = flags_cache_;
     // ---- the applications: earlier drivers in creation order, then this one
     std::string err;
     auto resources = sparkResources(driver, &err);
@@ -420,13 +433,26 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
     std::vector<gf_app> apps;
     if (isFIFO_)
         for (const Pod* p : filterToEarliestAndSort(driver, pods)) {
-            auto r = sparkResources(*p, nullptr);
-            if (!r) continue;
-            gf_app a{};
-            if (!r->DriverResources.canonical(a.drv) || !r->ExecutorResources.canonical(a.exe) || r->MinExecutorCount < 0 ||
-                r->MinExecutorCount > GF_MAX_K)
-                return not_served("earlier driver " + p->Name + " is not exactly representable");
-            a.k = r->MinExecutorCount;
+            // annotations -> canonical requests, once per (pod, resourceVersion); the skip flag depends on the clock
+            ParsedApp fresh;
+            ParsedApp* pa = &fresh;
+            bool cached = false;
+            if (p->ResourceVersion != 0) {
+                pa = &parsed_apps_[p->UID.empty() ? p->Namespace + "/" + p->Name : p->UID];
+                cached = pa->version == p->ResourceVersion;
+            }
+            if (!cached) {
+                pa->version = p->ResourceVersion;
+                pa->app = gf_app{};
+                auto r = sparkResources(*p, nullptr);
+                pa->ok = r.has_value();
+                pa->representable = pa->ok && r->DriverResources.canonical(pa->app.drv) && r->ExecutorResources.canonical(pa->app.exe) &&
+                                    r->MinExecutorCount >= 0 && r->MinExecutorCount <= GF_MAX_K;
+                if (pa->representable) pa->app.k = r->MinExecutorCount;
+            }
+            if (!pa->ok) continue;
+            if (!pa->representable) return not_served("earlier driver " + p->Name + " is not exactly representable");
+            gf_app a = pa->app;
             a.flags = shouldSkipDriverFifo(*p, instanceGroup) ? GF_APP_SKIPPABLE : 0u;
             apps.push_back(a);
         }

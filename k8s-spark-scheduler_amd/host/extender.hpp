@@ -142,6 +142,19 @@ private:
     // chain's checkpoints (include/gangfit.h, "Incremental FIFO chains")
     uint64_t built_epoch_ = 0, built_cluster_ = 0, built_usage_ = 0;
     std::vector<uint32_t> built_flags_;
+    // The reference parses the nine annotations of every earlier driver on every Filter (sparkpods.go:73-137 from
+    // resource.go:231) and matches the request's NodeNames against the node set again.  Both are pure functions of things
+    // that carry a version: the flat route keeps the canonical requests per (pod UID, resourceVersion) and the candidate
+    // flags per (cluster version, NodeNames).
+    struct ParsedApp {
+        uint64_t version = 0;
+        bool ok = false, representable = false;
+        gf_app app{};
+    };
+    std::unordered_map<std::string, ParsedApp> parsed_apps_;
+    uint64_t flags_cluster_ = 0, flags_hash_ = 0;
+    size_t flags_names_ = 0;
+    std::vector<uint32_t> flags_cache_;
     Binpacker binpacker_;
     NodeSorter sorter_;
     bool isFIFO_;

@@ -43,6 +43,8 @@ struct Pod {  // the fields of corev1.Pod this path reads
     bool Deleting = false;               // DeletionTimestamp != nil
     std::string InstanceGroup;           // value the pod's node affinity / selector requires for the instance-group label
                                          // (internal.MatchPodInstanceGroup compares exactly this, internal/podspec.go)
+    uint64_t ResourceVersion = 0;        // metadata.resourceVersion as a number; 0 = unknown.  Annotations are immutable per
+                                         // version: selectDriverNodeFlat keeps the parsed requests of a (UID, version) pair
 };
 
 struct SparkApplicationResources {

@@ -97,6 +97,8 @@ int main(int argc, char** argv) {
         pod.SchedulerName = common::SparkSchedulerName;
         pod.InstanceGroup = "batch-medium-priority";
         pod.CreationTimestampNanos = (int64_t)(p + 1) * 1000000000;
+        pod.UID = "uid-" + std::to_string(p);
+        pod.ResourceVersion = 1000 + (uint64_t)p;  // what an informer hands over: the flat route parses each version once
         ext.pods.push_back(std::move(pod));
     }
     ext.nowNanos = (int64_t)(n_pending + 10) * 1000000000;

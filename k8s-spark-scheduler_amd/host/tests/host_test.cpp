@@ -690,6 +690,8 @@ static void TestIncrementalFilters() {
             const char* ec = ecpu[next() % 3];
             Pod pod = Driver(("pending-" + std::to_string(p)).c_str(), StaticAnnotations(k, "2Gi", "1", em, ec), p + 1);
             pod.Annotations.erase("spark-driver-nvidia.com/gpu");
+            pod.UID = "uid-" + std::to_string(p);
+            pod.ResourceVersion = 100 + (uint64_t)p;  // the flat route parses each (UID, version) once
             pod.Annotations.erase("spark-executor-nvidia.com/gpu");
             ext.pods.push_back(pod);
         }
@@ -728,6 +730,17 @@ static void TestIncrementalFilters() {
         gf_chain_cache_stats(g_ctx, 0, st1);
         CHECK(st1[0] == 2u * (n_pending - 60));
         CHECK(st1[1] >= 2u * (n_pending - 60) - 4u);  // every Filter but the first of a round (and the one behind the intruder) resumes
+        // a pod whose annotations change arrives with a new resourceVersion: its cached requests are parsed again
+        ext.pods[70].Annotations["spark-executor-count"] = "57";
+        ext.pods[70].ResourceVersion += 1000;
+        const Pod& lastd = ext.pods[(size_t)n_pending - 1];
+        const SelectNodeResult w2 = ext.selectDriverNode("batch-medium-priority", lastd, names, ext.nodes);
+        const SelectNodeResult g2 = ext.selectDriverNodeFlat("batch-medium-priority", lastd, names, cluster, &flat);
+        bool same2 = g2.served && w2.served && g2.outcome == w2.outcome && g2.node == w2.node && g2.created.has_value() == w2.created.has_value();
+        if (same2 && g2.created)
+            for (const auto& [name, res] : w2.created->Reservations)
+                same2 = same2 && g2.created->Reservations.count(name) && g2.created->Reservations.at(name).Node == res.Node;
+        CHECK(same2);
     }
 }
 
