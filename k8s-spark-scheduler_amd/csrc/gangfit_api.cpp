@@ -209,7 +209,20 @@ struct gf_ctx {
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (prepare_apps_kernel)
-    DeviceBuf<int32_t> d_wide_needed;       // set by prepare_apps_kernel when a request has no narrow form
+    DeviceBuf<int32_t> d_wide_needed;       // two words used alternately: set by the chain prologue when a request has no narrow
+                                            // form; each prologue zeroes the word the NEXT chain will use (wide_flag)
+    uint32_t wide_seq = 0;                  // chains launched: parity picks the word
+    bool wide_dirty = false;                // a launch failed half way: both words are cleared before the next chain
+    struct HostIo {  // set by gf_fit_batch around launch(): where the first / last kernel of a chain may read and write directly
+        bool active = false;
+        uint32_t n_apps = 0;           // records of the whole queue in h_apps
+        const gf_app* apps = nullptr;  // device addresses of the pinned h_apps / h_results / h_exec / h_failed
+        gf_result* results = nullptr;
+        uint32_t* exec = nullptr;
+        int32_t* failed = nullptr;
+        bool apps_done = false;  // a kernel of this launch writes (or a copy wrote) the records to d_apps
+        bool out_done = false;   // the last kernel of this launch writes the answers to the host buffers
+    } hio;
     DeviceBuf<int32_t> d_capmat;            // minimal-fragmentation chain: capacity per (request shape, slot)
     bool fifo_minfrag_matrix = true;        // option "minfrag_matrix" = 0 recomputes capacities in every pass
     DeviceBuf<int32_t> d_mfhist;            // ... and the capacity histograms per (candidate view, request shape)
@@ -541,8 +554,9 @@ void narrow_units(const gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, int6
 
 // restore (nullable): a checkpoint of an earlier chain in the SAME units — the working copy starts from it instead of the
 // snapshot (incremental chains).
+// The copies themselves are left to the chain's first kernel (io).
 int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t stream, gangfit::NarrowTable* nt,
-                 const int32_t* restore = nullptr, bool restore_dirty_chunks = false) {
+                 gangfit::ChainIo* io, const int32_t* restore = nullptr, bool restore_dirty_chunks = false) {
     int64_t eff[3];
     int32_t factor[3];
     narrow_units(ctx, h_apps, n_apps, eff, factor, nullptr);
@@ -552,19 +566,29 @@ int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t
     for (int j = 0; j < 3; ++j) nt->unit[j] = eff[j];
     const size_t table_bytes = 3 * (size_t)ctx->n_slots * sizeof(int32_t);
     const bool whole = restore != nullptr && !restore_dirty_chunks;  // the checkpoint is the whole table
+    const int32_t* src = nullptr;  // what the working copy starts from, when a plain copy makes it
     if (factor[0] == 1 && factor[1] == 1 && factor[2] == 1) {
-        GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, whole ? restore : ctx->d_nsnap.ptr, table_bytes, hipMemcpyDeviceToDevice, stream));
+        src = whole ? restore : ctx->d_nsnap.ptr;
         nt->cmax = ctx->d_ncmax.ptr;
     } else {
         GF_HIP(ctx, ctx->d_ncmax_w.reserve(3 * (size_t)ctx->n_chunks));
         GF_HIP(ctx, gangfit::launch_narrow_rescale(ctx->d_nsnap.ptr, ctx->d_nwork.ptr, ctx->n_slots, ctx->d_ncmax.ptr,
                                                    ctx->d_ncmax_w.ptr, ctx->n_chunks, factor, stream));
-        if (whole) GF_HIP(ctx, hipMemcpyAsync(ctx->d_nwork.ptr, restore, table_bytes, hipMemcpyDeviceToDevice, stream));
+        if (whole) src = restore;
         nt->cmax = ctx->d_ncmax_w.ptr;
     }
+    if (src != nullptr) {
+        io->copy_src[0] = reinterpret_cast<const uint32_t*>(src);
+        io->copy_dst[0] = reinterpret_cast<uint32_t*>(ctx->d_nwork.ptr);
+        io->copy_words[0] = table_bytes / sizeof(uint32_t);
+    }
     // ... or only the chunks that differ from the snapshot (in the chain's units), laid over it
-    if (restore != nullptr && restore_dirty_chunks)
-        GF_HIP(ctx, gangfit::launch_ckpt_restore(ctx->d_nwork.ptr, restore, ctx->n_slots, ctx->n_chunks, stream));
+    if (restore != nullptr && restore_dirty_chunks) {
+        io->overlay = restore;
+        io->overlay_dst = ctx->d_nwork.ptr;
+        io->overlay_slots = ctx->n_slots;
+        io->overlay_chunks = ctx->n_chunks;
+    }
     return GF_OK;
 }
 
@@ -588,6 +612,41 @@ gangfit::ChainCkpt chain_ckpt_args(gf_ctx* ctx, const ChainRun* run, const int32
         }
     }
     return ck;
+}
+
+// The flag word of the chain being launched ("a request has no scaled form") and the ChainIo that goes with a launch on
+// the records [a0, n_apps): the records come from the pinned host buffer when gf_fit_batch offered it, the answers go to
+// the host buffers when the translate step is the last kernel to write them (answers_final).
+int32_t* wide_flag(gf_ctx* ctx) { return ctx->d_wide_needed.ptr + (ctx->wide_seq & 1u); }
+int chain_io_begin(gf_ctx* ctx, uint32_t a0, bool answers_final, hipStream_t stream, gangfit::ChainIo* io) {
+    if (ctx->wide_dirty) {
+        GF_HIP(ctx, hipMemsetAsync(ctx->d_wide_needed.ptr, 0, 2 * sizeof(int32_t), stream));
+        ctx->wide_dirty = false;
+    }
+    io->wide_clear = ctx->d_wide_needed.ptr + ((ctx->wide_seq & 1u) ^ 1u);
+    gf_ctx::HostIo& h = ctx->hio;
+    if (h.active && !h.apps_done) io->apps_src = h.apps + a0;
+    if (h.active && answers_final) {
+        io->h_results = h.results + a0;
+        io->h_exec = h.exec;
+        io->h_failed = h.failed;
+    }
+    ctx->wide_dirty = true;  // until chain_io_end: a launch that fails half way leaves the flag words in an unknown state
+    return GF_OK;
+}
+void chain_io_end(gf_ctx* ctx, const gangfit::ChainIo& io) {
+    ctx->wide_dirty = false;
+    ++ctx->wide_seq;
+    if (io.apps_src != nullptr) ctx->hio.apps_done = true;
+    if (io.h_results != nullptr) ctx->hio.out_done = true;
+}
+// Launch paths whose first kernel does not take the records from the host: an ordinary copy, once per gf_fit_batch.
+int apps_to_device(gf_ctx* ctx, hipStream_t stream) {
+    gf_ctx::HostIo& h = ctx->hio;
+    if (!h.active || h.apps_done) return GF_OK;
+    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)h.n_apps * sizeof(gf_app), hipMemcpyHostToDevice, stream));
+    h.apps_done = true;
+    return GF_OK;
 }
 
 // Table slots the solo chain kernel keeps in LDS (whole 64-slot chunk blocks of 784 bytes next to its fixed tables).
@@ -649,7 +708,9 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     gangfit::NarrowTable nt{};
     const int32_t* restore = nullptr;
     const gangfit::ChainCkpt ck = chain_ckpt_args(ctx, run, &restore);
-    if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
+    gangfit::ChainIo io;
+    if (const int irc = chain_io_begin(ctx, ck.a_base, run != nullptr && run->narrow_proven, stream, &io); irc != GF_OK) return irc;
+    if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, &io, restore); nrc != GF_OK) return nrc;
     // capacity matrix: one int32 per (request shape, slot); skipped (capacities recomputed per pass) beyond 1 GiB
     int32_t* capmat = nullptr;
     if ((uint64_t)n_shapes * ctx->n_slots * sizeof(int32_t) <= (UINT64_C(1) << 30) && ctx->fifo_minfrag_matrix) {
@@ -664,9 +725,10 @@ int try_minfrag_lds(gf_ctx* ctx, bool zoned, const gangfit::ZoneTable& zt, uint3
     const uint32_t a0 = ck.a_base;
     GF_HIP(ctx, gangfit::launch_fit_fifo_minfrag_lds(zoned, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr, lds_slots,
                                                      n_shapes, n_idx, n_apps - a0, d_apps + a0, ctx->d_napps.ptr + a0,
-                                                     ctx->d_wide_needed.ptr, d_results + a0, d_exec_nodes, ctx->d_zexec.ptr, half,
-                                                     d_failed, capmat, hist, ck, ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
-    *run_if = ctx->d_wide_needed.ptr;
+                                                     wide_flag(ctx), d_results + a0, d_exec_nodes, ctx->d_zexec.ptr, half,
+                                                     d_failed, capmat, hist, ck, io, ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
+    *run_if = wide_flag(ctx);
+    chain_io_end(ctx, io);
     *served = true;
     return GF_OK;
 }
@@ -695,9 +757,11 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         const bool proven = run != nullptr && run->narrow_proven;  // the LDS chain serves for certain: no generic twin
         // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303);
         // the LDS chains rewrite every real slot of the wide working table in their epilogue
-        if (!proven)
+        if (!proven) {
+            if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;  // the generic kernel reads d_apps
             GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                        hipMemcpyDeviceToDevice, stream));
+        }
         ctx->work_valid = true;
         const bool az_aware = algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK;
         const int32_t* run_if = nullptr;
@@ -710,14 +774,17 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
             gangfit::NarrowTable nt{};
             const int32_t* restore = nullptr;
             const gangfit::ChainCkpt ck = chain_ckpt_args(ctx, run, &restore);
-            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore); nrc != GF_OK) return nrc;
+            gangfit::ChainIo io;
+            if (const int irc = chain_io_begin(ctx, ck.a_base, proven, stream, &io); irc != GF_OK) return irc;
+            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, &io, restore); nrc != GF_OK) return nrc;
             const uint32_t a0 = ck.a_base;
             GF_HIP(ctx, gangfit::launch_fit_fifo_zoned_lds(az_aware, make_table(ctx, ctx->d_work.ptr), nt, zt, ctx->d_sched.ptr,
                                                            lds_slots, n_shapes, n_apps - a0, d_apps + a0, ctx->d_napps.ptr + a0,
-                                                           ctx->d_wide_needed.ptr, d_results + a0, d_exec_nodes,
-                                                           ctx->d_zexec.ptr, half, d_failed, ck,
+                                                           wide_flag(ctx), d_results + a0, d_exec_nodes,
+                                                           ctx->d_zexec.ptr, half, d_failed, ck, io,
                                                            ctx->stats_on ? ctx->d_stats.ptr : nullptr, stream));
-            run_if = ctx->d_wide_needed.ptr;  // the generic kernel below only runs when a request had no scaled form
+            run_if = wide_flag(ctx);  // the generic kernel below only runs when a request had no scaled form
+            chain_io_end(ctx, io);
             zb.zexec = ctx->d_zexec.ptr;
             served = true;
         }
@@ -735,6 +802,7 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
                                                      ctx->d_scratch.ptr, half, d_failed, run_if, stream));
         return GF_OK;
     }
+    if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;
     GF_HIP(ctx, gangfit::launch_fit_zoned(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK,
                                           reserves_executors(algo), make_table(ctx, ctx->d_snap.ptr), zt,
                                           slot_eff_tables(ctx, ctx->d_snap.ptr), zb, n_apps, d_apps, d_results,
@@ -867,9 +935,11 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         // the working table in global memory
         const bool proven = run != nullptr && run->narrow_proven;
         GF_HIP(ctx, ctx->d_zexec.reserve(half));
-        if (!proven)
+        if (!proven) {
+            if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;  // the generic kernel reads d_apps
             GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
                                        hipMemcpyDeviceToDevice, stream));
+        }
         ctx->work_valid = true;
         gangfit::ZoneTable zt{nullptr, nullptr, 0, 0};
         const int32_t* run_if = nullptr;
@@ -888,6 +958,7 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     }
     ScanStats* stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
     if (mode == GF_MODE_INDEPENDENT) {
+        if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;
         GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps,
                                                     d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
     } else if (mode == GF_MODE_FIFO_CHAIN) {
@@ -897,10 +968,14 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
         const uint32_t a_begin = (plan.narrow && run != nullptr) ? run->a_begin : 0u;
         // every chain starts from the snapshot: availableNodesSchedulingMetadata is rebuilt per request (resource.go:303).
         // The solo kernel rewrites every real slot of the wide working table in its epilogue: the copy is only needed by the
-        // wide kernel.
-        if (plan.wide)
-            GF_HIP(ctx, hipMemcpyAsync(ctx->d_work.ptr, ctx->d_snap.ptr, 3 * (size_t)ctx->n_slots * sizeof(int64_t),
-                                       hipMemcpyDeviceToDevice, stream));
+        // wide kernel.  Like the narrow table's, the copy is made by the chain's first kernel (ChainIo).
+        gangfit::ChainIo io;
+        if (const int irc = chain_io_begin(ctx, a_begin, true, stream, &io); irc != GF_OK) return irc;
+        if (plan.wide) {
+            io.copy_src[1] = reinterpret_cast<const uint32_t*>(ctx->d_snap.ptr);
+            io.copy_dst[1] = reinterpret_cast<uint32_t*>(ctx->d_work.ptr);
+            io.copy_words[1] = 3 * (size_t)ctx->n_slots * (sizeof(int64_t) / sizeof(uint32_t));
+        }
         ctx->work_valid = true;
         // as much of the table front as fits next to each kernel's fixed LDS needs stays in LDS for the whole chain
         auto front = [&](size_t fixed, size_t per_slot, uint32_t round) {
@@ -918,13 +993,15 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
             GF_HIP(ctx, ctx->d_napps.reserve(n_apps));
             const int32_t* restore = nullptr;
             ck = chain_ckpt_args(ctx, run, &restore);
-            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, restore, ctx->chain.dirty_format); nrc != GF_OK) return nrc;
+            if (const int nrc = narrow_begin(ctx, h_apps, n_apps, stream, &nt, &io, restore, ctx->chain.dirty_format); nrc != GF_OK)
+                return nrc;
         }
         // a resumed chain is launched on the tail of the queue: exec_off is absolute, so offset pointers are all it takes
         const uint64_t heads_lo = a_begin > 0 ? h_apps[a_begin].exec_off : 0;
         GF_HIP(ctx, gangfit::launch_fit_fifo(algo, plan, make_table(ctx, ctx->d_work.ptr), nt, n_apps - a_begin, d_apps + a_begin,
-                                             ctx->d_napps.ptr + a_begin, ctx->d_wide_needed.ptr, d_results + a_begin,
-                                             d_exec_nodes, ctx->d_scratch.ptr, half, heads_lo, d_failed, ck, stats, stream));
+                                             ctx->d_napps.ptr + a_begin, wide_flag(ctx), d_results + a_begin,
+                                             d_exec_nodes, ctx->d_scratch.ptr, half, heads_lo, d_failed, ck, io, stats, stream));
+        chain_io_end(ctx, io);
     } else {
         return fail(ctx, GF_ERR_UNSUPPORTED, "unknown gf_mode %d", (int)mode);
     }
@@ -1088,8 +1165,9 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess ||
         ctx->d_stats.reserve(1) != hipSuccess || ctx->d_failed.reserve(1) != hipSuccess ||
-        ctx->d_wide_needed.reserve(1) != hipSuccess ||
+        ctx->d_wide_needed.reserve(2) != hipSuccess ||
         ctx->h_failed.reserve(1) != hipSuccess ||
+        hipMemset(ctx->d_wide_needed.ptr, 0, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(ctx->d_stats.ptr, 0, sizeof(ScanStats)) != hipSuccess) {
         gf_destroy(ctx);
         return GF_ERR_HIP;
@@ -1925,22 +2003,40 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     const bool use_cache = chain_plan(ctx, mode, algo, n_apps, ctx->h_apps.ptr, &run);
     const uint32_t a0 = run.a_begin;
     const uint64_t k0 = a0 > 0 ? ctx->h_apps.ptr[a0].exec_off : 0;  // placements of the skipped prefix
-    GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr + a0, ctx->h_apps.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_app),
-                               hipMemcpyHostToDevice, st));
+    // The answers travel to the pinned host buffers by posted writes of a kernel when the buffers are device-mapped: three
+    // copy-engine transfers behind the last kernel are three hand-overs between the compute queue and a copy engine — a
+    // visible part of a resumed chain, and what keeps chains on different streams from overlapping.  A FIFO chain goes
+    // further: its first kernel reads the records from the pinned buffer and its last one writes the answers there
+    // (gf_ctx::HostIo), which makes a Filter three launches and no copy.
+    void *da = nullptr, *dr = nullptr, *de = nullptr, *df = nullptr;
+    const bool mapped = ctx->zero_copy && hipHostGetDevicePointer(&dr, ctx->h_results.ptr, 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&de, ctx->h_exec.ptr, 0) == hipSuccess &&
+                        hipHostGetDevicePointer(&df, ctx->h_failed.ptr, 0) == hipSuccess;
+    gf_ctx::HostIo& hio = ctx->hio;
+    hio = gf_ctx::HostIo{};
+    if (mapped && mode == GF_MODE_FIFO_CHAIN && hipHostGetDevicePointer(&da, ctx->h_apps.ptr, 0) == hipSuccess) {
+        hio.active = true;
+        hio.n_apps = n_apps;
+        hio.apps = static_cast<const gf_app*>(da);
+        hio.results = static_cast<gf_result*>(dr);
+        hio.exec = static_cast<uint32_t*>(de);
+        hio.failed = static_cast<int32_t*>(df);
+    } else {
+        (void)hipGetLastError();
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr + a0, ctx->h_apps.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_app),
+                                   hipMemcpyHostToDevice, st));
+    }
     const int rc = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, ctx->d_apps.ptr, ctx->d_results.ptr, ctx->d_exec.ptr,
                           total_k, ctx->d_failed.ptr, st, use_cache ? &run : nullptr);
+    const bool answers_sent = hio.active && hio.out_done;
+    hio.active = false;
     if (rc != GF_OK) {
         ctx->chain.valid = false;
         return rc;
     }
-    // The answers travel to the pinned host buffers by ONE kernel (posted writes) when the buffers are device-mapped: three
-    // copy-engine transfers behind the last kernel are three hand-overs between the compute queue and a copy engine — a
-    // visible part of a resumed chain, and what keeps chains on different streams from overlapping.
-    void *dr = nullptr, *de = nullptr, *df = nullptr;
-    const bool mapped = ctx->zero_copy && hipHostGetDevicePointer(&dr, ctx->h_results.ptr, 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&de, ctx->h_exec.ptr, 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&df, ctx->h_failed.ptr, 0) == hipSuccess;
-    if (mapped) {
+    if (answers_sent) {
+        // the chain's last kernel wrote results, placements and the abort index to the host buffers
+    } else if (mapped) {
         gangfit::CopyOut co{};
         co.src[0] = reinterpret_cast<const uint32_t*>(ctx->d_results.ptr + a0);
         co.dst[0] = reinterpret_cast<uint32_t*>(static_cast<gf_result*>(dr) + a0);

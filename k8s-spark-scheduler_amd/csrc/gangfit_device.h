@@ -146,16 +146,35 @@ struct ChainCkpt {
 inline size_t chain_ckpt_stride(uint32_t n_slots, uint32_t n_chunks) {
     return 3 * (size_t)n_slots + (n_slots & 1u) + 2 * (size_t)((n_chunks + 63u) / 64u);
 }
-// d_work (an already initialised narrow working table: the snapshot in the chain's units) gets the dirty chunks of a checkpoint
-hipError_t launch_ckpt_restore(int32_t* d_work, const int32_t* d_ckpt, uint32_t n_slots, uint32_t n_chunks, hipStream_t stream);
+// What a chain launcher folds into its first and its last kernel, so that a Filter's chain is three launches instead of
+// nine runtime calls (each costs ~7 us of host time alone, several times that when eight threads enqueue eight chains):
+//   first kernel (chain_prologue_kernel) — reads the app records from wherever the caller has them (device-mapped pinned
+//       host memory, or the device), writes the device copy and the scaled records, presets the run-head slice, copies up
+//       to two tables (working table <- snapshot / checkpoint) and lays the dirty chunks of a checkpoint over the first;
+//   last kernel (the translate / expand step) — also writes the final results, placements and the abort index to
+//       device-mapped host buffers (posted writes, visible when the kernel has completed).
+// Everything is optional; a default-constructed ChainIo means "records are in d_apps, nothing to copy, no host outputs".
+struct ChainIo {
+    const gf_app* apps_src = nullptr;  // device-visible source of the n_apps records (nullptr: d_apps holds them already)
+    const uint32_t* copy_src[2] = {nullptr, nullptr};
+    uint32_t* copy_dst[2] = {nullptr, nullptr};
+    size_t copy_words[2] = {0, 0};
+    const int32_t* overlay = nullptr;  // a checkpoint in the dirty-chunk format, laid over overlay_dst after the copies
+    int32_t* overlay_dst = nullptr;
+    uint32_t overlay_slots = 0, overlay_chunks = 0;
+    int32_t* wide_clear = nullptr;     // the flag word the NEXT chain will use (zeroed here: the words alternate)
+    gf_result* h_results = nullptr;    // [n_apps] of this launch
+    uint32_t* h_exec = nullptr;        // indexed by the records' absolute exec_off
+    int32_t* h_failed = nullptr;
+};
 size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks);
 // heads_lo: first entry of d_scratch this launch may write run heads to (the placements of a resumed chain start there)
 hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
                            uint32_t n_apps, const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed,
                            gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
-                           uint64_t heads_lo, int32_t* d_chain_failed_at, const ChainCkpt& ckpt, ScanStats* d_stats,
-                           hipStream_t stream);
+                           uint64_t heads_lo, int32_t* d_chain_failed_at, const ChainCkpt& ckpt, const ChainIo& io,
+                           ScanStats* d_stats, hipStream_t stream);
 
 // Zone-aware packers on an independent batch: one wave per (app, zone) runs SparkBinPack on the zone's view, one wave
 // per decision averages the packing efficiencies of [driver] ++ executors in slice order (chooseBestResult,
@@ -194,7 +213,8 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
                                      const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                      const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                      uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                     int32_t* d_chain_failed_at, const ChainCkpt& ckpt, ScanStats* d_stats, hipStream_t stream);
+                                     int32_t* d_chain_failed_at, const ChainCkpt& ckpt, const ChainIo& io, ScanStats* d_stats,
+                                     hipStream_t stream);
 
 // LDS-resident, block-cooperative chain for minimal-fragmentation, plain (zoned = false) or single-AZ
 // (gangfit_fifo_minfrag.inc); same contract as launch_fit_fifo_zoned_lds.
@@ -209,7 +229,8 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
                                        int32_t* d_chain_failed_at, int32_t* d_capmat /* n_shapes x n_slots, nullable */,
                                        int32_t* d_hist /* fifo_minfrag_hist_words, nullable: no histogram path */,
-                                       const ChainCkpt& ckpt, ScanStats* d_stats /* nullable */, hipStream_t stream);
+                                       const ChainCkpt& ckpt, const ChainIo& io, ScanStats* d_stats /* nullable */,
+                                       hipStream_t stream);
 
 // ComputeAvgPackingEfficiency over [driver] ++ executors of n_apps finished results whose placements are NODE indices
 // (efficiency.go:114-156); d_avg_out: n_apps x 4 doubles {CPU, Memory, GPU, Max}.

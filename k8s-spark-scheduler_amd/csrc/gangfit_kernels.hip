@@ -19,7 +19,10 @@
 // loads) and fit_fifo_chain_kernel (one workgroup walks the chain, table front resident in LDS).
 // No MFMA (nothing here is a contraction) — see DESIGN.md for the roofline discussion.
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "gangfit_device.h"
 
@@ -1625,14 +1628,63 @@ size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
 }
 
 namespace {
+// hipFuncAttributeMaxDynamicSharedMemorySize is per kernel and per device and only ever needs raising: the runtime call is
+// made when a launch asks for more than any launch before it (one call less per chain otherwise).
+hipError_t raise_dynamic_lds(const void* kernel, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> raised;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = raised[{kernel, dev}];
+    if (lds <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have = lds;
+    return e;
+}
+
 template <class Kernel, class... Args>
 hipError_t launch_one_workgroup(Kernel kernel, int n_waves, size_t lds, hipStream_t stream, Args... args) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(1), dim3(kWave * n_waves), lds, stream, args...);
     return hipGetLastError();
 }
+
+// The first kernel of a chain (ChainIo): records, scaled records, table copies, checkpoint overlay, run-head preset.
+hipError_t launch_chain_prologue(const ChainIo& io, uint32_t n_apps, const gf_app* d_apps, NApp* d_napps, const int64_t* unit,
+                                 int32_t* d_wide_needed, uint32_t* fill_dst, size_t fill_words, hipStream_t stream) {
+    ChainPrologue p{};
+    p.n_apps = (io.apps_src != nullptr || d_napps != nullptr) ? n_apps : 0u;
+    p.apps_src = io.apps_src;
+    p.apps_dst = const_cast<gf_app*>(d_apps);
+    p.napps = d_napps;
+    for (int j = 0; j < 3; ++j) p.unit[j] = unit ? unit[j] : 1;
+    p.wide_needed = d_wide_needed;
+    p.wide_clear = io.wide_clear;
+    size_t most = p.n_apps;
+    for (int r = 0; r < 2; ++r) {
+        p.copy_src[r] = io.copy_src[r];
+        p.copy_dst[r] = io.copy_dst[r];
+        p.copy_words[r] = io.copy_words[r];
+        most = std::max(most, io.copy_words[r] / 4);
+    }
+    p.overlay = io.overlay;
+    p.overlay_dst = io.overlay_dst;
+    p.overlay_slots = io.overlay_slots;
+    p.overlay_chunks = io.overlay_chunks;
+    if (io.overlay != nullptr) most = std::max(most, 3 * (size_t)io.overlay_slots / 4);
+    p.fill_dst = fill_dst;
+    p.fill_words = fill_words;
+    most = std::max(most, fill_words);
+    if (most == 0 && io.wide_clear == nullptr) return hipSuccess;
+    size_t blocks = (most + 255) / 256;
+    blocks = std::min<size_t>(std::max<size_t>(blocks, 1), 1024);
+    hipLaunchKernelGGL(chain_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+inline ChainOut chain_out_of(const ChainIo& io, const int32_t* d_failed) { return ChainOut{io.h_results, io.h_exec, d_failed, io.h_failed}; }
 
 template <int ALGO>
 hipError_t launch_v2(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, const gf_app* d_apps, gf_result* d_results,
@@ -1670,21 +1722,16 @@ template <int ALGO>
 hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps,
                             const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                             uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t half, uint64_t heads_lo, int32_t* d_failed,
-                            const ChainCkpt& ck, ScanStats* d_stats, hipStream_t stream) {
+                            const ChainCkpt& ck, const ChainIo& io, ScanStats* d_stats, hipStream_t stream) {
     hipError_t e = hipSuccess;
     const int32_t* guard = nullptr;
+    // run heads of the tightly-pack fast path: "no head here"
+    const bool heads = P.narrow && ALGO == GF_ALGO_TIGHTLY_PACK && half > 1 + heads_lo;
+    e = launch_chain_prologue(io, n_apps, d_apps, P.narrow ? d_napps : nullptr, NT.unit, d_wide_needed,
+                              heads ? d_scratch + heads_lo : nullptr, heads ? (size_t)(half - 1 - heads_lo) : 0, stream);
+    if (e != hipSuccess) return e;
     if (P.narrow) {
-        e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
-        if (e != hipSuccess) return e;
-        // run heads of the tightly-pack fast path: "no head here"
-        if (ALGO == GF_ALGO_TIGHTLY_PACK && half > 1 + heads_lo) {
-            e = hipMemsetAsync(d_scratch + heads_lo, 0xFF, (half - 1 - heads_lo) * sizeof(uint32_t), stream);
-            if (e != hipSuccess) return e;
-        }
         guard = d_wide_needed;
-        hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps, d_napps,
-                           NT.unit[0], NT.unit[1], NT.unit[2], d_wide_needed);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
         e = launch_solo<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, ck,
                               d_stats, stream);
         if (e != hipSuccess) return e;
@@ -1696,7 +1743,7 @@ hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowT
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(expand_translate_kernel, grid, block, 0, stream, T.slot_node, n_apps, d_apps, d_results,
-                       d_exec_nodes, d_scratch);
+                       d_exec_nodes, d_scratch, chain_out_of(io, d_failed));
     return hipGetLastError();
 }
 }  // namespace
@@ -1704,23 +1751,17 @@ hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowT
 hipError_t launch_fit_fifo(gf_algo algo, const FifoPlan& plan, const NodeTable& table, const NarrowTable& ntable,
                            uint32_t n_apps, const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed,
                            gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch, uint64_t scratch_half,
-                           uint64_t heads_lo, int32_t* d_chain_failed_at, const ChainCkpt& ckpt, ScanStats* d_stats,
-                           hipStream_t stream) {
+                           uint64_t heads_lo, int32_t* d_chain_failed_at, const ChainCkpt& ckpt, const ChainIo& io,
+                           ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     if (!plan.narrow && !plan.wide) return hipErrorInvalidValue;
     if (algo == GF_ALGO_TIGHTLY_PACK)
         return launch_fifo_algo<GF_ALGO_TIGHTLY_PACK>(plan, table, ntable, n_apps, d_apps, d_napps, d_wide_needed, d_results,
                                                       d_exec_nodes, d_scratch, scratch_half, heads_lo, d_chain_failed_at, ckpt,
-                                                      d_stats, stream);
+                                                      io, d_stats, stream);
     return launch_fifo_algo<GF_ALGO_DISTRIBUTE_EVENLY>(plan, table, ntable, n_apps, d_apps, d_napps, d_wide_needed, d_results,
                                                        d_exec_nodes, d_scratch, scratch_half, heads_lo, d_chain_failed_at, ckpt,
-                                                       d_stats, stream);
-}
-
-hipError_t launch_ckpt_restore(int32_t* d_work, const int32_t* d_ckpt, uint32_t n_slots, uint32_t n_chunks, hipStream_t stream) {
-    if (n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(ckpt_restore_kernel, dim3((n_chunks + 3u) / 4u), dim3(256), 0, stream, d_work, d_ckpt, n_slots, n_chunks);
-    return hipGetLastError();
+                                                       io, d_stats, stream);
 }
 
 hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, const NodeTable& table,
@@ -1825,15 +1866,13 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
                                      const int64_t* d_sched, uint32_t lds_slots, uint32_t n_shapes, uint32_t n_apps,
                                      const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                      uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
-                                     int32_t* d_chain_failed_at, const ChainCkpt& ck, ScanStats* d_stats, hipStream_t stream) {
+                                     int32_t* d_chain_failed_at, const ChainCkpt& ck, const ChainIo& io, ScanStats* d_stats,
+                                     hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     if (zones.n_zones + (az_aware ? 1u : 0u) > 16 || !table.d_identity) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
-                       d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_shapes == 0 || n_shapes > kZShapes) return hipErrorInvalidValue;
+    hipError_t e = launch_chain_prologue(io, n_apps, d_apps, d_napps, ntable.unit, d_wide_needed, nullptr, 0, stream);
+    if (e != hipSuccess) return e;
     // one wavefront per candidate view; the rest of the workgroup only helps with the prologue and shares every barrier and
     // the per-app control flow, i.e. takes issue slots from the views' wavefronts: no more wavefronts than views need
     const uint32_t n_cand = zones.n_zones + (az_aware ? 1u : 0u);
@@ -1856,7 +1895,7 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
 #undef GF_ZL
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
-                       n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);
+                       n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed, chain_out_of(io, d_chain_failed_at));
     return hipGetLastError();
 }
 
@@ -1874,17 +1913,14 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                        const gf_app* d_apps, NApp* d_napps, int32_t* d_wide_needed, gf_result* d_results,
                                        uint32_t* d_exec_nodes, uint32_t* d_spill, uint64_t spill_stride,
                                        int32_t* d_chain_failed_at, int32_t* d_capmat, int32_t* d_hist, const ChainCkpt& ck,
-                                       ScanStats* d_stats, hipStream_t stream) {
+                                       const ChainIo& io, ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     if ((zoned && zones.n_zones > 16) || !table.d_identity || n_shapes == 0 || n_shapes > kZShapes || n_idx > n_shapes)
         return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(d_wide_needed, 0, sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
     if (d_capmat == nullptr) d_hist = nullptr;  // the histograms are patched together with the matrix
     // (no initialisation of d_hist: the row fill of a shape writes every bin of its histograms and first positions)
-    hipLaunchKernelGGL(prepare_apps_kernel, dim3((n_apps + 255) / 256), dim3(256), 0, stream, n_apps, d_apps,
-                       d_napps, ntable.unit[0], ntable.unit[1], ntable.unit[2], d_wide_needed);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipError_t e = launch_chain_prologue(io, n_apps, d_apps, d_napps, ntable.unit, d_wide_needed, nullptr, 0, stream);
+    if (e != hipSuccess) return e;
     const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_idx);
     if (zoned)
         e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
@@ -1896,7 +1932,7 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
                                  d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
-                       n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed);
+                       n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed, chain_out_of(io, d_chain_failed_at));
     return hipGetLastError();
 }
 

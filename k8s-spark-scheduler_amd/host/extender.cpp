@@ -1,5 +1,6 @@
 #include "extender.hpp"
 
+#include <cstring>
 #include <algorithm>
 #include <atomic>
 
@@ -408,10 +409,25 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
     }
     // the request's NodeNames as candidate flags: the same list for every Filter of an instance group until the node set
     // changes, so the 10 000 map lookups are done once per (cluster version, list)
+    // (eight bytes per multiply: a byte-at-a-time hash of 100 000 names is a 1.5 ms dependent chain)
     uint64_t names_hash = 1469598103934665603ull;
     for (const std::string& name : nodeNames) {
-        for (const char ch : name) names_hash = (names_hash ^ (unsigned char)ch) * 1099511628211ull;
-        names_hash = (names_hash ^ 0xFFu) * 1099511628211ull;
+        const char* p = name.data();
+        size_t left = name.size();
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)left;
+        for (; left >= 8; left -= 8, p += 8) {
+            uint64_t w;
+            std::memcpy(&w, p, 8);
+            h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+            h ^= h >> 29;
+        }
+        if (left) {
+            uint64_t w = 0;
+            std::memcpy(&w, p, left);
+            h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+            h ^= h >> 31;
+        }
+        names_hash = (names_hash ^ h) * 1099511628211ull;  // order-sensitive across names; h of each name is independent work
     }
     if (cluster.version == 0 || flags_cluster_ != cluster.version || flags_hash_ != names_hash || flags_names_ != nodeNames.size()) {
         flags_cache_ = cluster.base_flags;
