@@ -433,6 +433,47 @@ int gf_hbm_probe(gf_ctx *ctx, uint64_t bytes, uint32_t iters, double *read_gb_pe
  * to compute — the floor a latency-bound batch kernel is measured against. */
 int gf_launch_floor(gf_ctx *ctx, void *stream, uint32_t iters, float *us_per_launch);
 
+/* ---- The resident worker of the independent batch.
+ * A batch of GF_MODE_INDEPENDENT is ~n_apps wavefronts that each walk a short chain of dependent misses: as a kernel launch it
+ * pays the dispatch (~2.5 us) and cold caches, and two launches on one stream never overlap.  The worker is ONE launch that
+ * stays on the device while batches keep coming: the host posts TICKETS into a ring in pinned memory and rings a doorbell word,
+ * groups of wavefronts take the tickets in turn (several batches in flight), the wavefront that completes a ticket writes its
+ * completion word to pinned memory.  No launch, no copy engine, no stream operation per batch.
+ *   - it leaves the device by itself when no ticket has arrived for "worker_idle_us" (gf_set_option; default 200) and is
+ *     launched again by the next submit; gf_worker_stop makes it leave at once (a host that wants to hipDeviceSynchronize);
+ *   - it reads the installed snapshot: every install (gf_snapshot_* / gf_orders_set / gf_cluster_set ...) first serves what
+ *     was posted and makes it leave;
+ *   - plain packers only (tightly-pack, distribute-evenly, minimal-fragmentation); plain contexts only (no views, one
+ *     device); results are bit-identical to gf_fit_batch(GF_MODE_INDEPENDENT) — same wave-level code.
+ *   options: "worker_sets" (groups of wavefronts = batches in flight on the device, default 3), "worker_blocks_per_set"
+ *   (workgroups of eight wavefronts per group, default 128), "worker_idle_us".
+ *
+ * gf_worker_fit: one blocking batch with host arrays, like gf_fit_batch(GF_MODE_INDEPENDENT): the records are written into
+ * a pinned slice the device reads in place, results and placements are written by the device into pinned memory (zero copy
+ * both ways).
+ *
+ * gf_worker_submit_dev / gf_worker_wait: device-resident batches, asynchronously.  Tickets are numbered from 0 in posting
+ * order; *first_ticket receives the number of batches[0].  A record array handed to the worker is read around the device's
+ * L1 but through its L2: an array whose CONTENT is replaced while the worker is resident must be replaced by a stream
+ * operation that completed before the submit (a finished copy or kernel), as for any kernel launch.  GF_WORKER_HOST_OUTPUTS:
+ * d_results / d_exec_nodes are device addresses of PINNED HOST memory (no cache write-back before the completion word). */
+typedef struct gf_worker_batch {
+    uint32_t n_apps;          /* > 0 */
+    uint32_t flags;           /* GF_WORKER_* */
+    const gf_app *d_apps;     /* exec_off filled by the caller, as for gf_fit_batch_dev */
+    gf_result *d_results;
+    uint32_t *d_exec_nodes;
+    uint64_t exec_nodes_len;  /* sum of k over the batch */
+} gf_worker_batch;
+#define GF_WORKER_HOST_OUTPUTS 1u
+int gf_worker_fit(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, gf_result *results, uint32_t *exec_nodes,
+                  uint64_t exec_nodes_cap);
+int gf_worker_submit_dev(gf_ctx *ctx, gf_algo algo, uint32_t n_batches, const gf_worker_batch *batches, uint64_t *first_ticket);
+int gf_worker_wait(gf_ctx *ctx, uint64_t first_ticket, uint32_t n_tickets);
+int gf_worker_stop(gf_ctx *ctx);
+/* out[0] tickets posted, [1] tickets known complete (a prefix), [2] launches of the worker so far, [3] 1 = resident now */
+int gf_worker_stats(gf_ctx *ctx, uint64_t out[4]);
+
 /* Device properties the host uses to size launches (also lets a caller verify it is talking to a gfx950). */
 typedef struct gf_device_info {
     char name[128];

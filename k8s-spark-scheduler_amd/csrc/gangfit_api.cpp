@@ -172,6 +172,29 @@ struct gf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // The resident worker of the independent batch (gf_worker_*; gangfit_worker.inc).
+    struct Worker {
+        bool allocated = false;
+        bool running = false;       // a launch is (or may still be) on the device
+        int algo = -1;
+        uint64_t epoch = 0;         // snapshot the launch's table arguments belong to
+        hipStream_t stream = nullptr;
+        gangfit::WorkerHostCtl* h = nullptr;  // pinned, coherent, device-mapped
+        gangfit::WorkerHostCtl* h_dev = nullptr;
+        gangfit::WorkerDevCtl* d = nullptr;   // device memory
+        DeviceBuf<uint32_t> scratch;
+        uint64_t scratch_stride = 0;
+        uint64_t posted = 0;          // tickets posted so far (the host's copy of the doorbell)
+        uint64_t completed_upto = 0;  // every ticket below this one is known complete
+        uint32_t sets = 3;
+        uint32_t blocks_per_set = 128;  // x 8 wavefronts
+        uint32_t idle_us = 200;
+        uint64_t launches = 0;
+        // staging of gf_worker_fit: one pinned (coherent, device-mapped) slice per ring slot
+        void* stage = nullptr;
+        void* stage_dev = nullptr;
+        size_t stage_apps = 0, stage_k = 0;  // capacity per slot
+    } worker;
     hipStream_t timer_stream = nullptr;
     std::string err;
     gf_device_info info{};
@@ -370,10 +393,14 @@ int fail(gf_ctx* ctx, int code, const char* fmt, ...) {
 
 // An install on a context that has views: exclusive against the views' calls in flight (taken once per outermost install;
 // ctx->mu is held, so the depth counter needs no further protection).
+void worker_quiesce(gf_ctx* ctx);
 struct InstallGuard {
     gf_ctx* c;
     explicit InstallGuard(gf_ctx* ctx) : c(ctx) {
-        if (c->install_depth++ == 0) c->views_mu.lock();
+        if (c->install_depth++ == 0) {
+            worker_quiesce(c);  // the resident worker reads the installed tables: it leaves before they change
+            c->views_mu.lock();
+        }
     }
     ~InstallGuard() {
         if (--c->install_depth == 0) c->views_mu.unlock();
@@ -1298,6 +1325,14 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->h_failed.release();
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->worker.allocated) {
+        worker_quiesce(ctx);
+        ctx->worker.scratch.release();
+        if (ctx->worker.stage) (void)hipHostFree(ctx->worker.stage);
+        if (ctx->worker.d) (void)hipFree(ctx->worker.d);
+        if (ctx->worker.h) (void)hipHostFree(ctx->worker.h);
+        if (ctx->worker.stream) (void)hipStreamDestroy(ctx->worker.stream);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1382,6 +1417,18 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->force_general_layout = value != 0;
     } else if (k == "chain_cache") {
         ctx->chain_cache_on = value != 0;
+    } else if (k == "worker_sets" || k == "worker_blocks_per_set" || k == "worker_idle_us") {
+        worker_quiesce(ctx);
+        if (k == "worker_sets") {
+            if (value < 1 || value > 16) return fail(ctx, GF_ERR_INVALID, "worker_sets outside [1, 16]");
+            ctx->worker.sets = (uint32_t)value;
+        } else if (k == "worker_blocks_per_set") {
+            if (value < 1 || value > 1024) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set outside [1, 1024]");
+            ctx->worker.blocks_per_set = (uint32_t)value;
+        } else {
+            if (value < 10 || value > 1000000) return fail(ctx, GF_ERR_INVALID, "worker_idle_us outside [10, 10^6]");
+            ctx->worker.idle_us = (uint32_t)value;
+        }
     } else if (k == "rccl_selftest") {
         // the run-time binding of the collective library, exercised with a one-rank communicator on this device: an
         // all-gather and a reduction of `value` words must reproduce their input
@@ -2087,6 +2134,347 @@ int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, c
     if (mode == GF_MODE_FIFO_CHAIN && !d_chain_failed_at) d_chain_failed_at = ctx->d_failed.ptr;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     return launch(ctx, mode, algo, n_apps, nullptr, d_apps, d_results, d_exec_nodes, exec_nodes_len, d_chain_failed_at, st);
+}
+
+// ------------------------------------------------------------------------------------------------ resident worker
+namespace {
+constexpr uint32_t kRing = gangfit::kWorkerRing;
+
+inline uint64_t host_load(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void host_store(unsigned long long* p, uint64_t v) { __atomic_store_n(p, (unsigned long long)v, __ATOMIC_RELEASE); }
+
+int worker_alloc(gf_ctx* ctx) {
+    gf_ctx::Worker& w = ctx->worker;
+    if (w.allocated) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    void* hp = nullptr;
+    GF_HIP(ctx, hipHostMalloc(&hp, sizeof(gangfit::WorkerHostCtl), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(hp, 0, sizeof(gangfit::WorkerHostCtl));
+    void* hd = nullptr;
+    if (hipHostGetDevicePointer(&hd, hp, 0) != hipSuccess) {
+        (void)hipHostFree(hp);
+        return fail(ctx, GF_ERR_HIP, "the worker's control block cannot be mapped to the device");
+    }
+    void* dp = nullptr;
+    // (ordinary device memory: the relaxed agent-scope loads of the pollers are served by their XCD's L2 — 32 workgroups
+    //  probing one line cost one miss per update and XCD; in fine-grained memory every probe of every workgroup went to the
+    //  one memory channel that holds the line)
+    if (hipMalloc(&dp, sizeof(gangfit::WorkerDevCtl)) != hipSuccess ||
+        hipMemset(dp, 0, sizeof(gangfit::WorkerDevCtl)) != hipSuccess) {
+        if (dp) (void)hipFree(dp);
+        (void)hipHostFree(hp);
+        return fail(ctx, GF_ERR_HIP, "the worker's device control block cannot be allocated");
+    }
+    // its own stream, kept off a few compute units: the worker's wavefronts sit on every CU they may use for as long as
+    // batches keep coming, and a FIFO chain needs a whole CU (sixteen wavefronts, the LDS) to start
+    hipStream_t st = nullptr;
+    {
+        const uint32_t cus = (uint32_t)ctx->info.compute_units;
+        std::vector<uint32_t> mask((cus + 31) / 32, 0xFFFFFFFFu);
+        const uint32_t keep_free = cus >= 64 ? 16u : 0u;
+        for (uint32_t i = cus - keep_free; i < (uint32_t)mask.size() * 32; ++i) mask[i / 32] &= ~(1u << (i % 32));
+        if (keep_free == 0 || hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipFree(dp);
+                (void)hipHostFree(hp);
+                return fail(ctx, GF_ERR_HIP, "the worker's stream cannot be created");
+            }
+        }
+    }
+    w.h = static_cast<gangfit::WorkerHostCtl*>(hp);
+    w.h_dev = static_cast<gangfit::WorkerHostCtl*>(hd);
+    w.d = static_cast<gangfit::WorkerDevCtl*>(dp);
+    w.stream = st;
+    w.allocated = true;
+    return GF_OK;
+}
+
+void worker_advance(gf_ctx::Worker& w);
+
+// Makes the launch on the device (if any) leave once it has relayed and served every ticket posted so far, and waits for that.
+int worker_join(gf_ctx* ctx) {
+    gf_ctx::Worker& w = ctx->worker;
+    if (!w.running) return GF_OK;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    host_store(&w.h->stop, w.posted + 2);  // "leave after ticket posted - 1" (gangfit_worker.inc)
+    const hipError_t e = hipStreamSynchronize(w.stream);
+    host_store(&w.h->stop, 0);
+    w.running = false;
+    if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "the worker did not leave the device: %s", hipGetErrorString(e));
+    worker_advance(w);
+    if (w.completed_upto != w.posted)
+        return fail(ctx, GF_ERR_HIP, "the worker left with tickets %llu .. %llu unserved", (unsigned long long)w.completed_upto,
+                    (unsigned long long)w.posted);
+    return GF_OK;
+}
+
+// (Re)launches the worker for tickets >= first_ticket on the installed snapshot.
+int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
+    gf_ctx::Worker& w = ctx->worker;
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, hipMemsetAsync(&w.d->quit, 0, sizeof(unsigned long long), w.stream));
+    host_store(&w.h->state, 0);
+    host_store(&w.h->stop, 0);
+    gangfit::WorkerArgs a{};
+    a.host = w.h_dev;
+    a.dev = w.d;
+    a.first_ticket = first_ticket;
+    a.idle_ticks = (unsigned long long)w.idle_us * 100ull;  // wall_clock64 ticks at 100 MHz
+    a.scratch = w.scratch.ptr;
+    a.scratch_stride = w.scratch_stride;
+    // every workgroup must be resident at once (a group that waits for a CU would leave its tickets unserved while the others
+    // spin): at most what the device admits, with a margin
+    uint32_t sets = w.sets;
+    {
+        const uint32_t cus = (uint32_t)ctx->info.compute_units;
+        const uint32_t usable = cus >= 64 ? cus - 16u : cus;  // the worker's stream keeps sixteen CUs free (worker_alloc)
+        int per_cu = 0;
+        GF_HIP(ctx, gangfit::worker_blocks_per_cu(algo, &per_cu));
+        if (per_cu > 3) per_cu = 3;  // (106 SGPRs: the hardware admits six 256-thread workgroups' worth of wavefronts)
+        if (per_cu < 1) return fail(ctx, GF_ERR_HIP, "the worker kernel does not fit a CU");
+        const uint32_t room = usable * (uint32_t)per_cu;
+        while (sets > 1 && 1u + sets * w.blocks_per_set > room) --sets;
+        if (1u + sets * w.blocks_per_set > room) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set does not fit the device");
+    }
+    a.sets = sets;
+    a.blocks_per_set = w.blocks_per_set;
+    GF_HIP(ctx, gangfit::launch_fit_worker(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), a, w.stream));
+    w.running = true;
+    w.algo = (int)algo;
+    w.epoch = ctx->snap_epoch;
+    ++w.launches;
+    return GF_OK;
+}
+
+void worker_advance(gf_ctx::Worker& w) {
+    while (w.completed_upto < w.posted && host_load(&w.h->done[w.completed_upto % kRing]) == w.completed_upto + 1) ++w.completed_upto;
+}
+
+// The leader leaves when no ticket has arrived for a while — possibly just as one was posted.  When it has left: the old
+// launch is joined (its wavefronts work off everything it relayed first) and, if tickets were posted that it did not relay,
+// the worker is launched again from the first of them.
+int worker_revive(gf_ctx* ctx) {
+    gf_ctx::Worker& w = ctx->worker;
+    if (w.running) {
+        if (host_load(&w.h->state) != 2) return GF_OK;
+        GF_HIP(ctx, hipSetDevice(ctx->device));
+        GF_HIP(ctx, hipStreamSynchronize(w.stream));
+        w.running = false;
+    }
+    // not on the device: whatever was posted behind the last ticket the leader relayed needs a launch
+    const uint64_t consumed = host_load(&w.h->consumed);
+    if (w.algo >= 0 && consumed < w.posted) {
+        if (w.epoch != ctx->snap_epoch) return fail(ctx, GF_ERR_STATE, "the snapshot changed under a posted ticket");
+        return worker_launch(ctx, (gf_algo)w.algo, consumed);
+    }
+    return GF_OK;
+}
+
+// Waits for ticket t (t < posted).
+int worker_wait_ticket(gf_ctx* ctx, uint64_t t) {
+    gf_ctx::Worker& w = ctx->worker;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    for (;;) {
+        if (t < w.completed_upto || host_load(&w.h->done[t % kRing]) == t + 1) return GF_OK;
+        if ((++spins & 0x3Fu) == 0) {
+            if (const int rc = worker_revive(ctx); rc != GF_OK) return rc;
+            if (!w.running && host_load(&w.h->done[t % kRing]) != t + 1)
+                return fail(ctx, GF_ERR_STATE, "ticket %llu was never served (posted %llu, doorbell %llu, relayed %llu, complete below %llu, "
+                            "completion word %llu, launches %llu)", (unsigned long long)t, (unsigned long long)w.posted,
+                            (unsigned long long)host_load(&w.h->posted), (unsigned long long)host_load(&w.h->consumed),
+                            (unsigned long long)w.completed_upto, (unsigned long long)host_load(&w.h->done[t % kRing]),
+                            (unsigned long long)w.launches);
+            if ((spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                host_store(&w.h->stop, 1);
+                return fail(ctx, GF_ERR_HIP, "the worker did not complete ticket %llu within 5 s", (unsigned long long)t);
+            }
+        }
+    }
+}
+
+int worker_drain(gf_ctx* ctx) {
+    gf_ctx::Worker& w = ctx->worker;
+    worker_advance(w);
+    for (uint64_t t = w.completed_upto; t < w.posted; ++t)
+        if (const int rc = worker_wait_ticket(ctx, t); rc != GF_OK) return rc;
+    worker_advance(w);
+    return GF_OK;
+}
+
+int worker_prepare(gf_ctx* ctx, gf_algo algo, uint64_t max_total_k) {
+    gf_ctx::Worker& w = ctx->worker;
+    if (!ctx->group.empty() || ctx->view_of != nullptr)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "the resident worker serves plain contexts (no views, one device)");
+    if (algo != GF_ALGO_TIGHTLY_PACK && algo != GF_ALGO_DISTRIBUTE_EVENLY && algo != GF_ALGO_MINIMAL_FRAGMENTATION)
+        return fail(ctx, GF_ERR_UNSUPPORTED, "the resident worker serves the plain packers");
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
+    if (const int rc = worker_alloc(ctx); rc != GF_OK) return rc;
+    if (const int rc = worker_revive(ctx); rc != GF_OK) return rc;
+    const bool grow = max_total_k + 1 > w.scratch_stride;
+    if (w.running && (w.algo != (int)algo || w.epoch != ctx->snap_epoch || grow)) {
+        // another packer, another snapshot or a larger scratch: everything posted is served first, then the worker leaves
+        if (const int rc = worker_join(ctx); rc != GF_OK) return rc;
+    }
+    if (grow) {
+        if (const int rc = worker_drain(ctx); rc != GF_OK) return rc;
+        uint64_t stride = w.scratch_stride ? w.scratch_stride : 1024;
+        while (stride < max_total_k + 1) stride *= 2;
+        GF_HIP(ctx, hipSetDevice(ctx->device));
+        GF_HIP(ctx, w.scratch.reserve((size_t)kRing * 3 * stride));
+        w.scratch_stride = stride;
+    }
+    // not running: every ticket posted so far was relayed and served (worker_revive re-drives the ones that were not)
+    if (!w.running) return worker_launch(ctx, algo, w.posted);
+    return GF_OK;
+}
+
+// Posts one ticket (the caller has made room in the ring).
+void worker_post(gf_ctx::Worker& w, uint32_t n_apps, const gf_app* apps, gf_result* results, uint32_t* exec_nodes, uint64_t exec_len,
+                 bool host_out) {
+    gangfit::WorkerTicket& tk = w.h->ring[w.posted % kRing];
+    const unsigned long long tag = gangfit::worker_tag(w.posted) << 48;
+    tk.word[1] = (unsigned long long)reinterpret_cast<uintptr_t>(apps) | tag;
+    tk.word[2] = (unsigned long long)reinterpret_cast<uintptr_t>(results) | tag;
+    tk.word[3] = (unsigned long long)reinterpret_cast<uintptr_t>(exec_nodes) | tag;
+    tk.word[4] = (unsigned long long)exec_len | tag;
+    tk.word[5] = (unsigned long long)n_apps | ((unsigned long long)(host_out ? 1u : 0u) << 32) | tag;
+    tk.word[0] = w.posted + 1;
+    ++w.posted;
+}
+void worker_quiesce(gf_ctx* ctx) {
+    gf_ctx::Worker& w = ctx->worker;
+    if (!w.allocated) return;
+    if (worker_revive(ctx) != GF_OK) return;  // (it may have left for lack of work just as tickets were posted)
+    if (w.running)
+        (void)worker_join(ctx);
+    else
+        (void)worker_drain(ctx);
+}
+}  // namespace
+
+int gf_worker_submit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_batches, const gf_worker_batch* batches, uint64_t* first_ticket) {
+    if (!ctx || (n_batches > 0 && !batches)) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    uint64_t max_k = 0;
+    for (uint32_t i = 0; i < n_batches; ++i) {
+        if (batches[i].n_apps == 0 || !batches[i].d_apps || !batches[i].d_results)
+            return fail(ctx, GF_ERR_INVALID, "batch %u: empty, or apps / results NULL", i);
+        if (batches[i].exec_nodes_len > max_k) max_k = batches[i].exec_nodes_len;
+    }
+    if (const int rc = worker_prepare(ctx, algo, max_k); rc != GF_OK) return rc;
+    gf_ctx::Worker& w = ctx->worker;
+    if (first_ticket) *first_ticket = w.posted;
+    for (uint32_t i = 0; i < n_batches; ++i) {
+        if (w.posted - w.completed_upto >= kRing) {  // the slot of ticket `posted` is free once ticket posted - ring is done
+            host_store(&w.h->posted, w.posted);      // (ring the doorbell for what has been written so far)
+            if (const int rc = worker_wait_ticket(ctx, w.posted - kRing); rc != GF_OK) return rc;
+            worker_advance(w);
+        }
+        const gf_worker_batch& b = batches[i];
+        worker_post(w, b.n_apps, b.d_apps, b.d_results, b.d_exec_nodes, b.exec_nodes_len, (b.flags & GF_WORKER_HOST_OUTPUTS) != 0);
+    }
+    host_store(&w.h->posted, w.posted);  // the doorbell: one word for the whole group
+    return GF_OK;
+}
+
+int gf_worker_wait(gf_ctx* ctx, uint64_t first_ticket, uint32_t n_tickets) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    gf_ctx::Worker& w = ctx->worker;
+    if (!w.allocated || first_ticket + n_tickets > w.posted) return fail(ctx, GF_ERR_INVALID, "tickets that were never posted");
+    for (uint64_t t = first_ticket; t < first_ticket + n_tickets; ++t)
+        if (const int rc = worker_wait_ticket(ctx, t); rc != GF_OK) return rc;
+    worker_advance(w);
+    return GF_OK;
+}
+
+int gf_worker_fit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results, uint32_t* exec_nodes,
+                  uint64_t exec_nodes_cap) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (n_apps > 0 && (!apps || !results)) return fail(ctx, GF_ERR_INVALID, "apps/results must not be NULL");
+    if (n_apps == 0) return GF_OK;
+    uint64_t total_k = 0;
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        const gf_app& in = apps[a];
+        if (in.k < 0 || in.k > GF_MAX_K) return fail(ctx, GF_ERR_INVALID, "apps[%u].k = %d outside [0, %d]", a, in.k, GF_MAX_K);
+        for (int j = 0; j < 3; ++j)
+            if (in.drv[j] < 0 || in.drv[j] >= GF_MAX_ABS_QUANTITY || in.exe[j] < 0 || in.exe[j] >= GF_MAX_ABS_QUANTITY)
+                return fail(ctx, GF_ERR_INVALID, "apps[%u] request outside [0, 2^62)", a);
+        total_k += (uint64_t)in.k;
+    }
+    if (total_k > exec_nodes_cap || (total_k > 0 && !exec_nodes))
+        return fail(ctx, GF_ERR_CAPACITY, "exec_nodes holds %llu entries, %llu needed", (unsigned long long)exec_nodes_cap,
+                    (unsigned long long)total_k);
+    if (const int rc = worker_prepare(ctx, algo, total_k); rc != GF_OK) return rc;
+    gf_ctx::Worker& w = ctx->worker;
+    // one pinned slice per ring slot: records in, results and placements out — the device reads and writes them in place
+    if (n_apps > w.stage_apps || total_k + 1 > w.stage_k) {
+        if (const int rc = worker_drain(ctx); rc != GF_OK) return rc;
+        size_t na = w.stage_apps ? w.stage_apps : 1024, nk = w.stage_k ? w.stage_k : 16384;
+        while (na < n_apps) na *= 2;
+        while (nk < total_k + 1) nk *= 2;
+        const size_t slice = na * (sizeof(gf_app) + sizeof(gf_result)) + nk * sizeof(uint32_t);
+        void *hp = nullptr, *hd = nullptr;
+        GF_HIP(ctx, hipSetDevice(ctx->device));
+        GF_HIP(ctx, hipHostMalloc(&hp, slice * kRing, hipHostMallocMapped | hipHostMallocCoherent));
+        if (hipHostGetDevicePointer(&hd, hp, 0) != hipSuccess) {
+            (void)hipHostFree(hp);
+            return fail(ctx, GF_ERR_HIP, "the worker's staging cannot be mapped to the device");
+        }
+        if (w.stage) (void)hipHostFree(w.stage);
+        w.stage = hp;
+        w.stage_dev = hd;
+        w.stage_apps = na;
+        w.stage_k = nk;
+    }
+    if (w.posted - w.completed_upto >= kRing) {
+        if (const int rc = worker_wait_ticket(ctx, w.posted - kRing); rc != GF_OK) return rc;
+        worker_advance(w);
+    }
+    const size_t slice = w.stage_apps * (sizeof(gf_app) + sizeof(gf_result)) + w.stage_k * sizeof(uint32_t);
+    const size_t off = (size_t)(w.posted % kRing) * slice;
+    char* hb = static_cast<char*>(w.stage) + off;
+    char* db = static_cast<char*>(w.stage_dev) + off;
+    gf_app* h_apps = reinterpret_cast<gf_app*>(hb);
+    gf_result* h_res = reinterpret_cast<gf_result*>(hb + w.stage_apps * sizeof(gf_app));
+    uint32_t* h_exec = reinterpret_cast<uint32_t*>(hb + w.stage_apps * (sizeof(gf_app) + sizeof(gf_result)));
+    uint64_t k_off = 0;
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        h_apps[a] = apps[a];
+        h_apps[a].exec_off = k_off;
+        k_off += (uint64_t)apps[a].k;
+    }
+    const uint64_t ticket = w.posted;
+    worker_post(w, n_apps, reinterpret_cast<const gf_app*>(db), reinterpret_cast<gf_result*>(db + w.stage_apps * sizeof(gf_app)),
+                reinterpret_cast<uint32_t*>(db + w.stage_apps * (sizeof(gf_app) + sizeof(gf_result))), total_k, true);
+    host_store(&w.h->posted, w.posted);
+    if (const int rc = worker_wait_ticket(ctx, ticket); rc != GF_OK) return rc;
+    worker_advance(w);
+    std::memcpy(results, h_res, (size_t)n_apps * sizeof(gf_result));
+    if (total_k) std::memcpy(exec_nodes, h_exec, (size_t)total_k * sizeof(uint32_t));
+    return GF_OK;
+}
+
+int gf_worker_stop(gf_ctx* ctx) {
+    if (!ctx) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    worker_quiesce(ctx);
+    return GF_OK;
+}
+
+int gf_worker_stats(gf_ctx* ctx, uint64_t out[4]) {
+    if (!ctx || !out) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const gf_ctx::Worker& w = ctx->worker;
+    out[0] = w.posted;
+    out[1] = w.completed_upto;
+    out[2] = w.launches;
+    out[3] = (w.allocated && w.running && host_load(&w.h->state) != 2) ? 1 : 0;
+    return GF_OK;
 }
 
 int gf_graph_begin(gf_ctx* ctx, void* stream) {

@@ -117,6 +117,54 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
 
+// ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gf_worker_* in gangfit_api.cpp)
+constexpr uint32_t kWorkerRing = 64;
+constexpr int kWorkerWaves = 8;              // wavefronts per workgroup of the worker kernel
+constexpr uint32_t kWorkerCountStride = 64;  // words between two tickets' counters: one 256-byte line (one memory channel) each  // tickets in flight at most (host side waits for ticket t - kWorkerRing before it posts t)
+
+// A ticket: six self-validating 8-byte words.  word[0] = ticket number + 1; words 1..5 carry worker_tag(ticket) in their
+// top sixteen bits (device and pinned-host addresses, the placement count and n_apps | flags << 32 all stay below 2^48): a
+// reader that finds the right tag in every word has the whole ticket without any ordering between the words.
+struct WorkerTicket {  // 64 bytes
+    unsigned long long word[8];  // [0] seq, [1] apps, [2] results, [3] exec_nodes, [4] exec_len, [5] n_apps | flags << 32
+};
+static_assert(sizeof(WorkerTicket) == 64, "one cache line per ticket");
+__host__ __device__ inline unsigned long long worker_tag(unsigned long long ticket) { return ((ticket + 1ull) & 0x7FFFull) | 0x8000ull; }
+
+struct WorkerHostCtl {  // pinned host memory, device-mapped
+    unsigned long long posted;  // host -> device: tickets posted so far (the doorbell)
+    unsigned long long stop;    // host -> device: 1 = leave now; N + 2 = leave once ticket N - 1 has been relayed (N tickets in all)
+    unsigned long long pad0[6];
+    unsigned long long consumed;  // device -> host: tickets the leader has relayed (valid once state == 2)
+    unsigned long long state;     // device -> host: 1 = the leader runs, 2 = it has left
+    unsigned long long pad1[6];
+    unsigned long long done[kWorkerRing];  // device -> host: done[t % ring] = t + 1 when ticket t is complete
+    WorkerTicket ring[kWorkerRing];        // host -> device
+};
+
+struct WorkerDevCtl {  // fine-grained device memory
+    unsigned long long quit;
+    unsigned long long pad0[7];
+    uint32_t count[kWorkerRing * kWorkerCountStride];  // [slot * stride]: applications of the slot's ticket finished so far
+    WorkerTicket ring[kWorkerRing];
+};
+
+struct WorkerArgs {
+    WorkerHostCtl* host;
+    WorkerDevCtl* dev;
+    unsigned long long first_ticket;  // tickets below this one were served by an earlier launch
+    unsigned long long idle_ticks;    // the leader leaves after this long without a new ticket (100 MHz)
+    uint32_t* scratch;                // [kWorkerRing][3 * scratch_stride]: private placements, two survivor lists
+    unsigned long long scratch_stride;
+    uint32_t sets;
+    uint32_t blocks_per_set;
+};
+
+hipError_t worker_blocks_per_cu(gf_algo algo, int* out);
+// One launch: 1 + sets * blocks_per_set workgroups of four wavefronts.
+hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const WorkerArgs& args,
+                             hipStream_t stream);
+
 // FIFO chain (fitEarlierDrivers + final pack) of the plain packers.  One workgroup walks the chain; two kernels:
 //   solo (gangfit_fifo_solo.inc) — merged layout, scaled int32 table in LDS, ONE wavefront walking the chain: the fast
 //                                  path; when a request of the batch has no scaled form it returns at once

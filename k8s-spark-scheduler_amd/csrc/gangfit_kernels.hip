@@ -1520,6 +1520,7 @@ __global__ __launch_bounds__(kWave* NW) void fit_fifo_chain_kernel(NodeTable T, 
     }
 }
 
+#include "gangfit_worker.inc"
 #include "gangfit_fifo_common.inc"
 #include "gangfit_fifo_solo.inc"
 #include "gangfit_zones.inc"
@@ -1593,6 +1594,34 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
+
+// Workgroups of the worker kernel one CU holds at a time (what the runtime reports; the caller keeps a margin).
+hipError_t worker_blocks_per_cu(gf_algo algo, int* out) {
+    const int threads = kWave * kWorkerWaves;
+    if (algo == GF_ALGO_TIGHTLY_PACK)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fit_worker_kernel<GF_ALGO_TIGHTLY_PACK>, threads, 0);
+    if (algo == GF_ALGO_DISTRIBUTE_EVENLY)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fit_worker_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, threads, 0);
+    if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fit_worker_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, threads, 0);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const WorkerArgs& args,
+                             hipStream_t stream) {
+    if (args.sets == 0 || args.blocks_per_set == 0 || args.host == nullptr || args.dev == nullptr) return hipErrorInvalidValue;
+    const dim3 block(kWave * kWorkerWaves);
+    const dim3 grid(1u + args.sets * args.blocks_per_set);
+    if (algo == GF_ALGO_TIGHTLY_PACK)
+        hipLaunchKernelGGL(fit_worker_kernel<GF_ALGO_TIGHTLY_PACK>, grid, block, 0, stream, table, gpu_view, args);
+    else if (algo == GF_ALGO_DISTRIBUTE_EVENLY)
+        hipLaunchKernelGGL(fit_worker_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, grid, block, 0, stream, table, gpu_view, args);
+    else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+        hipLaunchKernelGGL(fit_worker_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, grid, block, 0, stream, table, gpu_view, args);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,

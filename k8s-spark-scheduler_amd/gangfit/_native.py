@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
     "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
     "gf_usage_reset", "gf_usage_apply", "gf_set_option", "gf_chain_cache_stats", "gf_generation", "gf_shard_count", "gf_ctx_view",
+    "gf_worker_fit", "gf_worker_submit_dev", "gf_worker_wait", "gf_worker_stop", "gf_worker_stats",
 ]
 
 
@@ -54,6 +55,15 @@ class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int32),
                 ("lds_bytes_per_cu", C.c_int32), ("wavefront_size", C.c_int32), ("clock_khz", C.c_int32),
                 ("hbm_bytes", C.c_int64)]
+
+
+class WorkerBatch(C.Structure):
+    """gf_worker_batch (include/gangfit.h)."""
+    _fields_ = [("n_apps", C.c_uint32), ("flags", C.c_uint32), ("d_apps", C.c_void_p), ("d_results", C.c_void_p),
+                ("d_exec_nodes", C.c_void_p), ("exec_nodes_len", C.c_uint64)]
+
+
+GF_WORKER_HOST_OUTPUTS = 1
 
 
 class GangfitError(RuntimeError):
@@ -170,6 +180,16 @@ def load() -> C.CDLL:
     L.gf_set_option.argtypes = [p, C.c_char_p, C.c_int64]
     L.gf_ctx_view.restype = i32
     L.gf_ctx_view.argtypes = [p, C.POINTER(p)]
+    L.gf_worker_fit.restype = i32
+    L.gf_worker_fit.argtypes = [p, i32, u32, p, p, p, u64]
+    L.gf_worker_submit_dev.restype = i32
+    L.gf_worker_submit_dev.argtypes = [p, i32, u32, p, p]
+    L.gf_worker_wait.restype = i32
+    L.gf_worker_wait.argtypes = [p, u64, u32]
+    L.gf_worker_stop.restype = i32
+    L.gf_worker_stop.argtypes = [p]
+    L.gf_worker_stats.restype = i32
+    L.gf_worker_stats.argtypes = [p, p]
     L.gf_shard_count.restype = i32
     L.gf_shard_count.argtypes = [p]
     L.gf_generation.restype = i32

@@ -335,6 +335,50 @@ class Context:
                                                C.c_void_p(d_failed_at) if d_failed_at else None,
                                                C.c_void_p(stream) if stream else None))
 
+    # -- the resident worker of the independent batch (gf_worker_*)
+    def worker_fit(self, algo: int, apps: np.ndarray) -> BatchOut:
+        """One blocking independent batch through the resident worker (records and answers in pinned memory, no launch)."""
+        apps = np.ascontiguousarray(apps, dtype=N.APP_DTYPE)
+        apps_off, total_k = with_offsets(apps)
+        res = np.zeros(len(apps), dtype=N.RESULT_DTYPE)
+        out = np.zeros(total_k + 1, dtype=np.uint32)
+        self._check(self._lib.gf_worker_fit(self._h, algo, len(apps), N.ptr(apps), N.ptr(res), N.ptr(out), total_k))
+        return BatchOut(res, apps_off["exec_off"].copy(), out[:total_k], -1)
+
+    def worker_submit_dev(self, algo: int, batches) -> int:
+        """batches: iterable of (n_apps, d_apps, d_results, d_exec_nodes, exec_nodes_len[, flags]); returns the first ticket."""
+        arr = (N.WorkerBatch * len(batches))()
+        for i, b in enumerate(batches):
+            arr[i].n_apps, arr[i].d_apps, arr[i].d_results, arr[i].d_exec_nodes, arr[i].exec_nodes_len = b[0], b[1], b[2], b[3], b[4]
+            arr[i].flags = b[5] if len(b) > 5 else 0
+        first = C.c_uint64(0)
+        self._check(self._lib.gf_worker_submit_dev(self._h, algo, len(batches), arr, C.byref(first)))
+        return int(first.value)
+
+    def worker_batches(self, batches):
+        """A prepared ctypes array for worker_submit_prepared (keeps the marshalling out of a timed region)."""
+        arr = (N.WorkerBatch * len(batches))()
+        for i, b in enumerate(batches):
+            arr[i].n_apps, arr[i].d_apps, arr[i].d_results, arr[i].d_exec_nodes, arr[i].exec_nodes_len = b[0], b[1], b[2], b[3], b[4]
+            arr[i].flags = b[5] if len(b) > 5 else 0
+        return arr
+
+    def worker_submit_prepared(self, algo: int, arr) -> int:
+        first = C.c_uint64(0)
+        self._check(self._lib.gf_worker_submit_dev(self._h, algo, len(arr), arr, C.byref(first)))
+        return int(first.value)
+
+    def worker_wait(self, first_ticket: int, n_tickets: int = 1):
+        self._check(self._lib.gf_worker_wait(self._h, first_ticket, n_tickets))
+
+    def worker_stop(self):
+        self._check(self._lib.gf_worker_stop(self._h))
+
+    def worker_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.gf_worker_stats(self._h, out))
+        return {"posted": int(out[0]), "complete": int(out[1]), "launches": int(out[2]), "resident": bool(out[3])}
+
     # -- replayable launch sequences (gf_graph_*)
     def graph_begin(self, stream: int = 0):
         self._check(self._lib.gf_graph_begin(self._h, C.c_void_p(stream) if stream else None))

@@ -1,0 +1,142 @@
+"""The resident worker of the independent batch (gf_worker_*): same answers as the launch path, tickets in flight, leaving and
+coming back, installs under a resident worker."""
+import time
+
+import numpy as np
+import pytest
+
+import gangfit
+from gangfit import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+TIGHT, EVEN, MINFRAG = gangfit.GF_ALGO_TIGHTLY_PACK, gangfit.GF_ALGO_DISTRIBUTE_EVENLY, gangfit.GF_ALGO_MINIMAL_FRAGMENTATION
+IND = gangfit.GF_MODE_INDEPENDENT
+
+
+def _install(ctx, w):
+    s = w.snapshot
+    ctx.set_snapshot(s.avail, s.sched)
+    ctx.set_orders(s.driver_order, s.exec_order)
+
+
+def _same(a, b):
+    return np.array_equal(a.results, b.results) and np.array_equal(a.exec_nodes, b.exec_nodes)
+
+
+@pytest.mark.parametrize("algo", [TIGHT, EVEN, MINFRAG])
+def test_worker_fit_answers_what_a_launch_answers(algo):
+    ctx = gangfit.Context(0)
+    try:
+        w = wl.headline(3000, 700, seed=0xB0B + algo)
+        _install(ctx, w)
+        apps = gangfit.make_apps(w.drv, w.exe, w.k)
+        want = ctx.fit_batch(IND, algo, apps)
+        for _ in range(3):
+            assert _same(ctx.worker_fit(algo, apps), want)
+        # other batches on the same resident worker, small and ragged ones included
+        rng = np.random.default_rng(algo)
+        for n in (1, 3, 64, 257, 700):
+            pick = rng.permutation(len(apps))[:n]
+            sub = apps[pick]
+            assert _same(ctx.worker_fit(algo, sub), ctx.fit_batch(IND, algo, sub))
+        st = ctx.worker_stats()
+        assert st["posted"] == st["complete"] == 8
+    finally:
+        ctx.close()
+
+
+def test_worker_leaves_when_idle_and_comes_back():
+    ctx = gangfit.Context(0, options={"worker_idle_us": 50})
+    try:
+        w = wl.headline(2000, 300, seed=77)
+        _install(ctx, w)
+        apps = gangfit.make_apps(w.drv, w.exe, w.k)
+        want = ctx.fit_batch(IND, TIGHT, apps)
+        assert _same(ctx.worker_fit(TIGHT, apps), want)
+        time.sleep(0.05)  # a thousand idle periods
+        assert not ctx.worker_stats()["resident"]
+        assert _same(ctx.worker_fit(TIGHT, apps), want)
+        assert ctx.worker_stats()["launches"] >= 2
+        ctx.worker_stop()
+        assert not ctx.worker_stats()["resident"]
+        assert _same(ctx.worker_fit(TIGHT, apps), want)
+    finally:
+        ctx.close()
+
+
+def test_an_install_makes_the_worker_leave_and_the_next_batch_sees_the_new_snapshot():
+    ctx = gangfit.Context(0, options={"worker_idle_us": 100000})
+    try:
+        w1, w2 = wl.headline(2000, 300, seed=5), wl.headline(2500, 300, seed=6)
+        apps = gangfit.make_apps(w1.drv, w1.exe, w1.k)
+        _install(ctx, w1)
+        a1 = ctx.worker_fit(TIGHT, apps)
+        assert ctx.worker_stats()["resident"]
+        assert _same(a1, ctx.fit_batch(IND, TIGHT, apps))
+        _install(ctx, w2)  # serves what was posted, then the worker leaves
+        assert not ctx.worker_stats()["resident"]
+        a2 = ctx.worker_fit(TIGHT, apps)
+        assert _same(a2, ctx.fit_batch(IND, TIGHT, apps))
+        assert not _same(a1, a2)
+        # another packer on the same snapshot: the worker is relaunched for it
+        assert _same(ctx.worker_fit(EVEN, apps), ctx.fit_batch(IND, EVEN, apps))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("algo,sets", [(TIGHT, 4), (EVEN, 3), (TIGHT, 1)])
+def test_tickets_in_flight_device_resident(algo, sets):
+    """More tickets than the ring holds, different queues, own output arrays: every ticket answers what a launch answers."""
+    import torch
+
+    ctx = gangfit.Context(0, options={"worker_sets": sets})
+    try:
+        w = wl.headline(3000, 400, seed=0x71C + sets)
+        _install(ctx, w)
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(sets)
+        n_batches = 150
+        batches, outs, want = [], [], []
+        for b in range(n_batches):
+            n = int(rng.integers(1, 401))
+            pick = rng.permutation(400)[:n]
+            apps, total_k = gangfit.with_offsets(gangfit.make_apps(w.drv[pick], w.exe[pick], w.k[pick]))
+            d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
+            d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+            d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+            ctx.fit_batch_dev(IND, algo, n, d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k)
+            torch.cuda.synchronize()
+            want.append((d_res.clone(), d_exec.clone()))
+            d_res.zero_()
+            d_exec.zero_()
+            batches.append((n, d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k))
+            outs.append((d_apps, d_res, d_exec))
+        torch.cuda.synchronize()
+        first = ctx.worker_submit_dev(algo, batches)
+        ctx.worker_wait(first, n_batches)
+        ctx.worker_stop()
+        torch.cuda.synchronize()
+        for (_, d_res, d_exec), (w_res, w_exec) in zip(outs, want):
+            assert torch.equal(d_res, w_res) and torch.equal(d_exec, w_exec)
+        st = ctx.worker_stats()
+        assert st["posted"] == st["complete"] == n_batches
+    finally:
+        ctx.close()
+
+
+def test_worker_refusals():
+    ctx = gangfit.Context(0)
+    try:
+        with pytest.raises(gangfit.GangfitError):  # no snapshot yet
+            ctx.worker_fit(TIGHT, gangfit.make_apps([[1, 1, 0]], [[1, 1, 0]], [1]))
+        w = wl.headline(500, 10, seed=1)
+        _install(ctx, w)
+        with pytest.raises(gangfit.GangfitError):  # zone packers are not served by the worker
+            ctx.worker_fit(gangfit.GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, gangfit.make_apps(w.drv, w.exe, w.k))
+        v = ctx.view()
+        with pytest.raises(gangfit.GangfitError):
+            v.worker_fit(TIGHT, gangfit.make_apps(w.drv, w.exe, w.k))
+        v.close()
+    finally:
+        ctx.close()
