@@ -2214,12 +2214,12 @@ int worker_join(gf_ctx* ctx) {
 int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     gf_ctx::Worker& w = ctx->worker;
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    GF_HIP(ctx, hipMemsetAsync(&w.d->quit, 0, sizeof(unsigned long long), w.stream));
     host_store(&w.h->state, 0);
     host_store(&w.h->stop, 0);
     gangfit::WorkerArgs a{};
     a.host = w.h_dev;
     a.dev = w.d;
+    a.generation = w.launches + 1;
     a.first_ticket = first_ticket;
     a.idle_ticks = (unsigned long long)w.idle_us * 100ull;  // wall_clock64 ticks at 100 MHz
     a.scratch = w.scratch.ptr;
@@ -2304,7 +2304,9 @@ int worker_drain(gf_ctx* ctx) {
     return GF_OK;
 }
 
-int worker_prepare(gf_ctx* ctx, gf_algo algo, uint64_t max_total_k) {
+// need_launch (nullable): instead of launching, report that a launch for tickets >= posted is needed — the caller posts its
+// tickets first, so that the leader finds them at its first look (gf_worker_submit_dev).
+int worker_prepare(gf_ctx* ctx, gf_algo algo, uint64_t max_total_k, bool* need_launch = nullptr) {
     gf_ctx::Worker& w = ctx->worker;
     if (!ctx->group.empty() || ctx->view_of != nullptr)
         return fail(ctx, GF_ERR_UNSUPPORTED, "the resident worker serves plain contexts (no views, one device)");
@@ -2327,7 +2329,8 @@ int worker_prepare(gf_ctx* ctx, gf_algo algo, uint64_t max_total_k) {
         w.scratch_stride = stride;
     }
     // not running: every ticket posted so far was relayed and served (worker_revive re-drives the ones that were not)
-    if (!w.running) return worker_launch(ctx, algo, w.posted);
+    if (need_launch) *need_launch = !w.running;
+    if (!w.running && !need_launch) return worker_launch(ctx, algo, w.posted);
     return GF_OK;
 }
 
@@ -2364,12 +2367,18 @@ int gf_worker_submit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_batches, const gf
             return fail(ctx, GF_ERR_INVALID, "batch %u: empty, or apps / results NULL", i);
         if (batches[i].exec_nodes_len > max_k) max_k = batches[i].exec_nodes_len;
     }
-    if (const int rc = worker_prepare(ctx, algo, max_k); rc != GF_OK) return rc;
+    bool need_launch = false;
+    if (const int rc = worker_prepare(ctx, algo, max_k, &need_launch); rc != GF_OK) return rc;
     gf_ctx::Worker& w = ctx->worker;
-    if (first_ticket) *first_ticket = w.posted;
+    const uint64_t first = w.posted;
+    if (first_ticket) *first_ticket = first;
     for (uint32_t i = 0; i < n_batches; ++i) {
         if (w.posted - w.completed_upto >= kRing) {  // the slot of ticket `posted` is free once ticket posted - ring is done
             host_store(&w.h->posted, w.posted);      // (ring the doorbell for what has been written so far)
+            if (need_launch) {
+                need_launch = false;
+                if (const int rc = worker_launch(ctx, algo, first); rc != GF_OK) return rc;
+            }
             if (const int rc = worker_wait_ticket(ctx, w.posted - kRing); rc != GF_OK) return rc;
             worker_advance(w);
         }
@@ -2377,6 +2386,7 @@ int gf_worker_submit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_batches, const gf
         worker_post(w, b.n_apps, b.d_apps, b.d_results, b.d_exec_nodes, b.exec_nodes_len, (b.flags & GF_WORKER_HOST_OUTPUTS) != 0);
     }
     host_store(&w.h->posted, w.posted);  // the doorbell: one word for the whole group
+    if (need_launch) return worker_launch(ctx, algo, first);
     return GF_OK;
 }
 

@@ -143,7 +143,7 @@ struct WorkerHostCtl {  // pinned host memory, device-mapped
 };
 
 struct WorkerDevCtl {  // fine-grained device memory
-    unsigned long long quit;
+    unsigned long long quit;  // = generation of the launch whose leader has left (never reset: the next launch has another one)
     unsigned long long pad0[7];
     uint32_t count[kWorkerRing * kWorkerCountStride];  // [slot * stride]: applications of the slot's ticket finished so far
     WorkerTicket ring[kWorkerRing];
@@ -152,6 +152,7 @@ struct WorkerDevCtl {  // fine-grained device memory
 struct WorkerArgs {
     WorkerHostCtl* host;
     WorkerDevCtl* dev;
+    unsigned long long generation;    // of this launch (1, 2, ...): the value the leader writes into the quit word when it leaves
     unsigned long long first_ticket;  // tickets below this one were served by an earlier launch
     unsigned long long idle_ticks;    // the leader leaves after this long without a new ticket (100 MHz)
     uint32_t* scratch;                // [kWorkerRing][3 * scratch_stride]: private placements, two survivor lists

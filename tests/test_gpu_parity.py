@@ -405,6 +405,7 @@ def test_recorded_graph_replays_the_same_batches(gf_ctx):
     for algo in (TIGHT, EVEN):
         d_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
         d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # torch fills on ITS stream; the context's stream does not wait for it
         gf_ctx.fit_batch_dev(IND, algo, len(apps), d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k)
         torch.cuda.synchronize()
         want_res, want_exec = d_res.clone(), d_exec.clone()

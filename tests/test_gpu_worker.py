@@ -105,6 +105,7 @@ def test_tickets_in_flight_device_resident(algo, sets):
             d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
             d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
             d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()  # torch fills on ITS stream; the context's stream does not wait for it
             ctx.fit_batch_dev(IND, algo, n, d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k)
             torch.cuda.synchronize()
             want.append((d_res.clone(), d_exec.clone()))
@@ -117,8 +118,14 @@ def test_tickets_in_flight_device_resident(algo, sets):
         ctx.worker_wait(first, n_batches)
         ctx.worker_stop()
         torch.cuda.synchronize()
-        for (_, d_res, d_exec), (w_res, w_exec) in zip(outs, want):
-            assert torch.equal(d_res, w_res) and torch.equal(d_exec, w_exec)
+        bad = []
+        for b, ((_, d_res, d_exec), (w_res, w_exec)) in enumerate(zip(outs, want)):
+            if not (torch.equal(d_res, w_res) and torch.equal(d_exec, w_exec)):
+                r, wr = d_res.cpu().numpy().view(np.uint32).reshape(-1, 4), w_res.cpu().numpy().view(np.uint32).reshape(-1, 4)
+                rows = np.nonzero((r != wr).any(axis=1))[0]
+                ex = np.nonzero(d_exec.cpu().numpy() != w_exec.cpu().numpy())[0]
+                bad.append((b, len(r), rows[:6].tolist(), r[rows[:3]].tolist(), wr[rows[:3]].tolist(), len(ex), ex[:8].tolist()))
+        assert not bad, bad[:6]
         st = ctx.worker_stats()
         assert st["posted"] == st["complete"] == n_batches
     finally:
@@ -138,5 +145,47 @@ def test_worker_refusals():
         with pytest.raises(gangfit.GangfitError):
             v.worker_fit(TIGHT, gangfit.make_apps(w.drv, w.exe, w.k))
         v.close()
+    finally:
+        ctx.close()
+
+
+def test_record_array_rewritten_while_the_worker_is_resident():
+    """The contract of gf_worker_submit_dev: a device array whose content is replaced by a copy that has COMPLETED before the
+    submit is read with its new content — same address, worker resident all along (its L2s were never invalidated by a
+    kernel boundary)."""
+    import torch
+
+    ctx = gangfit.Context(0, options={"worker_idle_us": 200000})
+    try:
+        w = wl.headline(3000, 400, seed=0xD0D0)
+        _install(ctx, w)
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(9)
+        n = 400
+        queues = []
+        for _ in range(6):
+            pick = rng.permutation(400)
+            apps, total_k = gangfit.with_offsets(gangfit.make_apps(w.drv[pick], w.exe[pick], w.k[pick]))
+            queues.append((apps, total_k, ctx.fit_batch(IND, TIGHT, apps)))
+        max_k = max(q[1] for q in queues)
+        d_apps = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        d_exec = torch.zeros(max_k + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()  # torch's default stream would wait for the resident worker (its stream is a blocking one)
+        for apps, total_k, want in queues:
+            host = torch.from_numpy(apps.view(np.uint8).copy()).pin_memory()
+            with torch.cuda.stream(side):
+                d_apps.copy_(host, non_blocking=True)
+            side.synchronize()
+            first = ctx.worker_submit_dev(TIGHT, [(n, d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k)])
+            ctx.worker_wait(first, 1)
+            with torch.cuda.stream(side):
+                got_res = d_res.cpu().numpy().view(gangfit._native.RESULT_DTYPE)
+                got_exec = d_exec.cpu().numpy().view(np.uint32)[:total_k]
+            assert np.array_equal(got_res, want.results) and np.array_equal(got_exec, want.exec_nodes)
+        st = ctx.worker_stats()
+        assert st["launches"] == 1 and st["resident"]
+        ctx.worker_stop()
     finally:
         ctx.close()

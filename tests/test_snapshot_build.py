@@ -266,6 +266,7 @@ def test_recorded_sequence_is_refused_after_an_install():
         d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
         d_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
         d_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # torch fills on ITS stream; the context's stream does not wait for it
 
         def step():
             ctx.fit_batch_dev(0, 0, len(apps), d_apps.data_ptr(), d_res.data_ptr(), d_exec.data_ptr(), total_k, stream=0)
