@@ -613,7 +613,37 @@ def main():
             e2e_steps = max(20, min(args.steps, 200))
             e2e_wall, _, e2e_walls = timed(host_batch, e2e_steps, 5, min(args.windows, 5))
             dres = d_res.cpu().numpy().view(N.RESULT_DTYPE)
+            # the same blocking host batch through the resident worker (gf_worker_fit: records written into a pinned slice the
+            # device reads in place, answers written by the device into pinned memory; no launch, no stream operation)
+            wk = None
+            try:
+                wres = np.zeros(len(happs), dtype=N.RESULT_DTYPE)
+                wexec = np.zeros(htotal + 1, dtype=np.uint32)
+                pwr, pwe = N.ptr(wres), N.ptr(wexec)
+
+                def worker_batch():
+                    rc = lib.gf_worker_fit(h, TIGHT, len(happs), pa, pwr, pwe, htotal)
+                    if rc != 0:
+                        raise RuntimeError(f"gf_worker_fit: {rc}")
+
+                for _ in range(10):
+                    worker_batch()
+                wws = []
+                for _ in range(min(args.windows, 5)):
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(e2e_steps):
+                        worker_batch()
+                    wws.append(time.perf_counter() - t0)
+                    ctx.worker_stop()
+                wk = {"ms_per_batch": _median(wws) / e2e_steps * 1e3, "decisions_per_s": len(happs) * e2e_steps / _median(wws),
+                      "results_equal": bool(np.array_equal(wres, hres) and np.array_equal(wexec, hexec)),
+                      "note": "one ticket at a time: a lone batch on the worker is a relay over the host link and back, slower "
+                              "than a launch; the worker pays off with tickets in flight (timing.resident_worker)"}
+            except Exception as e:
+                wk = {"error": f"{type(e).__name__}: {e}"}
             out["end_to_end"] = {
+                "through_the_resident_worker": wk,
                 "decisions_per_s": len(happs) * e2e_steps / e2e_wall, "ms_per_batch": e2e_wall / e2e_steps * 1e3,
                 "entry_point": "gf_fit_batch: app records in host memory in, results + placements in host memory out (64 KB + ~64 KB "
                                "per batch, read / written by the kernel through pinned staging buffers), snapshot resident; blocking",

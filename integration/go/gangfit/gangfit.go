@@ -575,6 +575,12 @@ func flattenApps(apps []App) ([]C.gf_app, int, error) {
 
 // fitLocked runs gf_fit_batch on the installed snapshot and maps node indices through `names`; c.mu is held.
 func (c *Context) fitLocked(fifo bool, algo int, apps []App, capps []C.gf_app, total int, names []string) ([]Result, int, error) {
+	return c.fitLockedVia(false, fifo, algo, apps, capps, total, names)
+}
+
+// fitLockedVia: viaWorker sends an INDEPENDENT batch of a plain packer through the resident worker (gf_worker_fit: no kernel
+// launch, records and answers in pinned memory) instead of gf_fit_batch — same answers.
+func (c *Context) fitLockedVia(viaWorker, fifo bool, algo int, apps []App, capps []C.gf_app, total int, names []string) ([]Result, int, error) {
 	cres := make([]C.gf_result, len(apps))
 	execNodes := make([]uint32, total+1)
 	var failed C.int32_t = -1
@@ -587,7 +593,11 @@ func (c *Context) fitLocked(fifo bool, algo int, apps []App, capps []C.gf_app, t
 	if len(apps) > 0 {
 		pa, pr = &capps[0], &cres[0]
 	}
-	if rc := C.gf_fit_batch(c.ctx, mode, C.gf_algo(algo), C.uint32_t(len(apps)), pa, pr, p32(execNodes),
+	if viaWorker && !fifo {
+		if rc := C.gf_worker_fit(c.ctx, C.gf_algo(algo), C.uint32_t(len(apps)), pa, pr, p32(execNodes), C.uint64_t(total)); rc != C.GF_OK {
+			return nil, -1, c.err(rc)
+		}
+	} else if rc := C.gf_fit_batch(c.ctx, mode, C.gf_algo(algo), C.uint32_t(len(apps)), pa, pr, p32(execNodes),
 		C.uint64_t(total), &failed); rc != C.GF_OK {
 		return nil, -1, c.err(rc)
 	}
@@ -626,3 +636,32 @@ func (c *Context) FitBatchOnInstalledSnapshot(fifo bool, algo int, apps []App) (
 	defer c.mu.Unlock()
 	return c.fitLocked(fifo, algo, apps, capps, total, c.names)
 }
+
+// FitIndependentOnWorker is FitBatchOnInstalledSnapshot(fifo = false) through the RESIDENT WORKER (include/gangfit.h,
+// gf_worker_*): for a caller that sends one independent batch after the other — the unschedulable-pod scan over many
+// instance groups' pods (unschedulablepods.go:93-166), a capacity what-if sweep.  Calls on one context serialise on c.mu;
+// the worker stays on the device for gf_set_option("worker_idle_us") after a batch and is launched again by the next one
+// that finds it gone, so back-to-back batches pay no kernel launch.  (Its throughput shows with several tickets in flight:
+// gf_worker_submit_dev, device-resident batches.)  Plain packers only (algo 0, 1, 2); any install (ClusterSet, SnapshotBuildResident, FitBatch) first serves what was
+// posted and makes the worker leave.  Unverified here (no Go toolchain); tests/test_gpu_worker.py drives the C entry points.
+func (c *Context) FitIndependentOnWorker(algo int, apps []App) ([]Result, error) {
+	capps, total, err := flattenApps(apps)
+	if err != nil {
+		return nil, err
+	}
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	results, _, err := c.fitLockedVia(true, false, algo, apps, capps, total, c.names)
+	return results, err
+}
+
+// WorkerStop makes the resident worker leave the device now (it leaves by itself when idle).
+func (c *Context) WorkerStop() error {
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	if rc := C.gf_worker_stop(c.ctx); rc != C.GF_OK {
+		return c.err(rc)
+	}
+	return nil
+}
+

@@ -1002,6 +1002,69 @@ static void TestConcurrentViews() {
 // ------------------------------------------------------------------------------------------------ one context, several devices
 // gf_init with n_dev > 1 (include/gangfit.h): the Go shim reaches node-range sharding by passing more device ids, nothing
 // else changes.  Driven here through gangfit.h only (no torch, no Python): the sharded batch must equal the one-device one.
+// The resident worker of the independent batch through the C ABI (gf_worker_fit): what a launch answers, batch after batch,
+// across an install (which makes the worker leave) and after it has left for lack of work.
+static void TestResidentWorker() {
+    const uint32_t n = 4000, n_apps = 600;
+    uint64_t rng = 0xFEEDBEEF;
+    auto next = [&]() {
+        rng += 0x9E3779B97F4A7C15ull;
+        uint64_t z = rng;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    gf_ctx* ctx = nullptr;
+    CHECK(gf_init(nullptr, 0, &ctx) == GF_OK);
+    if (!ctx) return;
+    CHECK(gf_set_option(ctx, "worker_idle_us", 100) == GF_OK);
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    for (int round = 0; round < 2; ++round) {  // two snapshots: the second install finds a worker on the device
+        std::vector<int64_t> cpu(n), mem(n), gpu(n, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            cpu[i] = (int64_t)(4 + next() % 60) * 1000;
+            mem[i] = (int64_t)(8 + next() % 248) * Gi;
+        }
+        CHECK(gf_snapshot_set(ctx, n, cpu.data(), mem.data(), gpu.data(), nullptr, nullptr, nullptr) == GF_OK);
+        CHECK(gf_orders_set(ctx, order.data(), n, order.data(), n) == GF_OK);
+        for (gf_algo algo : {GF_ALGO_TIGHTLY_PACK, GF_ALGO_DISTRIBUTE_EVENLY, GF_ALGO_MINIMAL_FRAGMENTATION}) {
+            for (int batch = 0; batch < 4; ++batch) {
+                const uint32_t na = batch == 3 ? 1u : n_apps - 37u * (uint32_t)batch;
+                std::vector<gf_app> apps(na);
+                uint64_t total_k = 0;
+                for (gf_app& a : apps) {
+                    a = gf_app{};
+                    a.drv[0] = 1000 * (int64_t)(1 + next() % 3);
+                    a.drv[1] = (int64_t)(2 << (next() % 3)) * Gi;
+                    a.exe[0] = 1000 * (int64_t)(1 << (next() % 4));
+                    a.exe[1] = (int64_t)(4 << (next() % 4)) * Gi;
+                    a.k = (int32_t)(next() % 24);
+                    total_k += (uint64_t)a.k;
+                }
+                std::vector<gf_result> want(na), got(na);
+                std::vector<uint32_t> want_x(total_k + 1), got_x(total_k + 1);
+                CHECK(gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, na, apps.data(), want.data(), want_x.data(), total_k, nullptr) == GF_OK);
+                CHECK(gf_worker_fit(ctx, algo, na, apps.data(), got.data(), got_x.data(), total_k) == GF_OK);
+                CHECK(std::memcmp(want.data(), got.data(), na * sizeof(gf_result)) == 0);
+                CHECK(std::memcmp(want_x.data(), got_x.data(), total_k * sizeof(uint32_t)) == 0);
+                if (batch == 1) std::this_thread::sleep_for(std::chrono::milliseconds(5));  // the worker leaves; the next batch brings it back
+            }
+        }
+    }
+    uint64_t st[4] = {0, 0, 0, 0};
+    CHECK(gf_worker_stats(ctx, st) == GF_OK);
+    CHECK(st[0] == 24 && st[1] == 24 && st[2] >= 8);  // 24 tickets; at least one launch per (snapshot, packer) + the idle exits
+    CHECK(gf_worker_stop(ctx) == GF_OK);
+    CHECK(gf_worker_stats(ctx, st) == GF_OK && st[3] == 0);
+    gf_app bad{};
+    bad.k = 1;
+    gf_result r{};
+    uint32_t x[2];
+    CHECK(gf_worker_fit(ctx, GF_ALGO_SINGLE_AZ_TIGHTLY_PACK, 1, &bad, &r, x, 1) != GF_OK);  // zone packers are not served
+    gf_destroy(ctx);
+}
+
 static void TestMultiDeviceContext() {
     const uint32_t n = 3000, n_apps = 500;
     std::vector<int64_t> col[3];
@@ -1106,6 +1169,7 @@ int main(int argc, char** argv) {
         TestFindNodes();
         TestTwoThreadsOneContext();
         TestConcurrentViews();
+        TestResidentWorker();
         TestMultiDeviceContext();
         gf_destroy(g_ctx);
     }
