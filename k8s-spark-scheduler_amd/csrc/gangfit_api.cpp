@@ -103,6 +103,7 @@ struct DeviceBuf {
 template <typename T>
 struct PinnedBuf {
     T* ptr = nullptr;
+    T* dev = nullptr;  // the device's address of the same memory (nullptr: not mapped); looked up once per allocation
     size_t cap = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
@@ -114,11 +115,19 @@ struct PinnedBuf {
         if (ptr) (void)hipHostFree(ptr);
         ptr = fresh;
         cap = want;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, fresh, 0) == hipSuccess) {
+            dev = static_cast<T*>(d);
+        } else {
+            (void)hipGetLastError();
+            dev = nullptr;
+        }
         return hipSuccess;
     }
     void release() {
         if (ptr) (void)hipHostFree(ptr);
         ptr = nullptr;
+        dev = nullptr;
         cap = 0;
     }
 };
@@ -171,6 +180,7 @@ struct gf_ctx {
     bool seq_held = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool stream_borrowed = false;  // a shard of a multi-device context on a device an earlier shard is on: it uses that one's stream
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // The resident worker of the independent batch (gf_worker_*; gangfit_worker.inc).
     struct Worker {
@@ -1126,6 +1136,18 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
             // what the other devices store into / read from lives in fine-grained memory: a posted peer store must not depend
             // on what a kernel boundary does to this device's caches
             sub->g_part_all.fine = sub->g_drv_all.fine = sub->g_exec2.fine = true;
+            // Shards on ONE device (a repeated id: how the path runs on a one-GPU box) share a stream: separate streams buy them
+            // nothing there, and with sixteen hardware queues every cross-stream event wait of the exchanges is a real
+            // cross-queue barrier (eight shards: 1.0 ms per headline batch with eight streams, 0.35 with the runtime's four
+            // queues).  Shards on different devices keep their own.
+            for (gf_ctx* earlier : g->group)
+                if (earlier->device == sub->device) {
+                    (void)hipSetDevice(sub->device);
+                    (void)hipStreamDestroy(sub->stream);
+                    sub->stream = earlier->stream;
+                    sub->stream_borrowed = true;
+                    break;
+                }
             g->group.push_back(sub);
             g->g_devices.push_back(device_ids[i]);
             bool ok = hipSetDevice(sub->device) == hipSuccess;
@@ -1232,7 +1254,7 @@ void gf_destroy(gf_ctx* ctx) {
         for (void* c : ctx->g_comms)
             if (c) (void)rccl().CommDestroy(c);
         ctx->g_comms.clear();
-        for (gf_ctx* s : ctx->group) gf_destroy(s);
+        for (auto it = ctx->group.rbegin(); it != ctx->group.rend(); ++it) gf_destroy(*it);  // (borrowers of a stream before its owner)
         ctx->group.clear();
         (void)hipSetDevice(ctx->device);
         ctx->h_apps.release();
@@ -1333,7 +1355,7 @@ void gf_destroy(gf_ctx* ctx) {
         if (ctx->worker.h) (void)hipHostFree(ctx->worker.h);
         if (ctx->worker.stream) (void)hipStreamDestroy(ctx->worker.stream);
     }
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -2031,10 +2053,8 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     // visible when the kernel has completed).  A copy engine round trip costs more than the whole kernel at these sizes.
     if (ctx->zero_copy && mode == GF_MODE_INDEPENDENT && !is_zone_algo(algo) && ctx->have_orders &&
         (uint64_t)n_apps * sizeof(gf_app) + total_k * sizeof(uint32_t) <= (UINT64_C(4) << 20)) {
-        void *da = nullptr, *dr = nullptr, *de = nullptr;
-        if (hipHostGetDevicePointer(&da, ctx->h_apps.ptr, 0) == hipSuccess &&
-            hipHostGetDevicePointer(&dr, ctx->h_results.ptr, 0) == hipSuccess &&
-            hipHostGetDevicePointer(&de, ctx->h_exec.ptr, 0) == hipSuccess) {
+        void *da = ctx->h_apps.dev, *dr = ctx->h_results.dev, *de = ctx->h_exec.dev;
+        if (da != nullptr && dr != nullptr && de != nullptr) {
             const int rc0 = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
                                    static_cast<gf_result*>(dr), static_cast<uint32_t*>(de), total_k, ctx->d_failed.ptr, st);
             if (rc0 != GF_OK) return rc0;
@@ -2043,7 +2063,6 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
             if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
             return GF_OK;
         }
-        (void)hipGetLastError();
     }
     // ---- FIFO chains of the plain packers on the solo kernel: resume from the last chain's checkpoints where the queues agree
     ChainRun run;
@@ -2055,13 +2074,11 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     // visible part of a resumed chain, and what keeps chains on different streams from overlapping.  A FIFO chain goes
     // further: its first kernel reads the records from the pinned buffer and its last one writes the answers there
     // (gf_ctx::HostIo), which makes a Filter three launches and no copy.
-    void *da = nullptr, *dr = nullptr, *de = nullptr, *df = nullptr;
-    const bool mapped = ctx->zero_copy && hipHostGetDevicePointer(&dr, ctx->h_results.ptr, 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&de, ctx->h_exec.ptr, 0) == hipSuccess &&
-                        hipHostGetDevicePointer(&df, ctx->h_failed.ptr, 0) == hipSuccess;
+    void *da = ctx->h_apps.dev, *dr = ctx->h_results.dev, *de = ctx->h_exec.dev, *df = ctx->h_failed.dev;
+    const bool mapped = ctx->zero_copy && dr != nullptr && de != nullptr && df != nullptr;
     gf_ctx::HostIo& hio = ctx->hio;
     hio = gf_ctx::HostIo{};
-    if (mapped && mode == GF_MODE_FIFO_CHAIN && hipHostGetDevicePointer(&da, ctx->h_apps.ptr, 0) == hipSuccess) {
+    if (mapped && mode == GF_MODE_FIFO_CHAIN && da != nullptr) {
         hio.active = true;
         hio.n_apps = n_apps;
         hio.apps = static_cast<const gf_app*>(da);
@@ -2069,7 +2086,6 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         hio.exec = static_cast<uint32_t*>(de);
         hio.failed = static_cast<int32_t*>(df);
     } else {
-        (void)hipGetLastError();
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr + a0, ctx->h_apps.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_app),
                                    hipMemcpyHostToDevice, st));
     }
@@ -3466,6 +3482,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
     }
     part_all.n = drv_all.n = S;
     const bool use_rccl = g->g_comms.size() == S;
+    bool several_streams = false;  // (every shard on one device: one stream, nothing to order with events)
+    for (uint32_t s = 1; s < S; ++s) several_streams = several_streams || g->group[s]->stream != first->stream;
     // RCCL exchange: every device's collective is enqueued on its own stream inside one group call; the library orders the
     // streams against each other, so the event fan-out of the peer-store path is not needed
     auto rccl_all_gather = [&](auto loc, auto all, size_t bytes_each) -> int {
@@ -3484,7 +3502,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         for (uint32_t t = 0; t < S; ++t) {
             hipError_t e = hipSetDevice(g->group[t]->device);
             for (uint32_t s = 0; s < S && e == hipSuccess; ++s)
-                if (s != t) e = hipStreamWaitEvent(g->group[t]->stream, g->group[s]->g_ev[which], 0);
+                if (s != t && g->group[s]->stream != g->group[t]->stream)  // (shards on one device share a stream: already ordered)
+                    e = hipStreamWaitEvent(g->group[t]->stream, g->group[s]->g_ev[which], 0);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -3499,14 +3518,14 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         if (use_rccl) continue;
         GF_HIP(g, gangfit::launch_shard_push(c->g_part_loc.ptr, part_all, (size_t)s * n_apps * sizeof(gf_shard_partial),
                                              (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
-        GF_HIP(g, hipEventRecord(c->g_ev[0], c->stream));
+        if (several_streams) GF_HIP(g, hipEventRecord(c->g_ev[0], c->stream));
     }
     if (use_rccl) {
         if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_part_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_part_all.ptr; },
                             (size_t)n_apps * sizeof(gf_shard_partial)) != 0)
             return fail(g, GF_ERR_HIP, "ncclAllGather of the capacity sums failed");
     } else {
-        GF_HIP(g, everyone_waits(0));
+        if (several_streams) GF_HIP(g, everyone_waits(0));
     }
     // ---- step 2: first feasible driver of each range, gathered everywhere
     for (uint32_t s = 0; s < S; ++s) {
@@ -3516,14 +3535,14 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         if (use_rccl) continue;
         GF_HIP(g, gangfit::launch_shard_push(c->g_drv_loc.ptr, drv_all, (size_t)s * n_apps * sizeof(gf_shard_driver),
                                              (size_t)n_apps * sizeof(gf_shard_driver), c->stream));
-        GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
+        if (several_streams) GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
     }
     if (use_rccl) {
         if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_drv_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_drv_all.ptr; },
                             (size_t)n_apps * sizeof(gf_shard_driver)) != 0)
             return fail(g, GF_ERR_HIP, "ncclAllGather of the driver records failed");
     } else {
-        GF_HIP(g, everyone_waits(1));
+        if (several_streams) GF_HIP(g, everyone_waits(1));
     }
     // ---- step 3: every shard emits its slice of the placements
     for (uint32_t s = 0; s < S; ++s) {
@@ -3531,7 +3550,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         GF_HIP(g, hipSetDevice(c->device));
         GF_HIP(g, gangfit::launch_shard_emit(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
                                              c->g_drv_all.ptr, c->d_results.ptr, c->g_exec2.ptr, half, c->stream));
-        GF_HIP(g, hipEventRecord(c->g_ev[2], c->stream));
+        if (several_streams) GF_HIP(g, hipEventRecord(c->g_ev[2], c->stream));
     }
     // ---- step 4 on the first device only: sum of the slices (each entry written by exactly one shard), finish, D2H
     if (use_rccl) {  // the reduction north_star names: sum of the placement slices onto the first device, over xGMI
@@ -3546,7 +3565,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         GF_HIP(g, hipSetDevice(first->device));
     } else {
         GF_HIP(g, hipSetDevice(first->device));
-        for (uint32_t s = 1; s < S; ++s) GF_HIP(g, hipStreamWaitEvent(first->stream, g->group[s]->g_ev[2], 0));
+        for (uint32_t s = 1; s < S; ++s)
+            if (g->group[s]->stream != first->stream) GF_HIP(g, hipStreamWaitEvent(first->stream, g->group[s]->g_ev[2], 0));
         if (g->g_fault != 1)  // fault injection: the other shards' placement slices never arrive
             GF_HIP(g, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream));
     }
