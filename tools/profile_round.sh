@@ -12,9 +12,12 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline ${BENCH_ARGS:-}"
+# (--worker-sets 0: the headline through the launch path only — every batch is a dispatch row; the resident worker of the
+#  independent batch is ONE long dispatch and gets a trace of its own below)
+BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline --worker-sets 0 ${BENCH_ARGS:-}"
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats_worker" -o stats -- python $ROOT/bench.py --steps 200 --warmup 5 --windows 3 --no-cpu-baseline --headline-only > "$OUT/stats_worker.log" 2>&1
 # the headline alone: every fit_independent_kernel dispatch of this trace is a headline launch (its average duration is the
 # figure bench.py's roofline.kernel_ms must agree with)
 timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats_headline" -o stats -- $BENCH --headline-only > "$OUT/stats_headline.log" 2>&1
@@ -24,7 +27,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -T -f csv -d
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -T -f csv -d "$OUT/pmc_sq" -o pmc -- $BENCH > "$OUT/pmc_sq.log" 2>&1
 # the plain FIFO chain alone: every fit_fifo_solo_kernel launch of these passes is a full replay of the headline chain
 # (999 earlier drivers + 1) -> instructions per application for bench.py's roofline.fifo_chain (profiles/pmc_chain.json)
-CHAIN="python $ROOT/bench.py --steps 20 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline --no-extras --fifo-protocols cold"
+CHAIN="python $ROOT/bench.py --steps 20 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline --no-extras --fifo-protocols cold --worker-sets 0"
 timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats_chain" -o stats -- $CHAIN > "$OUT/stats_chain.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -T -f csv -d "$OUT/chain_sq" -o pmc -- $CHAIN > "$OUT/chain_sq.log" 2>&1
 # BASELINE config 3 alone (10 000 nodes x 10 000 apps, both packers): kernel durations, HBM traffic, L2 hits / misses

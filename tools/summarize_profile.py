@@ -59,7 +59,7 @@ def main():
     with open(os.path.join(dst, f"{tag}_summary.md"), "w") as out:
         out.write(f"# rocprofv3 summary — {tag}\n\nCommand: `tools/profile_round.sh {tag}` on one MI355X (gfx950), "
                   "i.e. `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30 "
-                  "--no-cpu-baseline`, the same with `--headline-only`, and one `--pmc` pass per counter set (FETCH_SIZE, "
+                  "--no-cpu-baseline --worker-sets 0` (the launch path: every batch a dispatch row), the same with `--headline-only`, and one `--pmc` pass per counter set (FETCH_SIZE, "
                   "WRITE_SIZE and the L2 pair on the headline alone; the SQ and LDS sets on the full run so that the FIFO chain "
                   "kernels are covered).\n\n")
         hstats = os.path.join(src, "stats_headline", "stats_kernel_stats.csv")
@@ -70,6 +70,22 @@ def main():
             for r in csv.DictReader(open(hstats)):
                 if "fit_independent" in r["Name"] or "empty_kernel" in r["Name"]:
                     out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
+            out.write("\n")
+        wstats = os.path.join(src, "stats_worker", "stats_kernel_stats.csv")
+        if os.path.exists(wstats):
+            shutil.copy(wstats, os.path.join(dst, f"{tag}_kernel_stats_worker.csv"))
+            wj = _bench_json(os.path.join(src, "stats_worker.log"))
+            out.write("## the headline through the resident worker (`bench.py --steps 200 --headline-only`, worker on)\n\n"
+                      "One dispatch of `fit_worker_kernel` per window (it serves the window's 200 tickets and leaves); the "
+                      "launch-path windows of the same run appear as `fit_independent_kernel` rows.\n\n")
+            out.write("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
+            for r in csv.DictReader(open(wstats)):
+                if "fit_worker" in r["Name"] or "fit_independent" in r["Name"]:
+                    out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
+            if wj:
+                out.write(f"\nbench line of that run: value {wj.get('value', 0) / 1e6:.1f} M decisions/s, "
+                          f"{wj.get('ms_per_step', 0) * 1e3:.2f} us per step; launch path "
+                          f"{wj.get('timing', {}).get('launch_path', {}).get('value', 0) / 1e6:.1f} M/s\n")
             out.write("\n")
         out.write("## kernel stats (all kernels of the full bench run)\n\n")
         out.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
