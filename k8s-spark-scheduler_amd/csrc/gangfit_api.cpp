@@ -387,6 +387,11 @@ struct gf_ctx {
                                       // kernel on a table with a global tail): restored by a kernel instead of a copy
     } chain;
     uint64_t chain_stat[4] = {0, 0, 0, 0};  // chains | resumed chains | applications evaluated | applications skipped
+    struct PlannedUnits {  // what chain_plan found for the call in progress: narrow_begin does not scan the queue again
+        bool valid = false;
+        int64_t eff[3] = {0, 0, 0};
+        int32_t factor[3] = {1, 1, 1};
+    } planned_units;
 };
 
 namespace {
@@ -596,7 +601,14 @@ int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t
                  gangfit::ChainIo* io, const int32_t* restore = nullptr, bool restore_dirty_chunks = false) {
     int64_t eff[3];
     int32_t factor[3];
-    narrow_units(ctx, h_apps, n_apps, eff, factor, nullptr);
+    if (ctx->planned_units.valid) {
+        for (int j = 0; j < 3; ++j) {
+            eff[j] = ctx->planned_units.eff[j];
+            factor[j] = ctx->planned_units.factor[j];
+        }
+    } else {
+        narrow_units(ctx, h_apps, n_apps, eff, factor, nullptr);
+    }
     nt->cpu = ctx->d_nwork.ptr;
     nt->mem = nt->cpu + ctx->n_slots;
     nt->gpu = nt->mem + ctx->n_slots;
@@ -634,6 +646,7 @@ struct ChainRun {
     uint32_t a_begin = 0;        // first application this launch evaluates (a multiple of 1 << shift); 0 = from the snapshot
     bool record = false;         // dump checkpoints into ctx->chain.d_ckpt
     bool narrow_proven = false;  // every request has a scaled form (checked on the host): the wide twin is not launched
+    uint32_t common = 0;         // leading applications identical to the cached queue's (>= a_begin): the cache keeps them
 };
 
 // The checkpoint arguments of a chain kernel and the table it starts from.
@@ -873,10 +886,35 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
         if (!lds_chain) return false;
         table_in_lds = g1 >= ctx->n_slots;
     }
+    // The narrow units of the queue and the proof that every request has a scaled form.  A scan of the whole queue is twelve
+    // 64-bit divisions per application — more host time than a resumed chain takes on the device —, so a queue that shares a
+    // prefix with the cached one is only scanned behind it: the cached units divide the prefix by construction, and when they
+    // divide the new applications too they ARE a valid set of units for this queue (any common divisor keeps the chain exact;
+    // the checkpoints are scaled in them).  Otherwise: the full scan, and the chain replays.
     int64_t eff[3];
     int32_t factor[3];
     bool proven = false;
-    narrow_units(ctx, h_apps, n_apps, eff, factor, &proven);
+    uint32_t common = 0;  // applications this queue shares with the cached one, from the front (the last of either excluded)
+    bool units_from_cache = false;
+    if (C.valid && C.epoch == ctx->snap_epoch && C.algo == (int)algo && C.n_apps > 0) {
+        const uint32_t lim = (n_apps < C.n_apps ? n_apps : C.n_apps) - 1;
+        while (common < lim && std::memcmp(&h_apps[common], &C.apps[common], sizeof(gf_app)) == 0) ++common;
+        bool ok = common > 0;
+        for (uint32_t i = common; i < n_apps && ok; ++i) {
+            ok = h_apps[i].k >= 0 && h_apps[i].k <= GF_MAX_K;
+            for (int j = 0; j < 3 && ok; ++j)
+                for (const int64_t v : {h_apps[i].drv[j], h_apps[i].exe[j]})
+                    ok = ok && v >= 0 && v % C.unit[j] == 0 && v / C.unit[j] < (INT64_C(1) << 30);
+        }
+        if (ok) {
+            units_from_cache = proven = true;
+            for (int j = 0; j < 3; ++j) {
+                eff[j] = C.unit[j];
+                factor[j] = (int32_t)(ctx->unit[j] / C.unit[j]);  // (the cached chain passed the range check with these)
+            }
+        }
+    }
+    if (!units_from_cache) narrow_units(ctx, h_apps, n_apps, eff, factor, &proven);
     if (!proven) return false;
     // checkpoint interval: 32 applications while a dump is cheap — the whole table from LDS, or (solo kernel, table with a
     // global tail) only the chunks that differ from the snapshot; 128 where a dump copies a table that lives in global memory
@@ -893,10 +931,7 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
     if (same) {
         // longest common prefix of the two queues, the last application of either excluded (nothing is committed behind
         // the driver being filtered: its table is not a state of the longer chain)
-        uint32_t lim = (n_apps < C.n_apps ? n_apps : C.n_apps) - 1;
-        uint32_t m = 0;
-        while (m < lim && std::memcmp(&h_apps[m], &C.apps[m], sizeof(gf_app)) == 0) ++m;
-        uint32_t c = m >> shift;
+        uint32_t c = common >> shift;
         if (c > C.n_ckpt) c = C.n_ckpt;
         a_begin = c << shift;
     }
@@ -927,17 +962,31 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
     C.dirty_format = dirty_format;
     for (int j = 0; j < 3; ++j) C.unit[j] = eff[j];
     run->a_begin = a_begin;
+    run->common = same ? common : 0;
     run->record = true;
     run->narrow_proven = true;
+    ctx->planned_units.valid = true;
+    for (int j = 0; j < 3; ++j) {
+        ctx->planned_units.eff[j] = eff[j];
+        ctx->planned_units.factor[j] = factor[j];
+    }
     return true;
 }
 
 // The chain that just ran becomes the cached one (h_results / h_exec hold the complete answer, prefix included).
 void chain_commit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, uint64_t total_k, int32_t failed_at, const ChainRun& run) {
     gf_ctx::ChainCache& C = ctx->chain;
-    C.apps.assign(ctx->h_apps.ptr, ctx->h_apps.ptr + n_apps);
-    C.results.assign(ctx->h_results.ptr, ctx->h_results.ptr + n_apps);
-    C.exec.assign(ctx->h_exec.ptr, ctx->h_exec.ptr + total_k);
+    // what the cached queue already holds stays: records up to the common prefix, answers up to the first application evaluated
+    const uint32_t keep_apps = C.valid ? (run.common < n_apps ? run.common : n_apps) : 0u;
+    const uint32_t keep_res = C.valid ? run.a_begin : 0u;
+    const uint64_t keep_exec = keep_res > 0 ? ctx->h_apps.ptr[keep_res].exec_off : 0;
+    C.apps.resize(n_apps);
+    std::memcpy(C.apps.data() + keep_apps, ctx->h_apps.ptr + keep_apps, (size_t)(n_apps - keep_apps) * sizeof(gf_app));
+    C.results.resize(n_apps);
+    std::memcpy(C.results.data() + keep_res, ctx->h_results.ptr + keep_res, (size_t)(n_apps - keep_res) * sizeof(gf_result));
+    C.exec.resize(total_k);
+    if (total_k > keep_exec)
+        std::memcpy(C.exec.data() + keep_exec, ctx->h_exec.ptr + keep_exec, (size_t)(total_k - keep_exec) * sizeof(uint32_t));
     C.n_apps = n_apps;
     C.failed_at = failed_at;
     C.algo = (int)algo;
@@ -2066,6 +2115,7 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     }
     // ---- FIFO chains of the plain packers on the solo kernel: resume from the last chain's checkpoints where the queues agree
     ChainRun run;
+    ctx->planned_units.valid = false;
     const bool use_cache = chain_plan(ctx, mode, algo, n_apps, ctx->h_apps.ptr, &run);
     const uint32_t a0 = run.a_begin;
     const uint64_t k0 = a0 > 0 ? ctx->h_apps.ptr[a0].exec_off : 0;  // placements of the skipped prefix
@@ -2093,6 +2143,7 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
                           total_k, ctx->d_failed.ptr, st, use_cache ? &run : nullptr);
     const bool answers_sent = hio.active && hio.out_done;
     hio.active = false;
+    ctx->planned_units.valid = false;
     if (rc != GF_OK) {
         ctx->chain.valid = false;
         return rc;
@@ -2127,14 +2178,14 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         return fail(ctx, GF_ERR_HIP, "waiting for the batch failed: %s", hipGetErrorString(we));
     }
     int32_t failed_at = mode == GF_MODE_FIFO_CHAIN ? ctx->h_failed.ptr[0] : -1;
-    if (a0 > 0) {  // the prefix the chain did not replay comes from the cache; the kernel counted from a0
-        std::memcpy(ctx->h_results.ptr, ctx->chain.results.data(), (size_t)a0 * sizeof(gf_result));
-        if (k0) std::memcpy(ctx->h_exec.ptr, ctx->chain.exec.data(), (size_t)k0 * sizeof(uint32_t));
+    if (a0 > 0) {  // the prefix the chain did not replay comes from the cache, straight to the caller; the kernel counted from a0
+        std::memcpy(results, ctx->chain.results.data(), (size_t)a0 * sizeof(gf_result));
+        if (k0) std::memcpy(exec_nodes, ctx->chain.exec.data(), (size_t)k0 * sizeof(uint32_t));
         if (failed_at >= 0) failed_at += (int32_t)a0;
     }
     if (use_cache) chain_commit(ctx, algo, n_apps, total_k, failed_at, run);
-    std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
-    if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
+    std::memcpy(results + a0, ctx->h_results.ptr + a0, (size_t)(n_apps - a0) * sizeof(gf_result));
+    if (total_k > k0) std::memcpy(exec_nodes + k0, ctx->h_exec.ptr + k0, (size_t)(total_k - k0) * sizeof(uint32_t));
     if (mode == GF_MODE_FIFO_CHAIN && chain_failed_at) *chain_failed_at = failed_at;
     return GF_OK;
 }
