@@ -76,6 +76,11 @@ def one_seed(ctxs, seed):
             gpu = ctx.fit_batch(0, algo, apps)
             ref = ob.fit_independent(algo, avail, oapps, D, X, sched=sched, zone=zone)
             bad = same(gpu, ref, False)
+            if bad is None and algo in (0, 1, 2) and cname == "default":  # the same batch as a ticket of the resident worker
+                wk = ctx.worker_fit(algo, apps)
+                bad = same(wk, ref, False)
+                if bad:
+                    bad = "resident worker: " + bad
             if bad is None and algo in (3, 4, 5, 0, 1):
                 avg = ctx.avg_packing_efficiency(algo, apps, gpu)
                 if ref.avg_eff is not None and not np.array_equal(avg.view(np.uint64), np.asarray(ref.avg_eff).view(np.uint64)):
