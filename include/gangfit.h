@@ -446,7 +446,8 @@ int gf_launch_floor(gf_ctx *ctx, void *stream, uint32_t iters, float *us_per_lau
  *   - plain packers only (tightly-pack, distribute-evenly, minimal-fragmentation); plain contexts only (no views, one
  *     device); results are bit-identical to gf_fit_batch(GF_MODE_INDEPENDENT) — same wave-level code.
  *   options: "worker_sets" (groups of wavefronts = batches in flight on the device, default 3), "worker_blocks_per_set"
- *   (workgroups of eight wavefronts per group, default 128), "worker_idle_us".
+ *   (workgroups of sixteen wavefronts per group, default 64: each fills a CU, 3 x 64 + 1 of them leave the rest of the device
+ *   to FIFO chains), "worker_idle_us".
  *
  * gf_worker_fit: one blocking batch with host arrays, like gf_fit_batch(GF_MODE_INDEPENDENT): the records are written into
  * a pinned slice the device reads in place, results and placements are written by the device into pinned memory (zero copy

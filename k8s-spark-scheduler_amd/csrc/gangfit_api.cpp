@@ -197,7 +197,7 @@ struct gf_ctx {
         uint64_t posted = 0;          // tickets posted so far (the host's copy of the doorbell)
         uint64_t completed_upto = 0;  // every ticket below this one is known complete
         uint32_t sets = 3;
-        uint32_t blocks_per_set = 128;  // x 8 wavefronts
+        uint32_t blocks_per_set = 64;  // x 16 wavefronts
         uint32_t idle_us = 200;
         uint64_t launches = 0;
         // staging of gf_worker_fit: one pinned (coherent, device-mapped) slice per ring slot
@@ -2232,23 +2232,14 @@ int worker_alloc(gf_ctx* ctx) {
         (void)hipHostFree(hp);
         return fail(ctx, GF_ERR_HIP, "the worker's device control block cannot be allocated");
     }
-    // its own stream, kept off a few compute units: the worker's wavefronts sit on every CU they may use for as long as
-    // batches keep coming, and a FIFO chain needs a whole CU (sixteen wavefronts, the LDS) to start
+    // its own non-blocking stream.  (A stream with a CU mask — to keep compute units free for FIFO chains — was measured first:
+    // its first window cost 10 ms and, depending on the context, every ticket 3.8 instead of 2.4 us.  The free CUs come from the
+    // worker's shape instead: workgroups of sixteen wavefronts that fill a CU's registers, fewer of them than the device has CUs.)
     hipStream_t st = nullptr;
-    {
-        const uint32_t cus = (uint32_t)ctx->info.compute_units;
-        std::vector<uint32_t> mask((cus + 31) / 32, 0xFFFFFFFFu);
-        const uint32_t keep_free = cus >= 64 ? 16u : 0u;
-        for (uint32_t i = cus - keep_free; i < (uint32_t)mask.size() * 32; ++i) mask[i / 32] &= ~(1u << (i % 32));
-        if (keep_free == 0 || hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-            (void)hipGetLastError();
-            st = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-                (void)hipFree(dp);
-                (void)hipHostFree(hp);
-                return fail(ctx, GF_ERR_HIP, "the worker's stream cannot be created");
-            }
-        }
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipFree(dp);
+        (void)hipHostFree(hp);
+        return fail(ctx, GF_ERR_HIP, "the worker's stream cannot be created");
     }
     w.h = static_cast<gangfit::WorkerHostCtl*>(hp);
     w.h_dev = static_cast<gangfit::WorkerHostCtl*>(hd);
@@ -2292,16 +2283,15 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     a.scratch = w.scratch.ptr;
     a.scratch_stride = w.scratch_stride;
     // every workgroup must be resident at once (a group that waits for a CU would leave its tickets unserved while the others
-    // spin): at most what the device admits, with a margin
+    // spin), and sixteen CUs stay free for FIFO chains (a chain needs a whole CU: sixteen wavefronts, the LDS): a workgroup of
+    // the worker fills a CU's registers, so it has a CU to itself and the count of workgroups is the count of CUs taken
     uint32_t sets = w.sets;
     {
         const uint32_t cus = (uint32_t)ctx->info.compute_units;
-        const uint32_t usable = cus >= 64 ? cus - 16u : cus;  // the worker's stream keeps sixteen CUs free (worker_alloc)
         int per_cu = 0;
         GF_HIP(ctx, gangfit::worker_blocks_per_cu(algo, &per_cu));
-        if (per_cu > 3) per_cu = 3;  // (106 SGPRs: the hardware admits six 256-thread workgroups' worth of wavefronts)
         if (per_cu < 1) return fail(ctx, GF_ERR_HIP, "the worker kernel does not fit a CU");
-        const uint32_t room = usable * (uint32_t)per_cu;
+        const uint32_t room = cus > 32 ? cus - 16u : cus;  // (per_cu is 1 for the tightly-pack instance; never count on more)
         while (sets > 1 && 1u + sets * w.blocks_per_set > room) --sets;
         if (1u + sets * w.blocks_per_set > room) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set does not fit the device");
     }

@@ -119,7 +119,7 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
 
 // ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gf_worker_* in gangfit_api.cpp)
 constexpr uint32_t kWorkerRing = 64;
-constexpr int kWorkerWaves = 8;              // wavefronts per workgroup of the worker kernel
+constexpr int kWorkerWaves = 16;             // wavefronts per workgroup of the worker kernel (one workgroup fills a CU)
 constexpr uint32_t kWorkerCountStride = 64;  // words between two tickets' counters: one 256-byte line (one memory channel) each  // tickets in flight at most (host side waits for ticket t - kWorkerRing before it posts t)
 
 // A ticket: six self-validating 8-byte words.  word[0] = ticket number + 1; words 1..5 carry worker_tag(ticket) in their

@@ -189,3 +189,26 @@ def test_record_array_rewritten_while_the_worker_is_resident():
         ctx.worker_stop()
     finally:
         ctx.close()
+
+
+def test_a_fifo_chain_starts_next_to_a_resident_worker():
+    """The worker's workgroups each fill a CU and there are fewer of them than CUs: a FIFO chain (which needs a whole CU)
+    does not have to wait for the worker to leave."""
+    ctx = gangfit.Context(0, options={"worker_idle_us": 500000})
+    try:
+        w = wl.headline(5000, 300, seed=0xFEED)
+        _install(ctx, w)
+        apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+        want = ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, TIGHT, apps)
+        ctx.set_option("chain_cache", 0)  # the chain below replays
+        assert _same(ctx.worker_fit(TIGHT, apps), ctx.fit_batch(IND, TIGHT, apps))
+        assert ctx.worker_stats()["resident"]
+        t0 = time.perf_counter()
+        got = ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, TIGHT, apps)
+        dt = time.perf_counter() - t0
+        assert ctx.worker_stats()["resident"]  # ... and it is still there
+        assert _same(got, want) and got.failed_at == want.failed_at
+        assert dt < 0.1, dt  # (half a second would be the worker's idle period)
+        ctx.worker_stop()
+    finally:
+        ctx.close()

@@ -24,7 +24,7 @@ def med(x):
 
 
 for sets in (1, 2, 3):
-    for bps in (128,):
+    for bps in (64,):
         ctx = gangfit.Context(0, options={"worker_sets": sets, "worker_blocks_per_set": bps})
         ctx.set_snapshot(s.avail, s.sched)
         ctx.set_orders(s.driver_order, s.exec_order)
