@@ -2257,7 +2257,7 @@ int worker_join(gf_ctx* ctx) {
     if (!w.running) return GF_OK;
     GF_HIP(ctx, hipSetDevice(ctx->device));
     host_store(&w.h->stop, w.posted + 2);  // "leave after ticket posted - 1" (gangfit_worker.inc)
-    const hipError_t e = hipStreamSynchronize(w.stream);
+    const hipError_t e = gf_wait_stream(w.stream);
     host_store(&w.h->stop, 0);
     w.running = false;
     if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "the worker did not leave the device: %s", hipGetErrorString(e));
@@ -2317,7 +2317,7 @@ int worker_revive(gf_ctx* ctx) {
     if (w.running) {
         if (host_load(&w.h->state) != 2) return GF_OK;
         GF_HIP(ctx, hipSetDevice(ctx->device));
-        GF_HIP(ctx, hipStreamSynchronize(w.stream));
+        GF_HIP(ctx, gf_wait_stream(w.stream));
         w.running = false;
     }
     // not on the device: whatever was posted behind the last ticket the leader relayed needs a launch

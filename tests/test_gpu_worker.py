@@ -42,6 +42,9 @@ def test_worker_fit_answers_what_a_launch_answers(algo):
             assert _same(ctx.worker_fit(algo, sub), ctx.fit_batch(IND, algo, sub))
         st = ctx.worker_stats()
         assert st["posted"] == st["complete"] == 8
+        # more applications than a set has wavefronts (3 x 1024 + a ragged rest): every wavefront takes several per ticket
+        big = np.concatenate([apps] * 5)[:3333]
+        assert _same(ctx.worker_fit(algo, big), ctx.fit_batch(IND, algo, big))
     finally:
         ctx.close()
 
