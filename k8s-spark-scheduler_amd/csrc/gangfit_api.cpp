@@ -17,6 +17,7 @@
 #include <new>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gangfit.h"
@@ -2336,6 +2337,8 @@ int worker_wait_ticket(gf_ctx* ctx, uint64_t t) {
     uint32_t spins = 0;
     for (;;) {
         if (t < w.completed_upto || host_load(&w.h->done[t % kRing]) == t + 1) return GF_OK;
+        if (wait_blocking() && (spins & 0x7u) == 0x7u)  // GANGFIT_WAIT=block: the host cannot spare the core for the wait
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
         if ((++spins & 0x3Fu) == 0) {
             if (const int rc = worker_revive(ctx); rc != GF_OK) return rc;
             if (!w.running && host_load(&w.h->done[t % kRing]) != t + 1)
