@@ -242,7 +242,7 @@ struct gf_ctx {
     bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
     PinnedBuf<uint64_t> h_masks;
-    DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (prepare_apps_kernel)
+    DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (chain_prologue_kernel)
     DeviceBuf<int32_t> d_wide_needed;       // two words used alternately: set by the chain prologue when a request has no narrow
                                             // form; each prologue zeroes the word the NEXT chain will use (wide_flag)
     uint32_t wide_seq = 0;                  // chains launched: parity picks the word
@@ -553,7 +553,7 @@ int ensure_cnt(gf_ctx* ctx, uint64_t n_decisions, hipStream_t stream) {
 // as long as every scaled magnitude stays below 2^30; comparisons, subtractions and floor divisions are invariant under a
 // common factor, so the chain is bit-identical.  Device-resident batches (gf_fit_batch_dev) keep the table's units.
 // *proven (nullable): every request of the batch is a multiple of the resulting units and fits the narrow range, i.e. the
-// narrow kernel will not hand the batch to its wide twin (what prepare_apps_kernel tests on the device).
+// narrow kernel will not hand the batch to its wide twin (what prepare_app tests on the device).
 void narrow_units(const gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, int64_t eff[3], int32_t factor[3], bool* proven) {
     for (int j = 0; j < 3; ++j) {
         eff[j] = ctx->unit[j];

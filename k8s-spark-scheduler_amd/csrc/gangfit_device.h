@@ -76,7 +76,7 @@ struct EffTables {
 };
 
 // Narrow (scaled int32) domain of the FIFO chain — see gangfit_fifo_common.inc.
-struct NApp {  // 64 bytes, produced by prepare_apps_kernel: requests divided by the table's units
+struct NApp {  // 64 bytes, produced by the chain prologue (prepare_app): requests divided by the table's units
     int32_t drv[3];
     int32_t k;
     int32_t exe[3];  // >= 0
