@@ -1731,13 +1731,14 @@ hipError_t launch_v2(const FifoPlan& P, const NodeTable& T, uint32_t n_apps, con
 template <int ALGO>
 hipError_t launch_solo(const FifoPlan& P, const NodeTable& T, const NarrowTable& NT, uint32_t n_apps, NApp* d_napps,
                        const int32_t* d_wide_needed, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                       uint64_t half, int32_t* d_failed, const ChainCkpt& ck, ScanStats* d_stats, hipStream_t stream) {
+                       uint64_t half, int32_t* d_failed, const ChainCkpt& ck, const SoloFused& F, ScanStats* d_stats,
+                       hipStream_t stream) {
     const size_t lds = fifo_solo_lds_bytes(P.lds_slots_solo, T.n_chunks);
     constexpr int NW = 16;  // wavefront 0 walks the chain; all sixteen share the prologue, the checkpoints and the epilogue
     const bool resident = P.lds_slots_solo >= T.n_slots;
 #define GF_SOLO(PR, RE)                                                                                                     \
     return launch_one_workgroup(fit_fifo_solo_kernel<ALGO, NW, PR, RE>, NW, lds, stream, T, NT, P.lds_slots_solo, n_apps,    \
-                                d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, ck, d_stats)
+                                d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, ck, F, d_stats)
     if (d_stats != nullptr) {
         if (resident) GF_SOLO(true, true);
         GF_SOLO(true, false);
@@ -1756,13 +1757,30 @@ hipError_t launch_fifo_algo(const FifoPlan& P, const NodeTable& T, const NarrowT
     const int32_t* guard = nullptr;
     // run heads of the tightly-pack fast path: "no head here"
     const bool heads = P.narrow && ALGO == GF_ALGO_TIGHTLY_PACK && half > 1 + heads_lo;
-    e = launch_chain_prologue(io, n_apps, d_apps, P.narrow ? d_napps : nullptr, NT.unit, d_wide_needed,
-                              heads ? d_scratch + heads_lo : nullptr, heads ? (size_t)(half - 1 - heads_lo) : 0, stream);
-    if (e != hipSuccess) return e;
+    // The solo kernel is its own first kernel when the whole table lives in LDS, the host has proven every request's scaled
+    // form (no wide twin) and nothing but a plain table copy was left to the prologue.
+    SoloFused F{};
+    F.enabled = (P.narrow && !P.wide && P.lds_slots_solo >= T.n_slots && io.overlay == nullptr && io.copy_words[1] == 0 &&
+                 (io.copy_words[0] == 0 || io.copy_words[0] == 3 * (size_t)T.n_slots))
+                    ? 1
+                    : 0;
+    if (F.enabled) {
+        F.apps_src = io.apps_src;
+        F.apps_dst = const_cast<gf_app*>(d_apps);
+        F.table_src = io.copy_words[0] ? reinterpret_cast<const int32_t*>(io.copy_src[0]) : nullptr;
+        for (int j = 0; j < 3; ++j) F.unit[j] = NT.unit[j];
+        F.fill_dst = heads ? d_scratch + heads_lo : nullptr;
+        F.fill_words = heads ? (size_t)(half - 1 - heads_lo) : 0;
+        F.wide_clear = io.wide_clear;
+    } else {
+        e = launch_chain_prologue(io, n_apps, d_apps, P.narrow ? d_napps : nullptr, NT.unit, d_wide_needed,
+                                  heads ? d_scratch + heads_lo : nullptr, heads ? (size_t)(half - 1 - heads_lo) : 0, stream);
+        if (e != hipSuccess) return e;
+    }
     if (P.narrow) {
         guard = d_wide_needed;
         e = launch_solo<ALGO>(P, T, NT, n_apps, d_napps, d_wide_needed, d_results, d_exec_nodes, d_scratch, half, d_failed, ck,
-                              d_stats, stream);
+                              F, d_stats, stream);
         if (e != hipSuccess) return e;
     }
     if (P.wide) {
