@@ -1648,7 +1648,7 @@ size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
     const size_t nw = (n_chunks + 63u) / 64u, nwp = nw < 4 ? 4 : nw;
     size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nwp +
-                 8 * (size_t)n_chunks + 8 * nw;
+                 8 * (size_t)n_chunks + 8 * nw + 8 * (size_t)kMaxShapes;
     off = (off + 15) & ~(size_t)15;
     off += sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 + 4 * kMaxShapes +
            4 * (size_t)n_chunks + 12 * (size_t)n_chunks;
