@@ -30,6 +30,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # the deployment's setting: before the HIP runtime initialises
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "k8s-spark-scheduler_amd")):
     if _p not in sys.path:

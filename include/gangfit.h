@@ -165,8 +165,10 @@ const char *gf_last_error(gf_ctx *ctx);
  *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
  *   "rccl_selftest"          n: binds librccl at run time and checks a one-rank all-gather + reduce of n words on this device
  * GF_ERR_INVALID for an unknown key or a value out of range.  The only environment variables the library reads are
- * GANGFIT_WAIT=block (completion waits park the thread instead of polling) and GANGFIT_CHAIN_CACHE=0; the first gf_init
- * of a process sets GPU_MAX_HW_QUEUES=16 for the HIP runtime unless the host already set it (concurrent views, gf_ctx_view). */
+ * GANGFIT_WAIT=block (completion waits park the thread instead of polling) and GANGFIT_CHAIN_CACHE=0.  It never changes
+ * the process environment: a deployment that runs chains concurrently (gf_ctx_view) sets GPU_MAX_HW_QUEUES=16 itself
+ * before the process starts ("Deployment") — gf_ctx_view leaves a note in gf_last_error when it finds
+ * fewer than 8. */
 int gf_set_option(gf_ctx *ctx, const char *key, int64_t value);
 
 /* Upload the per-node snapshot = the AvailableResources / SchedulableResources columns of

@@ -360,6 +360,7 @@ struct gf_ctx {
     std::shared_mutex views_mu;  // (in the parent)
     int install_depth = 0;       // (in the parent, under mu) nested installs take views_mu once
     int n_views = 0;             // (in the parent, under mu) live views
+    std::vector<gf_ctx*> views;  // (in the parent, under mu) the live views: an install waits for their streams
 
     // ---- incremental FIFO chains (gf_fit_batch, GF_MODE_FIFO_CHAIN).  The reference replays every earlier driver on every
     //      Filter (resource.go:309-328); with an unchanged snapshot driver j + 1's chain is driver j's chain plus one
@@ -416,6 +417,10 @@ struct InstallGuard {
         if (c->install_depth++ == 0) {
             worker_quiesce(c);  // the resident worker reads the installed tables: it leaves before they change
             c->views_mu.lock();
+            // a view's asynchronous entry points (gf_fit_batch_dev, recorded graphs) return with kernels still reading the
+            // aliased tables, which an install overwrites in place: wait for every view's stream, not only for its calls
+            for (gf_ctx* v : c->views)
+                if (v->stream != nullptr && hipSetDevice(v->device) == hipSuccess) (void)gf_wait_stream(v->stream);
         }
     }
     ~InstallGuard() {
@@ -1159,14 +1164,6 @@ int gf_version(void) { return GF_VERSION; }
 int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (!out) return GF_ERR_INVALID;
     *out = nullptr;
-    // The HIP runtime multiplexes streams over a few hardware queues (four by default), and two FIFO chains whose streams
-    // share a queue run one after the other: eight views took 3.1x one chain's time with four queues, 1.1x with sixteen
-    // (host_test gpu, TestConcurrentViews).  The variable is read when the runtime initialises — normally the first HIP call
-    // below — and a value the host already set is left alone.
-    {
-        static std::once_flag once;
-        std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); });
-    }
     if (n_dev > 1) {
         // One context over several devices: sub-context i owns range i of n_dev of the priority order.  A device id may
         // repeat (several shards on one GPU: how the path is exercised on a one-GPU box).
@@ -1286,6 +1283,7 @@ int gf_ctx_view(gf_ctx* parent, gf_ctx** out) {
     {
         std::lock_guard<std::recursive_mutex> lock(parent->mu);
         ++parent->n_views;
+        parent->views.push_back(v);
         v->lds_budget = parent->lds_budget;
         v->fifo_generic = parent->fifo_generic;
         v->fifo_minfrag_matrix = parent->fifo_minfrag_matrix;
@@ -1294,6 +1292,18 @@ int gf_ctx_view(gf_ctx* parent, gf_ctx** out) {
         v->zero_copy = parent->zero_copy;
     }
     v->view_of = parent;
+    // The HIP runtime multiplexes streams over a few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise, read when
+    // the runtime initialises), and two FIFO chains whose streams share a queue run one after the other: eight views took 3.1x
+    // one chain's time with four queues, 1.1x with sixteen (host_test gpu, TestConcurrentViews).  That variable belongs to the
+    // deployment ("Deployment"), not to a library loaded into somebody else's process: say so, once per view.
+    {
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        const long nq = q ? std::strtol(q, nullptr, 10) : 0;
+        if (nq < 8)
+            v->err = "note: GPU_MAX_HW_QUEUES is " + std::string(q ? q : "unset (the HIP runtime's default is 4 hardware queues)") +
+                     ": chains of concurrent views may run one after the other; set GPU_MAX_HW_QUEUES=16 in the extender's "
+                     "environment before the process starts";
+    }
     *out = v;
     return GF_OK;
 }
@@ -1315,9 +1325,14 @@ void gf_destroy(gf_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)gf_wait_stream(ctx->stream);
+    // the resident worker reads the tables released below as kernel arguments: it serves what was posted and leaves first
+    // (hipFree would otherwise wait — implicitly, and for up to worker_idle_us — for a kernel that is still reading them)
+    if (ctx->worker.allocated) worker_quiesce(ctx);
     if (ctx->view_of != nullptr) {
         std::lock_guard<std::recursive_mutex> plock(ctx->view_of->mu);
         --ctx->view_of->n_views;
+        auto& vs = ctx->view_of->views;
+        vs.erase(std::remove(vs.begin(), vs.end(), ctx), vs.end());
     }
     ctx->d_snap.release();
     ctx->d_work.release();
@@ -1398,7 +1413,6 @@ void gf_destroy(gf_ctx* ctx) {
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->worker.allocated) {
-        worker_quiesce(ctx);
         ctx->worker.scratch.release();
         if (ctx->worker.stage) (void)hipHostFree(ctx->worker.stage);
         if (ctx->worker.d) (void)hipFree(ctx->worker.d);
@@ -2251,22 +2265,36 @@ int worker_alloc(gf_ctx* ctx) {
 }
 
 void worker_advance(gf_ctx::Worker& w);
+int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket);
 
 // Makes the launch on the device (if any) leave once it has relayed and served every ticket posted so far, and waits for that.
+// The leader may have idled out (or been stopped by worker_wait_ticket's 5 s limit) just as the last tickets were posted: it
+// then left with consumed < posted.  Those tickets are re-driven here, on the still-installed snapshot, before the caller —
+// usually an install — may go on; a context whose tickets cannot be served any more forgets them instead of refusing every
+// later call.
 int worker_join(gf_ctx* ctx) {
     gf_ctx::Worker& w = ctx->worker;
     if (!w.running) return GF_OK;
     GF_HIP(ctx, hipSetDevice(ctx->device));
-    host_store(&w.h->stop, w.posted + 2);  // "leave after ticket posted - 1" (gangfit_worker.inc)
-    const hipError_t e = gf_wait_stream(w.stream);
-    host_store(&w.h->stop, 0);
-    w.running = false;
-    if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "the worker did not leave the device: %s", hipGetErrorString(e));
-    worker_advance(w);
-    if (w.completed_upto != w.posted)
-        return fail(ctx, GF_ERR_HIP, "the worker left with tickets %llu .. %llu unserved", (unsigned long long)w.completed_upto,
-                    (unsigned long long)w.posted);
-    return GF_OK;
+    for (int attempt = 0;; ++attempt) {
+        host_store(&w.h->stop, w.posted + 2);  // "leave after ticket posted - 1" (gangfit_worker.inc)
+        const hipError_t e = gf_wait_stream(w.stream);
+        host_store(&w.h->stop, 0);
+        w.running = false;
+        if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "the worker did not leave the device: %s", hipGetErrorString(e));
+        worker_advance(w);
+        if (w.completed_upto == w.posted) return GF_OK;
+        const uint64_t consumed = host_load(&w.h->consumed);
+        if (attempt < 4 && w.algo >= 0 && consumed < w.posted && w.epoch == ctx->snap_epoch) {
+            if (const int rc = worker_launch(ctx, (gf_algo)w.algo, consumed); rc != GF_OK) return rc;
+            continue;
+        }
+        const uint64_t lost_lo = w.completed_upto, lost_hi = w.posted;
+        w.completed_upto = w.posted;  // forget them: the ring is usable again (their callers were told, or never will wait)
+        host_store(&w.h->consumed, w.posted);
+        return fail(ctx, GF_ERR_HIP, "the worker left with tickets %llu .. %llu unserved (relayed %llu)", (unsigned long long)lost_lo,
+                    (unsigned long long)lost_hi, (unsigned long long)consumed);
+    }
 }
 
 // (Re)launches the worker for tickets >= first_ticket on the installed snapshot.

@@ -1734,7 +1734,7 @@ hipError_t launch_solo(const FifoPlan& P, const NodeTable& T, const NarrowTable&
                        uint64_t half, int32_t* d_failed, const ChainCkpt& ck, const SoloFused& F, ScanStats* d_stats,
                        hipStream_t stream) {
     const size_t lds = fifo_solo_lds_bytes(P.lds_slots_solo, T.n_chunks);
-    constexpr int NW = 16;  // wavefront 0 walks the chain; all sixteen share the prologue, the checkpoints and the epilogue
+    constexpr int NW = GF_SOLO_WAVES;  // wavefront 0 walks the chain; all of them share the prologue, the checkpoints and the epilogue
     const bool resident = P.lds_slots_solo >= T.n_slots;
 #define GF_SOLO(PR, RE)                                                                                                     \
     return launch_one_workgroup(fit_fifo_solo_kernel<ALGO, NW, PR, RE>, NW, lds, stream, T, NT, P.lds_slots_solo, n_apps,    \

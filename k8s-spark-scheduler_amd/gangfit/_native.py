@@ -74,6 +74,11 @@ class GangfitError(RuntimeError):
 
 _lib: Optional[C.CDLL] = None
 
+# The deployment's part ("Deployment"): sixteen hardware queues, so that concurrent views' chains do not share
+# one.  The HIP runtime reads it when it initialises (its first call in the process — torch's, if torch gets there first), so
+# it is set when this package is imported; the library itself never touches the environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 
 def library_path() -> str:
     """The in-tree library; GANGFIT_LIB points tuning experiments at another build of the same sources."""

@@ -77,6 +77,9 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNode(const std::string& ins
             apps.push_back(a);
         }
     }
+    // pods come and go: entries no request has used lately are dropped once the map outgrows the pods it is asked about
+    if (parsed_apps_.size() > 2 * pods.size() + 64)
+        for (auto it = parsed_apps_.begin(); it != parsed_apps_.end();) it = it->second.seen == flat_calls_ ? std::next(it) : parsed_apps_.erase(it);
     gf_app cur{};
     if (!resources->DriverResources.canonical(cur.drv) || !resources->ExecutorResources.canonical(cur.exe) ||
         resources->MinExecutorCount < 0 || resources->MinExecutorCount > GF_MAX_K) {
@@ -407,6 +410,9 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
             for (int j = 0; j < 3; ++j) over[j][it->second] = v[j];
         }
     }
+    // ---- from here on this Filter reads and writes the extender's caches and its record of what sits on the device
+    std::lock_guard<std::mutex> flat_lock(*flat_mu_);
+    ++flat_calls_;
     // the request's NodeNames as candidate flags: the same list for every Filter of an instance group until the node set
     // changes, so the 10 000 map lookups are done once per (cluster version, list)
     // (eight bytes per multiply: a byte-at-a-time hash of 100 000 names is a 1.5 ms dependent chain)
@@ -429,13 +435,15 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
         }
         names_hash = (names_hash ^ h) * 1099511628211ull;  // order-sensitive across names; h of each name is independent work
     }
-    if (cluster.version == 0 || flags_cluster_ != cluster.version || flags_hash_ != names_hash || flags_names_ != nodeNames.size()) {
+    // (a hash hit is confirmed on the list itself: comparing 10 000 short strings costs a fraction of the 10 000 map lookups
+    //  it saves, and a collision would silently change the node the Filter returns)
+    if (cluster.version == 0 || flags_cluster_ != cluster.version || flags_hash_ != names_hash || flags_names_ != nodeNames) {
         flags_cache_ = cluster.base_flags;
         for (const std::string& name : nodeNames)
             if (auto it = cluster.index.find(name); it != cluster.index.end()) flags_cache_[it->second] |= GF_NODE_DRIVER_CANDIDATE;
         flags_cluster_ = cluster.version;
         flags_hash_ = names_hash;
-        flags_names_ = nodeNames.size();
+        flags_names_ = nodeNames;
     }
     const std::vector<uint32_t>& flags = flags_cache_;
     // ---- the applications: earlier drivers in creation order, then this one
@@ -457,6 +465,7 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
                 pa = &parsed_apps_[p->UID.empty() ? p->Namespace + "/" + p->Name : p->UID];
                 cached = pa->version == p->ResourceVersion;
             }
+            pa->seen = flat_calls_;
             if (!cached) {
                 pa->version = p->ResourceVersion;
                 pa->app = gf_app{};
@@ -472,6 +481,9 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNodeFlat(const std::string&
             a.flags = shouldSkipDriverFifo(*p, instanceGroup) ? GF_APP_SKIPPABLE : 0u;
             apps.push_back(a);
         }
+    // pods come and go: entries no request has used lately are dropped once the map outgrows the pods it is asked about
+    if (parsed_apps_.size() > 2 * pods.size() + 64)
+        for (auto it = parsed_apps_.begin(); it != parsed_apps_.end();) it = it->second.seen == flat_calls_ ? std::next(it) : parsed_apps_.erase(it);
     gf_app cur{};
     if (!resources->DriverResources.canonical(cur.drv) || !resources->ExecutorResources.canonical(cur.exe) ||
         resources->MinExecutorCount < 0 || resources->MinExecutorCount > GF_MAX_K)

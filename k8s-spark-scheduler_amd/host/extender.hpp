@@ -12,6 +12,8 @@
 #pragma once
 
 #include <map>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <set>
 #include <string>
@@ -146,14 +148,20 @@ private:
     // resource.go:231) and matches the request's NodeNames against the node set again.  Both are pure functions of things
     // that carry a version: the flat route keeps the canonical requests per (pod UID, resourceVersion) and the candidate
     // flags per (cluster version, NodeNames).
+    // Predicate requests run on per-request threads (cmd/endpoints.go:29-37): everything below is read and written under
+    // flat_mu_, which a flat Filter takes before it touches the caches and holds until it returns (always before the
+    // context's sequence lock, never the other way round).
     struct ParsedApp {
         uint64_t version = 0;
+        uint64_t seen = 0;  // flat_calls_ of the last Filter that used the entry: what a prune keeps
         bool ok = false, representable = false;
         gf_app app{};
     };
-    std::unordered_map<std::string, ParsedApp> parsed_apps_;
+    std::shared_ptr<std::mutex> flat_mu_ = std::make_shared<std::mutex>();  // (the extender stays copyable: copies share it)
+    uint64_t flat_calls_ = 0;
+    std::unordered_map<std::string, ParsedApp> parsed_apps_;  // pruned to the pods of the current request when it outgrows them
     uint64_t flags_cluster_ = 0, flags_hash_ = 0;
-    size_t flags_names_ = 0;
+    std::vector<std::string> flags_names_;  // the NodeNames the cached flags were computed from (a hash hit is confirmed on them)
     std::vector<uint32_t> flags_cache_;
     Binpacker binpacker_;
     NodeSorter sorter_;

@@ -36,6 +36,8 @@ static double pct(std::vector<double> v, double q) {
 }
 
 int main(int argc, char** argv) {
+    // the deployment's part ("Deployment"): the library never changes the environment itself
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     const int n_nodes = argc > 1 ? std::atoi(argv[1]) : 10000;
     const int n_pending = argc > 2 ? std::atoi(argv[2]) : 1000;
     const int n_rr = argc > 3 ? std::atoi(argv[3]) : 2000;

@@ -7,6 +7,7 @@
 //   findNodes (no reference test exists: checked against the literal loop of failover.go:412-436 on the host types)
 // `host_test cpu` needs no GPU (parsing, sorting, snapshot, reservations); `host_test gpu` drives the device through
 // the C ABI exactly like the Go shim would.  Exit code 0 = all passed.
+#include <cstdlib>
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
@@ -1140,6 +1141,8 @@ static void TestMultiDeviceContext() {
 }
 
 int main(int argc, char** argv) {
+    // the deployment's part ("Deployment"): the library never changes the environment itself
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     if (mode == "cpu" || mode == "all") {
         TestParseQuantity();
