@@ -2,20 +2,34 @@
 """bench.py — gang-fit decisions/sec + FIFO Filter latency on MI355X (BASELINE.json's metric, both halves).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-  * step      = one pass of the hot path over one batch: `gf_fit_batch_dev(INDEPENDENT, tightly-pack)` over the
-                pending-app table of the headline workload (10 000 nodes x 1 000 pending apps, SURVEY.md 8d
-                distributions), inputs already resident in HBM.
+  * step      = one pass of the hot path over one batch: the independent gang-fit decision (SparkBinPack + tightlyPackExecutors
+                + driver-fit check) of every application of the headline workload's pending table (10 000 nodes x 1 000 pending
+                apps, SURVEY.md 8d distributions), inputs already resident in HBM.  The K steps of a window are served in TWO
+                regimes and both are reported (`roofline.regimes`):
+                  streamed_tickets   K tickets of the resident worker (gf_worker_submit_dev: one launch of fit_worker_kernel
+                                     serves the window, `worker_sets` batches in flight; its launch and departure are inside
+                                     the window) — what a caller sees that sends batch after batch;
+                  launch_per_batch   K launches of fit_independent_kernel on one stream, recorded as one graph
+                                     (gf_fit_batch_dev) — what rocprofv3 sees as one dispatch per batch;
+                plus what ONE blocking call costs a host that hands over host memory (`blocking_call`, gf_fit_batch) — what the
+                reference's only independent-batch consumer issues (unschedulablepods.go:93-166, once a minute).
+  * value     = decisions/sec of the whole job = n_gpus * apps_per_batch * K / median window of the FASTER of the two K-step
+                regimes; `config.regime` names it and `roofline` describes the kernel of THAT regime (roofline.kernel_ms is that
+                kernel's device time per step, HIP events on the stream it runs on: <= ms_per_step).
   * timing    = W warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides,
-                wall time = max over ranks of (rank's clock from the opening barrier to its own synchronize after step K).  A K-step window is 0.1-0.2 ms at the driver's K = 20, where one scheduler
-                hiccup moves the figure by tens of percent, so `--windows` (default 9) such windows are timed and the
-                MEDIAN is reported; every window is listed under `timing`.
-  * value     = decisions/sec of the whole job = n_gpus * apps_per_batch * K / median window.
+                wall time = max over ranks of (rank's clock from the opening barrier to its own synchronize after step K).  A
+                K-step window is 0.1-0.2 ms at the driver's K = 20, where one scheduler hiccup moves the figure by tens of
+                percent, so `--windows` (default 9) such windows are timed and the MEDIAN is reported; every window is listed.
   * N > 1     = the pending-app table shards across ranks (independent decisions: no data-path collective);
                 every rank holds the full node table; per-GPU work is fixed -> "weak" scaling.
-  * roofline  = the dominant kernel (fit_independent_kernel) is LATENCY bound: `achieved` counts the bytes the lazy scan
-                really visits (in-kernel counters) against the HBM peak (frac <= 1 by construction), the full-scan
-                figure of SURVEY.md 8d is kept as `algorithmic_full_scan_GBps`, and the launch floor measured in this run
-                (empty kernel, same stream) says how much of the kernel is launch.
+  * roofline  = ONE definition of `frac` everywhere (headline, config 3, FIFO chain): three measured fractions —
+                hbm   = HBM bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this command, committed
+                        under profiles/) / kernel time / 8 TB/s,
+                l2    = L2 request bytes (TCC_HIT + TCC_MISS, 128-byte lines) / kernel time / 34.5 TB/s,
+                issue = issued instructions (SQ_INSTS_VALU + SALU + LDS + SMEM) / (1 024 SIMDs x 2.4 GHz x kernel time),
+                `bound` = the largest of them, `frac` = its value.  The SURVEY.md 8d full-scan formula (which charges bytes the
+                lazy scan never reads) and the visited bytes of the in-kernel counters are kept as information, never divided
+                by a peak.  `traffic` = the HBM bytes per step of the profile (null when no profile of this kernel is committed).
   * cpu_baseline = the literal C oracle (port of the reference's loops) on the same workload, 1 core; the FIFO Filter
                 (`fifo_filter`, the latency half of the metric) carries its own CPU figure: the literal chain on the same
                 queue, decision-only and with the per-node efficiency map the reference's SparkBinPack also builds.
@@ -38,7 +52,43 @@ for _p in (REPO, os.path.join(REPO, "k8s-spark-scheduler_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-PROFILE_TAG = "r3"      # profiles/<tag>_* hold the rocprofv3 passes of this command (tools/profile_round.sh)
+L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICROARCH.md)
+N_SIMDS = 1024          # 256 CUs x 4
+CLOCK_GHZ = 2.4
+ISSUE_PEAK_GINST = N_SIMDS * CLOCK_GHZ  # one instruction per SIMD and cycle
+PROFILE_TAG = "r4"      # profiles/<tag>_* hold the rocprofv3 passes of this command (tools/profile_round.sh)
+
+
+def load_profile(name):
+    """A committed counter summary (profiles/<name>, written by tools/summarize_profile.py from rocprofv3 --pmc passes of this
+    command on the MI355X box), or None."""
+    path = os.path.join(REPO, "profiles", name)
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def three_fractions(time_s, hbm_bytes, l2_bytes, instructions, simds=N_SIMDS):
+    """The one definition of `frac` (see the module docstring): measured HBM bytes, L2 request bytes and issued instructions of
+    one step, each against its own peak over the kernel's time for that step.  Returns (fractions, bound, frac); a quantity
+    that was not measured is left out, and bound is None when nothing was."""
+    fr = {}
+    if hbm_bytes is not None:
+        a = hbm_bytes / time_s / 1e9
+        fr["hbm"] = {"bytes_per_step": hbm_bytes, "achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS}
+    if l2_bytes is not None:
+        a = l2_bytes / time_s / 1e9
+        fr["l2"] = {"bytes_per_step": l2_bytes, "achieved": a, "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": a / L2_PEAK_GBPS}
+    if instructions is not None:
+        a = instructions / time_s / 1e9
+        peak = simds * CLOCK_GHZ
+        fr["issue"] = {"instructions_per_step": instructions, "achieved": a, "peak": peak, "unit": "Ginstr/s", "frac": a / peak,
+                       "simds": simds}
+    if not fr:
+        return fr, None, None
+    bound = max(fr, key=lambda k: fr[k]["frac"])
+    return fr, bound, fr[bound]["frac"]
 
 
 def _percentile(xs, q):
@@ -184,13 +234,11 @@ def cpu_chain_baseline(algo, avail, sched, zone, driver_order, exec_order, drv, 
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 3
 
-L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICROARCH.md)
-
-
 def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
-    """10 000 nodes x 10 000 pending apps, both plain packers, device resident: decisions/s, kernel time, and the roofline in
-    VISITED bytes (in-kernel counters: the scans are lazy like the reference's loops) against the HBM spec peak and against
-    the L2 peak (the 240 KB table is cache resident after first touch), next to the full-scan formula of SURVEY.md 8d."""
+    """10 000 nodes x 10 000 pending apps, both plain packers, device resident: decisions/s, kernel time, and the roofline as the
+    three measured fractions (HBM bytes, L2 request bytes, issued instructions of profiles/pmc_config3.json over this run's
+    kernel time).  The visited bytes of the in-kernel counters and the SURVEY.md 8d full-scan formula are listed as
+    information only: most visited bytes are served by the L1 / L2, and the formula charges bytes the lazy scan never reads."""
     import gangfit
     from gangfit import workloads as wl
 
@@ -203,13 +251,7 @@ def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
     d_res3 = torch.zeros(len(apps3) * 16, dtype=torch.uint8, device=dev)
     d_exec3 = torch.zeros(total_k3 + 1, dtype=torch.int32, device=dev)
     alg = wl.algorithmic_bytes(len(w3.snapshot.exec_order), w3.k)
-    pmc = None
-    pmc_path = os.path.join(REPO, "profiles", "pmc_config3.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-        except Exception:
-            pmc = None
+    pmc = load_profile("pmc_config3.json")
     c3 = {}
     for name, algo in (("tightly_pack", gangfit.GF_ALGO_TIGHTLY_PACK), ("distribute_evenly", gangfit.GF_ALGO_DISTRIBUTE_EVENLY)):
         def step3():
@@ -221,23 +263,23 @@ def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
         torch.cuda.synchronize()
         xv, dv = ctx.scan_stats(enable=False, reset=True)
         visited = xv * 24 + dv * 28 + len(apps3) * 88 + 4 * int(w3.k.sum())
-        ach = visited / (kern_3 * 1e-3) / 1e9
-        hb = ((pmc or {}).get(name) or {}).get("hbm_bytes")
-        c3[name] = {"decisions_per_s": len(apps3) * steps / wall_3, "kernel_ms": kern_3, "submission": how3,
-                    "roofline": {"bound": "latency", "nominal_bound": "hbm", "kernel": f"fit_independent_kernel<{name}>",
-                                 "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                                 "frac_of_l2_peak": ach / L2_PEAK_GBPS, "l2_peak": L2_PEAK_GBPS,
-                                 "bytes_counted": "visited (in-kernel counters of this run)",
-                                 "visited_bytes_per_launch": visited, "algorithmic_bytes_per_launch": alg,
-                                 "algorithmic_full_scan_GBps": alg / (kern_3 * 1e-3) / 1e9,
-                                 "traffic": None,
-                                 "traffic_from_profile": ({"tag": pmc.get("tag"), "hbm_bytes_per_launch": hb,
-                                                           "hbm_GBps": hb / (kern_3 * 1e-3) / 1e9 if hb else None,
-                                                           "source": "profiles/pmc_config3.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                                                     "passes of `bench.py --config3-only` — a committed profile, not this run"}
-                                                          if pmc else "HBM traffic not measured in this run and no committed profile"),
-                                 "note": "10 000 wavefronts over 1 024 SIMDs: ten per SIMD, bound by the depth of the dependent-miss "
-                                         "chain and the issue slots (DESIGN.md 9), not by bytes"}}
+        t = (pmc or {}).get(name) or {}
+        insts = sum(t.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")) or None
+        fr, bound, frac = three_fractions(kern_3 * 1e-3, t.get("hbm_bytes"), t.get("l2_request_bytes"), insts)
+        rf = {"kernel": f"fit_independent_kernel<{name}>", "kernel_ms": kern_3, "bound": bound, "frac": frac,
+              "achieved": fr[bound]["achieved"] if bound else None, "peak": fr[bound]["peak"] if bound else None,
+              "unit": fr[bound]["unit"] if bound else None, "fractions": fr,
+              "traffic": t.get("hbm_bytes"),
+              "counters_from": (f"profiles/pmc_config3.json ({pmc.get('tag')}): rocprofv3 --pmc passes of `bench.py --config3-only` — a "
+                                "committed profile, not this run; the kernel time IS this run's") if pmc else None,
+              "wait_fraction": (t["SQ_WAIT_ANY"] / t["SQ_WAVE_CYCLES"]) if t.get("SQ_WAVE_CYCLES") else None,
+              "information_only": {"visited_bytes_per_launch": visited, "visited_GBps": visited / (kern_3 * 1e-3) / 1e9,
+                                   "algorithmic_bytes_per_launch": alg, "algorithmic_full_scan_GBps": alg / (kern_3 * 1e-3) / 1e9,
+                                   "note": "visited = in-kernel counters of this run (mostly served by the L1 / L2: never divided by the "
+                                           "HBM peak); algorithmic = SURVEY.md 8d, which charges the full scan the lazy kernel skips"},
+              "note": "10 000 wavefronts over 1 024 SIMDs: about ten per SIMD; bound by the depth of the dependent-miss chain and the "
+                      "issue slots (DESIGN.md 9), not by bytes"}
+        c3[name] = {"decisions_per_s": len(apps3) * steps / wall_3, "kernel_ms": kern_3, "submission": how3, "roofline": rf}
     return c3
 
 
@@ -434,6 +476,7 @@ def main():
     seq_wall, seq_walls = wall, walls
     worker_info = None
     used_worker = False
+    wkern = []
     if args.worker_sets > 0:
         NOUT = 8
         w_res = [torch.zeros_like(d_res) for _ in range(NOUT)]
@@ -450,6 +493,12 @@ def main():
                 ctx.worker_stop()                       # served, then the worker leaves the device
                 torch.cuda.synchronize()
                 wall_ = time.perf_counter() - t0
+                try:  # HIP events on the worker's own stream around its launch: device time of this window's K tickets
+                    kms, ktk = ctx.worker_kernel_time()
+                    if ktk == args.steps:
+                        wkern.append(kms / ktk)
+                except Exception:
+                    pass
                 barrier()
                 if dist is not None:
                     t = torch.tensor([wall_], dtype=torch.float64, device=dev)
@@ -457,14 +506,16 @@ def main():
                     wall_ = float(t.item())
                 return wall_
 
+            wkern = []
             for _ in range(3):
                 window_worker()
+            del wkern[:]
             wwalls = [window_worker() for _ in range(max(1, args.windows))]
             step(TIGHT)  # the launch path's answer into d_res / d_exec
             torch.cuda.synchronize()
             same = all(bool(torch.equal(w_res[i], d_res)) and bool(torch.equal(w_exec[i], d_exec)) for i in range(min(NOUT, args.steps)))
             worker_info = {"sets": args.worker_sets, "window_ms": [x * 1e3 for x in wwalls], "answers_equal_launch_path": same,
-                           "stats": ctx.worker_stats()}
+                           "kernel_ms_per_ticket": _median(wkern) if wkern else None, "stats": ctx.worker_stats()}
             if dist is not None:
                 okf = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
                 dist.all_reduce(okf, op=dist.ReduceOp.MIN)
@@ -475,7 +526,7 @@ def main():
             worker_info = {"error": f"{type(e).__name__}: {e}"}
     decisions_per_s = world * len(apps) * args.steps / wall
 
-    # ---- roofline of the dominant kernel
+    # ---- roofline of the kernel behind `value` (and, beside it, of the other regime's kernel)
     alg_bytes = wl.algorithmic_bytes(len(s.exec_order), w.k)  # full scan of the executor order per decision
     ctx.scan_stats(enable=True, reset=True)
     step(TIGHT)
@@ -484,6 +535,15 @@ def main():
     # what the lazy scan touches: 24 B per executor slot evaluated, 28 B per driver position (24 B + its 4-byte node id),
     # the 64-byte app record + 16-byte result + 8 B of index words, 4 B per placement written
     visited_bytes = xvis * 24 + dvis * 28 + len(apps) * 88 + 4 * int(w.k.sum())
+    visited_worker = None
+    if used_worker:
+        try:  # the same counters inside the worker: one window of K tickets, per ticket
+            ctx.scan_stats(enable=True, reset=True)
+            window_worker()
+            xw, dw = ctx.scan_stats(enable=False, reset=True)
+            visited_worker = (xw * 24 + dw * 28) / args.steps + len(apps) * 88 + 4 * int(w.k.sum())
+        except Exception:
+            visited_worker = None
     try:
         floor_us = ctx.launch_floor(stream, 400)
     except Exception:
@@ -492,16 +552,6 @@ def main():
         read_peak, copy_peak = ctx.hbm_probe(2 << 30, 10)
     except Exception:
         read_peak = copy_peak = None
-    traffic_prof = None
-    pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            pj = json.load(open(pmc_path))
-            traffic_prof = {"tag": pj.get("tag"), "hbm_bytes_per_launch": pj.get("fit_independent_tight_headline_bytes_per_launch"),
-                            "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                      "(separate passes, gfx950 FETCH_SIZE x2 correction) — a committed profile, not this run"}
-        except Exception:
-            traffic_prof = None
     # one launch at a time between its own pair of events on an idle stream: what a LONE batch costs (the launch is not
     # overlapped with a predecessor).  kern_ms above — the K-step window divided by K — is what rocprofv3's average dispatch
     # duration agrees with (profiles/<tag>_summary.md, headline-only table).
@@ -511,30 +561,67 @@ def main():
         step(TIGHT)
         singles.append(ctx.timer_end())
     isolated_launch_ms = _median(singles[10:])
-    achieved = visited_bytes / (kern_ms * 1e-3) / 1e9
-    roofline = {
-        "bound": "latency", "nominal_bound": "hbm",
-        "kernel": "fit_independent_kernel<tightly-pack>", "kernel_ms": kern_ms,
-        "isolated_launch_ms": isolated_launch_ms,
-        "kernel_ms_note": "kernel_ms = HIP events around a K-step window / K: what a batch costs in a stream of batches, and what "
-                          "the rocprofv3 average dispatch duration in profiles/ agrees with; isolated_launch_ms = events around one "
-                          "launch on an idle stream (a lone batch also pays the un-overlapped launch)",
-        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-        "bytes_counted": "visited (in-kernel counters of this run): the scan is lazy like the reference's loop",
-        "visited_bytes_per_launch": visited_bytes,
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_full_scan_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
-        "traffic": None,
-        "traffic_note": (f"HBM traffic: from profile {traffic_prof['tag']} (rocprofv3 PMC passes of this command, committed under "
-                         "profiles/), not measured in this run" if traffic_prof else "HBM traffic not measured in this run"),
-        "traffic_from_profile": traffic_prof,
-        "launch_floor_us": floor_us,
-        "frac_of_launch_floor": (floor_us / (kern_ms * 1e3)) if floor_us else None,
-        "measured_read_stream_GBps": read_peak, "measured_copy_GBps": copy_peak,
-        "note": "10 000 nodes x 24 B = 240 KB of table: cache resident after first touch, so neither the visited nor the HBM "
-                "bytes come near the bandwidth roof; one launch is ~1 000 wavefronts on 1 024 SIMDs, each a short chain of "
-                "dependent L2/HBM round trips (DESIGN.md 4.1).  frac_of_launch_floor = empty-kernel launch / this kernel.",
-    }
+    prof = load_profile("pmc_headline.json") or {}
+
+    def kernel_roofline(kernel, regime, kernel_ms_step, how, per_step, visited):
+        """per_step: the profile's counters of one step of this kernel ({hbm_bytes, l2_request_bytes, instructions, ...}) or None."""
+        ps = per_step or {}
+        fr, bound, frac = three_fractions(kernel_ms_step * 1e-3, ps.get("hbm_bytes"), ps.get("l2_request_bytes"), ps.get("instructions"))
+        return {"kernel": kernel, "regime": regime, "kernel_ms": kernel_ms_step, "kernel_ms_is": how,
+                "bound": bound, "frac": frac,
+                "achieved": fr[bound]["achieved"] if bound else None, "peak": fr[bound]["peak"] if bound else None,
+                "unit": fr[bound]["unit"] if bound else None, "fractions": fr,
+                "traffic": ps.get("hbm_bytes"),
+                "counters_from": (f"profiles/pmc_headline.json ({prof.get('tag')}): separate rocprofv3 --pmc passes of this command "
+                                  "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; TCC_HIT + TCC_MISS x 128 B; SQ_INSTS_*), per step — a "
+                                  "committed profile, not this run; the kernel time IS this run's") if per_step else
+                                 "no committed counter profile of this kernel: fractions unmeasured",
+                "wait_fraction": ps.get("wait_fraction"),
+                "information_only": {
+                    "visited_bytes_per_step": visited, "visited_GBps": (visited / (kernel_ms_step * 1e-3) / 1e9) if visited else None,
+                    "algorithmic_bytes_per_step": alg_bytes, "algorithmic_full_scan_GBps": alg_bytes / (kernel_ms_step * 1e-3) / 1e9,
+                    "note": "visited = in-kernel counters of this run (the scan is lazy like the reference's loop; the 240 KB table is "
+                            "cache resident, so these bytes are mostly L1 / L2 hits and are never divided by the HBM peak); "
+                            "algorithmic = SURVEY.md 8d's full-scan formula, which charges bytes nobody reads"}}
+
+    launch_rf = kernel_roofline("fit_independent_kernel<tightly-pack>", "launch_per_batch", kern_ms,
+                                "HIP events on the launch stream around a K-step window / K (what rocprofv3's average dispatch "
+                                "duration agrees with)", prof.get("launch_path"), visited_bytes)
+    worker_rf = None
+    if worker_info and "error" not in worker_info:
+        wk_ms = worker_info.get("kernel_ms_per_ticket") or (_median(worker_info["window_ms"]) / args.steps)
+        worker_rf = kernel_roofline("fit_worker_kernel<tightly-pack>", "streamed_tickets", wk_ms,
+                                    "HIP events on the worker's stream around its ONE dispatch per window / the K tickets it served "
+                                    "(gf_worker_kernel_time)" if worker_info.get("kernel_ms_per_ticket") else
+                                    "window wall time / K (the worker's events were not available)",
+                                    prof.get("worker"), visited_worker)
+        worker_rf["issue_note"] = ("the worker's instruction count includes the polling of 3 x 64 workgroups that wait for their next "
+                                   "ticket: issue slots taken, not decisions made")
+    roofline = dict(worker_rf if used_worker else launch_rf)
+    roofline["other_regime"] = launch_rf if used_worker else worker_rf
+    e2e_ref = {}
+    roofline["regimes"] = {
+        "streamed_tickets": ({"value": world * len(apps) * args.steps / _median(worker_info["window_ms"]) * 1e3,
+                              "ms_per_step": _median(worker_info["window_ms"]) / args.steps, "kernel": "fit_worker_kernel<tightly-pack>",
+                              "kernel_ms": worker_rf["kernel_ms"], "batches_in_flight": args.worker_sets,
+                              "what": "K tickets per window through the resident worker, its launch and departure inside the window"}
+                             if worker_rf else None),
+        "launch_per_batch": {"value": world * len(apps) * args.steps / seq_wall, "ms_per_step": seq_wall / args.steps * 1e3,
+                             "kernel": "fit_independent_kernel<tightly-pack>", "kernel_ms": kern_ms,
+                             "isolated_launch_ms": isolated_launch_ms,
+                             "what": "K launches on one stream, recorded as one graph (rounds 1-2 reported this as value); "
+                                     "isolated_launch_ms = events around ONE launch on an idle stream"},
+        "blocking_call": e2e_ref,  # filled below (end_to_end): one gf_fit_batch call with host memory in and out
+        "value_is": "streamed_tickets" if used_worker else "launch_per_batch",
+        "reference_call_site": "the reference's only independent-batch consumer (unschedulablepods.go:77-129) issues ONE batch per "
+                               "minute: it sees `blocking_call`, not the streamed rate"}
+    roofline["launch_floor_us"] = floor_us
+    roofline["frac_of_launch_floor"] = (floor_us / (kern_ms * 1e3)) if floor_us else None
+    roofline["measured_read_stream_GBps"] = read_peak
+    roofline["measured_copy_GBps"] = copy_peak
+    roofline["note"] = ("10 000 nodes x 24 B = 240 KB of table: cache resident after first touch, so no byte count comes near a "
+                        "bandwidth roof; a batch is ~1 000 wavefronts on 1 024 SIMDs, each a short chain of dependent L2 / HBM round "
+                        "trips (DESIGN.md 4.1).  frac_of_launch_floor = empty-kernel launch / the launch path's kernel.")
 
     out = {
         "metric": "gang-fit decisions/sec at 10k nodes x 1k pending apps (+ p99 Filter latency: fifo_filter)",
@@ -553,6 +640,7 @@ def main():
                                "3-D (cpu milli, mem bytes, gpu) int64, SURVEY.md 8d/C2 distributions, seed 0x5EED0010",
                    "nodes": args.nodes, "apps_per_gpu": args.apps, "algo": "tightly-pack", "mode": "independent",
                    "batches_in_flight": args.worker_sets if used_worker else 1,
+                   "regime": "streamed_tickets (resident worker)" if used_worker else "launch_per_batch (one graph of K launches)",
                    "sharding": "pending apps across ranks, node table replicated, no collective"},
         "timing": {"windows": len(walls), "steps_per_window": args.steps, "statistic": "median of the windows (max over ranks each)",
                    "submission": ("resident worker: K tickets per window, one doorbell; the worker's launch and its departure are "
@@ -672,6 +760,12 @@ def main():
                 "entry_point": "gf_fit_batch: app records in host memory in, results + placements in host memory out (64 KB + ~64 KB "
                                "per batch, read / written by the kernel through pinned staging buffers), snapshot resident; blocking",
                 "windows": len(e2e_walls), "results_equal_device_resident_path": bool(np.array_equal(hres, dres)) if rank == 0 and world == 1 else None}
+            wkd = wk if isinstance(wk, dict) and "error" not in wk else {}
+            e2e_ref.update({"entry_point": "gf_fit_batch (host memory in / out, blocking), one call after the other",
+                            "us_per_call": (wkd.get("gf_fit_batch_ms_per_batch_same_protocol") or e2e_wall / e2e_steps * 1e3) * 1e3,
+                            "value": len(happs) / ((wkd.get("gf_fit_batch_ms_per_batch_same_protocol") or e2e_wall / e2e_steps * 1e3) * 1e-3),
+                            "through_gf_worker_fit_us_per_call": (wkd.get("ms_per_batch") * 1e3) if wkd.get("ms_per_batch") else None,
+                            "one_application_per_call_us": wkd.get("one_application_per_call_us")})
         except Exception as e:
             out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
         # ---- the latency half of the metric: FIFO Filter = chain of (apps-1) earlier drivers + the filtered one.
@@ -748,30 +842,36 @@ def main():
                 ctx.scan_stats(enable=False, reset=False)
                 ctx.set_option("chain_cache", 1)
                 cyc, ticks = ctx.last_fifo_clock
-            pmc = None
-            pmc_path2 = os.path.join(REPO, "profiles", "pmc_chain.json")
-            if os.path.exists(pmc_path2):
-                try:
-                    pmc = json.load(open(pmc_path2))
-                except Exception:
-                    pmc = None
+            pmc = load_profile("pmc_chain.json")
             instr_per_app = (pmc or {}).get("fit_fifo_solo_instructions_per_app")
             cyc_per_app = cyc / n_q if cyc else None
+            clock_ghz = (cyc / (ticks * 10.0)) if ticks else CLOCK_GHZ
             ISSUE = 4.3  # cycles between two instructions of a lone wavefront (tools/micro/probe_issue.hip)
+            # the same three fractions as everywhere, per chain, over the kernel's own duration (in-kernel clock of this run):
+            # ONE SIMD's issue slots — fifteen of the sixteen wavefronts sleep at a barrier while wavefront 0 walks the chain
+            chain_s = (cyc / (clock_ghz * 1e9)) if cyc else None
+            cfr, cbound, cfrac = ({}, None, None)
+            if chain_s:
+                cfr, cbound, cfrac = three_fractions(chain_s, (pmc or {}).get("hbm_bytes_per_chain"), (pmc or {}).get("l2_request_bytes_per_chain"),
+                                                     instr_per_app * n_q if instr_per_app else None, simds=1)
             roofline["fifo_chain"] = {
-                "kernel": "fit_fifo_solo_kernel<tightly-pack>", "bound": "issue",
-                "why": "one controlling wavefront (the chain is sequential in the applications, resource.go:224-262): bound by its "
-                       "instruction count x the 4.3-cycle issue interval of a lone wavefront, not by bytes",
+                "kernel": "fit_fifo_solo_kernel<tightly-pack>", "bound": cbound, "frac": cfrac, "fractions": cfr,
+                "achieved": cfr[cbound]["achieved"] if cbound else None, "peak": cfr[cbound]["peak"] if cbound else None,
+                "unit": cfr[cbound]["unit"] if cbound else None,
+                "traffic": (pmc or {}).get("hbm_bytes_per_chain"),
+                "why": "one controlling wavefront (the chain is sequential in the applications, resource.go:224-262) on one SIMD: its "
+                       "issue fraction is instructions / (1 SIMD x clock x kernel time); a LONE wavefront cannot issue faster than one "
+                       "instruction per ~4.3 cycles, so `lone_wavefront_issue_frac` = instructions x 4.3 / cycles says how much of the "
+                       "chain's time is issue at that rate (the rest: LDS round trips and taken branches)",
+                "lone_wavefront_issue_frac": (instr_per_app * ISSUE / cyc_per_app) if (instr_per_app and cyc_per_app) else None,
                 "filter_p50_ms": ff["p50_ms"], "filter_p99_ms": ff["p99_ms"],
                 "filter_warm_p50_ms": ff["warm_creation_order_heads"]["p50_ms"], "filter_warm_p99_ms": ff["warm_creation_order_heads"]["p99_ms"],
                 "filter_same_head_p50_ms": ff["warm_same_head"]["p50_ms"], "filter_same_head_p99_ms": ff["warm_same_head"]["p99_ms"],
                 "applications_per_chain": n_q, "shader_cycles_per_application": cyc_per_app,
                 "shader_clock_GHz": (cyc / (ticks * 10.0)) if ticks else None,
                 "instructions_per_application": instr_per_app, "issue_cycles_per_instruction": ISSUE,
-                "frac": (instr_per_app * ISSUE / cyc_per_app) if (instr_per_app and cyc_per_app) else None,
-                "frac_is": "instructions x issue interval / measured cycles of the controlling wavefront (1.0 = nothing but issue)",
-                "instructions_from": (f"profiles/pmc_chain.json ({pmc.get('tag')}): rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU "
-                                      "SQ_INSTS_LDS pass of this command — a committed profile, not this run") if pmc else None,
+                "counters_from": (f"profiles/pmc_chain.json ({pmc.get('tag')}): rocprofv3 --pmc passes of `bench.py --no-extras "
+                                  "--fifo-protocols cold` — a committed profile, not this run; cycles ARE this run's") if pmc else None,
             }
             if not args.no_cpu_baseline:
                 ff["cpu_baseline"] = cpu_chain_baseline(0, s.avail, s.sched, None, s.driver_order, s.exec_order, w.drv, w.exe, w.k,
@@ -956,9 +1056,9 @@ def main():
             extras["congested"] = {
                 "workload": wc.name, "feasible_fraction": float(res["has_capacity"].mean()),
                 "decisions_per_s": len(capps) * csteps / wall_c, "kernel_ms": kern_c, "submission": how_c,
-                "achieved_GBps_visited": cvis / (kern_c * 1e-3) / 1e9,
-                "frac_of_hbm_peak_visited": cvis / (kern_c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "algorithmic_full_scan_GBps": cb / (kern_c * 1e-3) / 1e9,
+                "information_only": {"visited_bytes_per_launch": cvis, "visited_GBps": cvis / (kern_c * 1e-3) / 1e9,
+                                     "algorithmic_full_scan_GBps": cb / (kern_c * 1e-3) / 1e9,
+                                     "note": "cache-served / unread bytes: never divided by a peak (no counter pass of this batch)"},
                 "fifo_filter_p50_ms": _percentile(clat, 0.5), "fifo_filter_p99_ms": _percentile(clat, 0.99),
             }
             if not args.no_cpu_baseline:

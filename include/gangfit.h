@@ -476,6 +476,11 @@ int gf_worker_wait(gf_ctx *ctx, uint64_t first_ticket, uint32_t n_tickets);
 int gf_worker_stop(gf_ctx *ctx);
 /* out[0] tickets posted, [1] tickets known complete (a prefix), [2] launches of the worker so far, [3] 1 = resident now */
 int gf_worker_stats(gf_ctx *ctx, uint64_t out[4]);
+/* Measurement helper (bench.py's roofline): HIP events on the worker's own stream around its launch.  *ms = how long the
+ * last FINISHED launch of the worker stayed on the device, *tickets = the tickets it relayed: ms / tickets is the device
+ * time per 1 000-application batch in a stream of batches.  GF_ERR_STATE while no launch has finished (gf_worker_stop
+ * makes the resident one leave).  Nothing in the reference corresponds to it. */
+int gf_worker_kernel_time(gf_ctx *ctx, float *ms, uint64_t *tickets);
 
 /* Device properties the host uses to size launches (also lets a caller verify it is talking to a gfx950). */
 typedef struct gf_device_info {

@@ -201,6 +201,12 @@ struct gf_ctx {
         uint32_t blocks_per_set = 64;  // x 16 wavefronts
         uint32_t idle_us = 200;
         uint64_t launches = 0;
+        // HIP events on the worker's stream around its launch: how long the last finished launch stayed on the device and how
+        // many tickets it served (gf_worker_kernel_time: the per-ticket kernel time of bench.py's roofline)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        uint64_t launch_first = 0;     // first ticket of the launch on the device (or of the last one)
+        float last_ms = 0.0f;          // duration of the last finished launch
+        uint64_t last_tickets = 0;     // tickets it relayed
         // staging of gf_worker_fit: one pinned (coherent, device-mapped) slice per ring slot
         void* stage = nullptr;
         void* stage_dev = nullptr;
@@ -1417,6 +1423,8 @@ void gf_destroy(gf_ctx* ctx) {
         if (ctx->worker.stage) (void)hipHostFree(ctx->worker.stage);
         if (ctx->worker.d) (void)hipFree(ctx->worker.d);
         if (ctx->worker.h) (void)hipHostFree(ctx->worker.h);
+        if (ctx->worker.ev0) (void)hipEventDestroy(ctx->worker.ev0);
+        if (ctx->worker.ev1) (void)hipEventDestroy(ctx->worker.ev1);
         if (ctx->worker.stream) (void)hipStreamDestroy(ctx->worker.stream);
     }
     if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
@@ -2260,12 +2268,25 @@ int worker_alloc(gf_ctx* ctx) {
     w.h_dev = static_cast<gangfit::WorkerHostCtl*>(hd);
     w.d = static_cast<gangfit::WorkerDevCtl*>(dp);
     w.stream = st;
+    (void)hipEventCreate(&w.ev0);
+    (void)hipEventCreate(&w.ev1);
     w.allocated = true;
     return GF_OK;
 }
 
 void worker_advance(gf_ctx::Worker& w);
 int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket);
+
+// The launch has left the device (its stream is idle): duration between the two events around it, tickets it relayed.
+void worker_finished(gf_ctx::Worker& w) {
+    float ms = 0.0f;
+    if (w.ev0 && w.ev1 && hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess) {
+        const uint64_t consumed = host_load(&w.h->consumed);
+        w.last_ms = ms;
+        w.last_tickets = consumed > w.launch_first ? consumed - w.launch_first : 0;
+    }
+    (void)hipGetLastError();
+}
 
 // Makes the launch on the device (if any) leave once it has relayed and served every ticket posted so far, and waits for that.
 // The leader may have idled out (or been stopped by worker_wait_ticket's 5 s limit) just as the last tickets were posted: it
@@ -2282,6 +2303,7 @@ int worker_join(gf_ctx* ctx) {
         host_store(&w.h->stop, 0);
         w.running = false;
         if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "the worker did not leave the device: %s", hipGetErrorString(e));
+        worker_finished(w);
         worker_advance(w);
         if (w.completed_upto == w.posted) return GF_OK;
         const uint64_t consumed = host_load(&w.h->consumed);
@@ -2326,7 +2348,11 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     }
     a.sets = sets;
     a.blocks_per_set = w.blocks_per_set;
+    a.stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
+    w.launch_first = first_ticket;
+    if (w.ev0) (void)hipEventRecord(w.ev0, w.stream);
     GF_HIP(ctx, gangfit::launch_fit_worker(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), a, w.stream));
+    if (w.ev1) (void)hipEventRecord(w.ev1, w.stream);
     w.running = true;
     w.algo = (int)algo;
     w.epoch = ctx->snap_epoch;
@@ -2348,6 +2374,7 @@ int worker_revive(gf_ctx* ctx) {
         GF_HIP(ctx, hipSetDevice(ctx->device));
         GF_HIP(ctx, gf_wait_stream(w.stream));
         w.running = false;
+        worker_finished(w);
     }
     // not on the device: whatever was posted behind the last ticket the leader relayed needs a launch
     const uint64_t consumed = host_load(&w.h->consumed);
@@ -2572,6 +2599,17 @@ int gf_worker_stats(gf_ctx* ctx, uint64_t out[4]) {
     out[1] = w.completed_upto;
     out[2] = w.launches;
     out[3] = (w.allocated && w.running && host_load(&w.h->state) != 2) ? 1 : 0;
+    return GF_OK;
+}
+
+int gf_worker_kernel_time(gf_ctx* ctx, float* ms, uint64_t* tickets) {
+    if (!ctx || !ms || !tickets) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    const gf_ctx::Worker& w = ctx->worker;
+    if (!w.allocated || w.launches == 0 || (w.running && w.launches == 1))
+        return fail(ctx, GF_ERR_STATE, "no launch of the worker has finished yet (gf_worker_stop first)");
+    *ms = w.last_ms;
+    *tickets = w.last_tickets;
     return GF_OK;
 }
 

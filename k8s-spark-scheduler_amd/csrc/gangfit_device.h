@@ -159,6 +159,7 @@ struct WorkerArgs {
     unsigned long long scratch_stride;
     uint32_t sets;
     uint32_t blocks_per_set;
+    ScanStats* stats;  // nullable: slots visited, summed over every decision of the launch (gf_scan_stats)
 };
 
 hipError_t worker_blocks_per_cu(gf_algo algo, int* out);

@@ -1024,15 +1024,61 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // ------------------------------------------------------------------------------------------------ independent batch
 
 // One wave per app, 4 apps per workgroup.  Grid = ceil(n_apps / 4) >> 256 CUs at the target sizes.
-template <int ALGO>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
+#ifndef GF_IND_PAIR_FROM
+#define GF_IND_PAIR_FROM 7168  // batches of at least this many applications run two per wavefront (0: never)
+#endif
+#ifndef GF_IND_PAIR_UNROLL
+#define GF_IND_PAIR_UNROLL 0  // experiment switch: 1 = two inlined copies of the decision instead of a two-trip loop
+#endif
+#ifndef GF_IND_WAVES_PER_EU
+#define GF_IND_WAVES_PER_EU 0  // experiment switch: > 0 asks the compiler for that many wavefronts per SIMD (VGPR and SGPR budget)
+#endif
+#if GF_IND_WAVES_PER_EU == 96
+#define GF_IND_OCC __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(64)))
+#elif GF_IND_WAVES_PER_EU > 0
+#define GF_IND_OCC __attribute__((amdgpu_waves_per_eu(GF_IND_WAVES_PER_EU, GF_IND_WAVES_PER_EU)))
+#else
+#define GF_IND_OCC
+#endif
+// A gf_app as eight 8-byte words in lanes 0..7 of one VGPR pair (a vector load: it can stay in flight, and later parked, while
+// another application is decided), and its fields handed out to the scalar side when its turn comes.
+__device__ __forceinline__ unsigned long long load_app_words(const gf_app* __restrict__ apps, uint32_t a, int lane) {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(apps + a);
+    return lane < 8 ? p[lane] : 0ull;
+}
+__device__ __forceinline__ App app_from_words(unsigned long long w) {
+    App r;
+    r.drv0 = (int64_t)read_lane((int64_t)w, 0);
+    r.drv1 = (int64_t)read_lane((int64_t)w, 1);
+    r.drv2 = (int64_t)read_lane((int64_t)w, 2);
+    r.exe0 = (int64_t)read_lane((int64_t)w, 3);
+    r.exe1 = (int64_t)read_lane((int64_t)w, 4);
+    r.exe2 = (int64_t)read_lane((int64_t)w, 5);
+    const uint64_t kf = (uint64_t)read_lane((int64_t)w, 6);
+    r.k = (int32_t)(uint32_t)kf;
+    r.flags = (uint32_t)(kf >> 32);
+    r.exec_off = (uint64_t)read_lane((int64_t)w, 7);
+    r.rcp0 = r.exe0 > 0 ? fast_rcp((double)r.exe0) : 0.0;
+    r.rcp1 = r.exe1 > 0 ? fast_rcp((double)r.exe1) : 0.0;
+    r.rcp2 = r.exe2 > 0 ? fast_rcp((double)r.exe2) : 0.0;
+    return r;
+}
+
+// One wavefront per application, four wavefronts per workgroup — or, for batches that would otherwise need more than one
+// round of wavefronts on the device (APW = 2, launch_fit_independent): two applications per wavefront, a and a + n_waves, one
+// after the other.  Group 0 of the chunk index does not depend on the application and both records are requested together
+// (the second one parked in lanes 0..7 of a VGPR pair while the first is decided): the second decision starts one round trip
+// into its chain, and 10 000 applications are 5 000 wavefronts — all resident at once at seven per SIMD — instead of 1.4 rounds.
+template <int ALGO, int APW>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independent_kernel(
     NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
     uint32_t* __restrict__ exec_nodes, uint32_t* __restrict__ scratch, uint64_t scratch_half,
     ScanStats* __restrict__ stats) {
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
-    if (a >= n_apps) return;
+    const uint32_t n_waves = APW == 1 ? n_apps : (n_apps + 1u) / 2u;
+    if (a >= n_waves) return;
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
@@ -1041,23 +1087,47 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void fit_independent_kernel(
     //      ignores the values, the buffers exist in both layouts)
     const Group0 g0 = load_group0(V, O, lane);
     const bool merged = T.d_identity != 0 && ALGO != GF_ALGO_MINIMAL_FRAGMENTATION;
-    const App app = load_app(apps, a);
     unsigned long long xvis = 0, dvis = 0;
-    Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
-                                                        scratch + scratch_half + app.exec_off, lane, xvis, dvis,
-                                                        merged ? &g0 : nullptr, &G);
-    if (lane == 0) {
-        gf_result r;
-        r.has_capacity = dec.feasible ? 1 : 0;
-        if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
-        r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
-        r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
-        r.evaluated = 1;
-        results[a] = r;
-        if (stats != nullptr) {
-            atomicAdd(&stats->exec_slots_visited, xvis);
-            atomicAdd(&stats->driver_slots_visited, dvis);
+    auto decide = [&](const App& app, uint32_t ai) {
+        Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
+                                                            scratch + scratch_half + app.exec_off, lane, xvis, dvis,
+                                                            merged ? &g0 : nullptr, &G);
+        if (lane == 0) {
+            gf_result r;
+            r.has_capacity = dec.feasible ? 1 : 0;
+            if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
+            r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
+            r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
+            r.evaluated = 1;
+            results[ai] = r;
         }
+    };
+    if (APW == 1) {
+        decide(load_app(apps, a), a);
+    } else {
+        const uint32_t b = a + n_waves;  // (wave-uniform) the second application of this wavefront
+        const unsigned long long wa = load_app_words(apps, a, lane);
+        const unsigned long long wb = b < n_apps ? load_app_words(apps, b, lane) : 0ull;
+#if GF_IND_PAIR_UNROLL
+        decide(app_from_words(wa), a);
+        if (b < n_apps) decide(app_from_words(wb), b);
+#else
+        unsigned long long w = wa;
+        uint32_t ai = a;
+#pragma nounroll
+        for (int i = 0; i < 2; ++i) {  // ONE copy of the decision in the code (the instruction cache is shared by the CU's wavefronts)
+            if (i == 1) {
+                if (b >= n_apps) break;
+                w = wb;
+                ai = b;
+            }
+            decide(app_from_words(w), ai);
+        }
+#endif
+    }
+    if (stats != nullptr && lane == 0) {
+        atomicAdd(&stats->exec_slots_visited, xvis);
+        atomicAdd(&stats->driver_slots_visited, dvis);
     }
 }
 
@@ -1628,16 +1698,26 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
-    const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+    // two applications per wavefront once one per wavefront would need more than a round of the device (1 024 SIMDs x 7)
+    const bool pair = GF_IND_PAIR_FROM != 0 && n_apps >= (uint32_t)GF_IND_PAIR_FROM;
+    const uint32_t n_waves = pair ? (n_apps + 1u) / 2u : n_apps;
+    const dim3 grid((n_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+#define GF_IND(ALGO)                                                                                                          \
+    do {                                                                                                                      \
+        if (pair)                                                                                                             \
+            hipLaunchKernelGGL((fit_independent_kernel<ALGO, 2>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,      \
+                               d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);                                    \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((fit_independent_kernel<ALGO, 1>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,      \
+                               d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);                                    \
+    } while (0)
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_TIGHTLY_PACK>, grid, block, 0, stream, table, gpu_view, n_apps,
-                           d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
+        GF_IND(GF_ALGO_TIGHTLY_PACK);
     else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
-        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_MINIMAL_FRAGMENTATION>, grid, block, 0, stream, table, gpu_view,
-                           n_apps, d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
+        GF_IND(GF_ALGO_MINIMAL_FRAGMENTATION);
     else
-        hipLaunchKernelGGL(fit_independent_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, grid, block, 0, stream, table, gpu_view, n_apps,
-                           d_apps, d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);
+        GF_IND(GF_ALGO_DISTRIBUTE_EVENLY);
+#undef GF_IND
     return hipGetLastError();
 }
 

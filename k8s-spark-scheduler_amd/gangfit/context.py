@@ -379,6 +379,12 @@ class Context:
         self._check(self._lib.gf_worker_stats(self._h, out))
         return {"posted": int(out[0]), "complete": int(out[1]), "launches": int(out[2]), "resident": bool(out[3])}
 
+    def worker_kernel_time(self):
+        """(ms on the device, tickets relayed) of the worker's last finished launch — HIP events on the worker's stream."""
+        ms, n = C.c_float(), C.c_uint64()
+        self._check(self._lib.gf_worker_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     # -- replayable launch sequences (gf_graph_*)
     def graph_begin(self, stream: int = 0):
         self._check(self._lib.gf_graph_begin(self._h, C.c_void_p(stream) if stream else None))

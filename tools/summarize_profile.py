@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """Turn the rocprofv3 CSVs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the tracked summaries under profiles/:
-  profiles/<tag>_kernel_stats.csv   — rocprofv3 --kernel-trace --stats summary (verbatim)
-  profiles/<tag>_pmc.csv            — per-kernel averages of every PMC pass (one counter set per pass)
-  profiles/<tag>_summary.md         — both, human readable, with the gfx950 FETCH_SIZE correction applied
-  profiles/pmc_traffic.json         — HBM bytes per launch of the dominant kernels (read by bench.py -> roofline.traffic)
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for
-wide coalesced reads (MI355X_MICROARCH.md, HBM section), so read bytes = 2 x FETCH_SIZE x 1024 is the upper estimate
-and 1 x the lower one; both are recorded, `traffic` uses the corrected (2x) figure.
+  profiles/<tag>_kernel_stats*.csv  — rocprofv3 --kernel-trace --stats summaries (verbatim; one per profiled command)
+  profiles/<tag>_pmc.csv            — per-kernel means of every PMC pass (one counter set per pass)
+  profiles/<tag>_summary.md         — all of it, human readable
+  profiles/pmc_headline.json        — per STEP counters of the two kernels behind bench.py's headline: one dispatch of
+                                      fit_independent_kernel = one step; one dispatch of fit_worker_kernel = K tickets = K steps
+  profiles/pmc_chain.json           — per chain counters of fit_fifo_solo_kernel (every launch replays the headline chain)
+  profiles/pmc_config3.json         — per launch counters of BASELINE config 3, per packer
+bench.py reads the three JSON files for its roofline objects (`fractions`, `traffic`).
+
+Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950
+FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024 (the upper
+estimate; the raw figure is recorded next to it); hbm_bytes = 2 x fetch + write.  L2 request bytes = (TCC_HIT_sum +
+TCC_MISS_sum) x 128.  instructions = SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS + SQ_INSTS_SMEM (all wavefronts).
 """
 import collections
 import csv
@@ -16,99 +22,13 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = ("fetch", "write", "l2", "sq")
+INST = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
-    src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
-    dst = os.path.join(REPO, "profiles")
-    os.makedirs(dst, exist_ok=True)
-    stats = os.path.join(src, "stats", "stats_kernel_stats.csv")
-    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    krows = list(csv.DictReader(open(stats)))
-    pmc = collections.OrderedDict()
-    for d in sorted(os.listdir(src)):
-        f = os.path.join(src, d, "pmc_counter_collection.csv")
-        if not os.path.exists(f) or not d.startswith("pmc_"):  # chain_* / c3_* passes: separate commands, summarised below
-            continue
-        for r in csv.DictReader(open(f)):
-            key = (r["Kernel_Name"], r["Counter_Name"])
-            pmc.setdefault(key, []).append(float(r["Counter_Value"]))
-        meta = {(r["Kernel_Name"]): (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],
-                                     r["SGPR_Count"]) for r in csv.DictReader(open(f))}
-        pmc.setdefault("_meta", {}).update(meta)
-    meta = pmc.pop("_meta", {})
-    with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as out:
-        w = csv.writer(out)
-        w.writerow(["kernel", "counter", "launches", "mean", "min", "max"])
-        for (k, c), v in pmc.items():
-            w.writerow([k, c, len(v), f"{sum(v) / len(v):.3f}", f"{min(v):.3f}", f"{max(v):.3f}"])
-    traffic = {}
-    for (k, c), v in pmc.items():
-        if c in ("FETCH_SIZE", "WRITE_SIZE"):
-            traffic.setdefault(k, {})[c] = sum(v) / len(v)
-    tj = {"tag": tag, "note": "bytes per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB"}
-    for k, t in traffic.items():
-        if "fit_" not in k:
-            continue
-        rd, wr = t.get("FETCH_SIZE", 0.0) * 1024, t.get("WRITE_SIZE", 0.0) * 1024
-        tj[k] = {"fetch_bytes_raw": rd, "fetch_bytes_corrected": 2 * rd, "write_bytes": wr, "hbm_bytes": 2 * rd + wr}
-    if "fit_independent_kernel" in tj:
-        tj["fit_independent_tight_headline_bytes_per_launch"] = tj["fit_independent_kernel"]["hbm_bytes"]
-    json.dump(tj, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-    with open(os.path.join(dst, f"{tag}_summary.md"), "w") as out:
-        out.write(f"# rocprofv3 summary — {tag}\n\nCommand: `tools/profile_round.sh {tag}` on one MI355X (gfx950), "
-                  "i.e. `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30 "
-                  "--no-cpu-baseline --worker-sets 0` (the launch path: every batch a dispatch row), the same with `--headline-only`, and one `--pmc` pass per counter set (FETCH_SIZE, "
-                  "WRITE_SIZE and the L2 pair on the headline alone; the SQ and LDS sets on the full run so that the FIFO chain "
-                  "kernels are covered).\n\n")
-        hstats = os.path.join(src, "stats_headline", "stats_kernel_stats.csv")
-        if os.path.exists(hstats):
-            shutil.copy(hstats, os.path.join(dst, f"{tag}_kernel_stats_headline.csv"))
-            out.write("## the headline alone (`--headline-only`: every dispatch of fit_independent_kernel is a headline launch)\n\n")
-            out.write("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
-            for r in csv.DictReader(open(hstats)):
-                if "fit_independent" in r["Name"] or "empty_kernel" in r["Name"]:
-                    out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
-            out.write("\n")
-        wstats = os.path.join(src, "stats_worker", "stats_kernel_stats.csv")
-        if os.path.exists(wstats):
-            shutil.copy(wstats, os.path.join(dst, f"{tag}_kernel_stats_worker.csv"))
-            wj = _bench_json(os.path.join(src, "stats_worker.log"))
-            out.write("## the headline through the resident worker (`bench.py --steps 200 --headline-only`, worker on)\n\n"
-                      "One dispatch of `fit_worker_kernel` per window (it serves the window's 200 tickets and leaves); the "
-                      "launch-path windows of the same run appear as `fit_independent_kernel` rows.\n\n")
-            out.write("| kernel | calls | avg ns | min ns | max ns |\n|---|---|---|---|---|\n")
-            for r in csv.DictReader(open(wstats)):
-                if "fit_worker" in r["Name"] or "fit_independent" in r["Name"]:
-                    out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} |\n")
-            if wj:
-                out.write(f"\nbench line of that run: value {wj.get('value', 0) / 1e6:.1f} M decisions/s, "
-                          f"{wj.get('ms_per_step', 0) * 1e3:.2f} us per step; launch path "
-                          f"{wj.get('timing', {}).get('launch_path', {}).get('value', 0) / 1e6:.1f} M/s\n")
-            out.write("\n")
-        out.write("## kernel stats (all kernels of the full bench run)\n\n")
-        out.write("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
-        for r in krows:
-            out.write(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | "
-                      f"{float(r['Percentage']):.3f} |\n")
-        out.write("\nNote: in the full run `fit_independent_kernel` covers every launch (tightly-pack, distribute-evenly, "
-                  "nominal and congested batches, config 3 and 4, the host-entry batches that read their records over PCIe); the "
-                  "headline-only table above isolates the headline launches.  FETCH_SIZE / WRITE_SIZE / TCC passes ran "
-                  "`--headline-only`; the SQ / LDS passes ran the full bench (means over all launches of a kernel).\n\n"
-                  "## PMC passes (mean per launch)\n\n")
-        out.write("| kernel | counter | launches | mean | min | max |\n|---|---|---|---|---|---|\n")
-        for (k, c), v in pmc.items():
-            if "fit_" not in k and "translate" not in k:
-                continue
-            out.write(f"| {k} | {c} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} |\n")
-        out.write("\nKernel resources (grid, workgroup, LDS, VGPR, SGPR): " +
-                  "; ".join(f"{k}: {v}" for k, v in meta.items() if "fit_" in k) + "\n\n")
-        out.write("## HBM traffic per launch\n\n```json\n" + json.dumps(tj, indent=1) + "\n```\n")
-    extra = chain_and_config3(tag, src, dst)
-    with open(os.path.join(dst, f"{tag}_summary.md"), "a") as out:
-        out.write(extra)
-    print(open(os.path.join(dst, f"{tag}_summary.md")).read())
+def _rows(src, d):
+    f = os.path.join(src, d, "pmc_counter_collection.csv")
+    return list(csv.DictReader(open(f))) if os.path.exists(f) else []
 
 
 def _bench_json(log):
@@ -124,74 +44,188 @@ def _bench_json(log):
     return None
 
 
-def _pass(src, d):
-    f = os.path.join(src, d, "pmc_counter_collection.csv")
-    return list(csv.DictReader(open(f))) if os.path.exists(f) else []
+def _group_means(src, pre):
+    """{kernel: {counter: [values per dispatch]}} over the four counter passes of one profiled command."""
+    per = collections.OrderedDict()
+    for p in PASSES:
+        for r in _rows(src, f"{pre}_{p}"):
+            per.setdefault(r["Kernel_Name"], collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return per
 
 
-def chain_and_config3(tag, src, dst):
-    """profiles/pmc_chain.json (instructions per application of the plain FIFO chain: `--fifo-protocols cold`, every launch a
-    full replay of the headline chain) and profiles/pmc_config3.json (HBM bytes / L2 requests per config-3 launch, per packer),
-    plus their sections of the summary."""
-    md = ""
-    # ---- the chain
-    rows = [r for r in _pass(src, "chain_sq") if r["Kernel_Name"].startswith("fit_fifo_solo_kernel")]
-    if rows:
-        per = collections.OrderedDict()
-        for r in rows:
-            per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        mean = {c: sum(v) / len(v) for c, v in per.items()}
+def _derive(mean, div=1.0):
+    """Per-step figures from a kernel's mean counters per dispatch (div = steps per dispatch)."""
+    out = {k: v / div for k, v in mean.items()}
+    rd, wr = mean.get("FETCH_SIZE"), mean.get("WRITE_SIZE")
+    if rd is not None and wr is not None:
+        out["fetch_bytes_raw"] = rd * 1024 / div
+        out["write_bytes"] = wr * 1024 / div
+        out["hbm_bytes"] = (2 * rd * 1024 + wr * 1024) / div
+    if "TCC_HIT_sum" in mean and "TCC_MISS_sum" in mean:
+        out["l2_request_bytes"] = 128 * (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"]) / div
+    if any(c in mean for c in INST):
+        out["instructions"] = sum(mean.get(c, 0.0) for c in INST) / div
+    if mean.get("SQ_WAVE_CYCLES"):
+        out["wait_fraction"] = mean.get("SQ_WAIT_ANY", 0.0) / mean["SQ_WAVE_CYCLES"]
+    return out
+
+
+def _stats_table(path, want):
+    md = "| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n"
+    for r in csv.DictReader(open(path)):
+        if want is None or any(w in r["Name"] for w in want):
+            md += (f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | "
+                   f"{float(r['Percentage']):.3f} |\n")
+    return md
+
+
+def _avg_ns(path, name):
+    if not os.path.exists(path):
+        return None, None
+    for r in csv.DictReader(open(path)):
+        if r["Name"].startswith(name):
+            return float(r["AverageNs"]), int(r["Calls"])
+    return None, None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+    src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(REPO, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    md = (f"# rocprofv3 summary — {tag}\n\nRecipe: `tools/profile_round.sh {tag}` on one MI355X (gfx950): per profiled command one "
+          "`rocprofv3 --kernel-trace --stats` run and one `--pmc` run per counter set (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum "
+          "TCC_MISS_sum | the SQ set), never combined with other trace domains.\n\n")
+    pmc_csv = [["command", "kernel", "counter", "dispatches", "mean", "min", "max"]]
+
+    def dump_group(pre, per):
+        for k, cs in per.items():
+            for c, v in cs.items():
+                pmc_csv.append([pre, k, c, len(v), f"{sum(v) / len(v):.3f}", f"{min(v):.3f}", f"{max(v):.3f}"])
+
+    # ---- the headline, both regimes
+    per = _group_means(src, "hl")
+    hstats = os.path.join(src, "hl_stats", "stats_kernel_stats.csv")
+    if per or os.path.exists(hstats):
+        dump_group("headline", per)
+        bj = _bench_json(os.path.join(src, "hl_stats.log")) or {}
+        steps = int(bj.get("steps") or 200)
+        hj = {"tag": tag, "command": "bench.py --headline-only --steps 200 --warmup 5 --windows 3",
+              "note": "per STEP (one 1 000-application batch); hbm_bytes = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB; "
+                      "l2_request_bytes = (TCC_HIT_sum + TCC_MISS_sum) x 128; instructions = SQ_INSTS_VALU + SALU + LDS + SMEM"}
+        if "fit_independent_kernel" in per:
+            mean = {c: sum(v) / len(v) for c, v in per["fit_independent_kernel"].items()}
+            hj["launch_path"] = dict(_derive(mean, 1.0), kernel="fit_independent_kernel<tightly-pack>", steps_per_dispatch=1,
+                                     dispatches=len(next(iter(per["fit_independent_kernel"].values()))))
+        if "fit_worker_kernel" in per:
+            mean = {c: sum(v) / len(v) for c, v in per["fit_worker_kernel"].items()}
+            hj["worker"] = dict(_derive(mean, float(steps)), kernel="fit_worker_kernel<tightly-pack>", steps_per_dispatch=steps,
+                                dispatches=len(next(iter(per["fit_worker_kernel"].values()))),
+                                note="one dispatch serves the K tickets of a window (launch and departure included); its "
+                                     "instruction and L2 counts include the polling of idle workgroups")
+        if os.path.exists(hstats):
+            shutil.copy(hstats, os.path.join(dst, f"{tag}_kernel_stats_headline.csv"))
+            a, n = _avg_ns(hstats, "fit_independent_kernel")
+            if a and "launch_path" in hj:
+                hj["launch_path"]["rocprof_avg_dispatch_ns"], hj["launch_path"]["rocprof_dispatches"] = a, n
+            a, n = _avg_ns(hstats, "fit_worker_kernel")
+            if a and "worker" in hj:
+                hj["worker"]["rocprof_avg_dispatch_ns"], hj["worker"]["rocprof_dispatches"] = a, n
+                hj["worker"]["rocprof_ns_per_ticket"] = a / steps
+            md += ("## the headline, both regimes (`bench.py --headline-only --steps 200`)\n\nEvery `fit_independent_kernel` dispatch is "
+                   "one headline batch (launch path); every `fit_worker_kernel` dispatch serves one window's 200 tickets.\n\n" +
+                   _stats_table(hstats, ("fit_independent", "fit_worker", "empty_kernel")) + "\n")
+            if bj:
+                rf = bj.get("roofline") or {}
+                md += (f"bench line of that (traced) run: value {bj.get('value', 0) / 1e6:.1f} M decisions/s, "
+                       f"{bj.get('ms_per_step', 0) * 1e3:.2f} us per step, roofline.kernel {rf.get('kernel')} "
+                       f"kernel_ms {rf.get('kernel_ms')}\n\n")
+        json.dump(hj, open(os.path.join(dst, "pmc_headline.json"), "w"), indent=1)
+        md += "```json\n" + json.dumps(hj, indent=1) + "\n```\n\n"
+
+    # ---- the plain FIFO chain alone
+    per = _group_means(src, "chain")
+    cstats = os.path.join(src, "chain_stats", "stats_kernel_stats.csv")
+    solo = next((k for k in per if k.startswith("fit_fifo_solo_kernel")), None)
+    if solo:
+        dump_group("chain", per)
+        mean = {c: sum(v) / len(v) for c, v in per[solo].items()}
         bj = _bench_json(os.path.join(src, "chain_sq.log")) or {}
         n_apps = ((bj.get("roofline") or {}).get("fifo_chain") or {}).get("applications_per_chain") or 1000
-        insts = sum(mean.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-        cj = {"tag": tag, "kernel": "fit_fifo_solo_kernel", "launches": len(next(iter(per.values()))),
+        d = _derive(mean, 1.0)
+        cj = {"tag": tag, "kernel": "fit_fifo_solo_kernel", "launches": len(next(iter(per[solo].values()))),
               "applications_per_chain": n_apps, "per_launch": mean,
-              "fit_fifo_solo_instructions_per_app": insts / n_apps,
-              "note": "VALU + SALU + LDS + SMEM instructions of ALL sixteen wavefronts per application (the fifteen helpers only run "
+              "fit_fifo_solo_instructions_per_app": d.get("instructions", 0.0) / n_apps,
+              "hbm_bytes_per_chain": d.get("hbm_bytes"), "l2_request_bytes_per_chain": d.get("l2_request_bytes"),
+              "wait_fraction": d.get("wait_fraction"),
+              "note": "VALU + SALU + LDS + SMEM instructions of ALL wavefronts of the workgroup per application (the helpers only run "
                       "the prologue, the checkpoint dumps and the epilogue); every launch is a full replay of the headline chain "
                       "(bench.py --fifo-protocols cold)"}
-        kst = os.path.join(src, "stats_chain", "stats_kernel_stats.csv")
-        if os.path.exists(kst):
-            shutil.copy(kst, os.path.join(dst, f"{tag}_kernel_stats_chain.csv"))
-            for r in csv.DictReader(open(kst)):
-                if r["Name"].startswith("fit_fifo_solo_kernel"):
-                    cj["kernel_avg_ns"] = float(r["AverageNs"])
-                    cj["kernel_calls"] = int(r["Calls"])
+        if os.path.exists(cstats):
+            shutil.copy(cstats, os.path.join(dst, f"{tag}_kernel_stats_chain.csv"))
+            a, n = _avg_ns(cstats, "fit_fifo_solo_kernel")
+            if a:
+                cj["kernel_avg_ns"], cj["kernel_calls"] = a, n
         json.dump(cj, open(os.path.join(dst, "pmc_chain.json"), "w"), indent=1)
-        md += ("\n## the plain FIFO chain alone (`--no-extras --fifo-protocols cold`: every launch replays the headline chain)\n\n"
-               "```json\n" + json.dumps(cj, indent=1) + "\n```\n")
+        md += ("## the plain FIFO chain alone (`--no-extras --fifo-protocols cold`: every launch replays the headline chain)\n\n"
+               "```json\n" + json.dumps(cj, indent=1) + "\n```\n\n")
+
     # ---- config 3: the two packers are two instantiations of fit_independent_kernel (Kernel_Id in launch order)
-    c3 = {"tag": tag, "note": "bytes per launch; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; L2 requests "
-                              "are 128-byte lines"}
+    c3 = {"tag": tag, "note": "per launch; hbm_bytes = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB; L2 requests are "
+                              "128-byte lines"}
     names = ["tightly_pack", "distribute_evenly"]
-    for d, counters in (("c3_fetch", ["FETCH_SIZE"]), ("c3_write", ["WRITE_SIZE"]), ("c3_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]),
-                        ("c3_sq", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAIT_ANY"])):
-        rows = [r for r in _pass(src, d) if r["Kernel_Name"].startswith("fit_independent_kernel")]
+    for p in PASSES:
+        rows = [r for r in _rows(src, f"c3_{p}") if r["Kernel_Name"].startswith("fit_independent_kernel")]
         ids = []
         for r in rows:
             if r["Kernel_Id"] not in ids:
                 ids.append(r["Kernel_Id"])
         for i, kid in enumerate(ids[:2]):
-            for c in counters:
+            for c in sorted({r["Counter_Name"] for r in rows}):
                 v = [float(r["Counter_Value"]) for r in rows if r["Kernel_Id"] == kid and r["Counter_Name"] == c]
                 if v:
                     c3.setdefault(names[i], {})[c] = sum(v) / len(v)
                     c3[names[i]]["launches"] = len(v)
+                    pmc_csv.append(["config3:" + names[i], "fit_independent_kernel", c, len(v), f"{sum(v) / len(v):.3f}",
+                                    f"{min(v):.3f}", f"{max(v):.3f}"])
     for nme in names:
         t = c3.get(nme)
-        if not t:
-            continue
-        rd, wr = t.get("FETCH_SIZE", 0.0) * 1024, t.get("WRITE_SIZE", 0.0) * 1024
-        t["hbm_bytes"] = 2 * rd + wr
-        t["l2_request_bytes"] = 128 * (t.get("TCC_HIT_sum", 0.0) + t.get("TCC_MISS_sum", 0.0))
-    kst = os.path.join(src, "stats_config3", "stats_kernel_stats.csv")
+        if t:
+            t.update({k: v for k, v in _derive(t, 1.0).items() if k in ("fetch_bytes_raw", "write_bytes", "hbm_bytes", "l2_request_bytes",
+                                                                       "instructions", "wait_fraction")})
+    kst = os.path.join(src, "c3_stats", "stats_kernel_stats.csv")
     if os.path.exists(kst):
         shutil.copy(kst, os.path.join(dst, f"{tag}_kernel_stats_config3.csv"))
     if any(n in c3 for n in names):
         json.dump(c3, open(os.path.join(dst, "pmc_config3.json"), "w"), indent=1)
-        md += ("\n## BASELINE config 3 alone (`bench.py --config3-only`: 10 000 nodes x 10 000 apps, both packers)\n\n```json\n" +
-               json.dumps(c3, indent=1) + "\n```\n")
-    return md
+        md += ("## BASELINE config 3 alone (`bench.py --config3-only`: 10 000 nodes x 10 000 apps, both packers)\n\n" +
+               (_stats_table(kst, ("fit_independent",)) + "\n" if os.path.exists(kst) else "") +
+               "```json\n" + json.dumps(c3, indent=1) + "\n```\n\n")
+
+    # ---- the full run (every chain kernel) + its LDS counter set
+    stats = os.path.join(src, "stats", "stats_kernel_stats.csv")
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+        md += ("## kernel stats of the full bench run (`--steps 50 --windows 3 --filter-calls 30 --worker-sets 0`, extras on)\n\n" +
+               _stats_table(stats, None) + "\n")
+    lds = collections.OrderedDict()
+    for r in _rows(src, "pmc_lds"):
+        lds.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    if lds:
+        md += "## LDS counter set of the full run (mean per launch)\n\n| kernel | counter | launches | mean |\n|---|---|---|---|\n"
+        for (k, c), v in lds.items():
+            pmc_csv.append(["full", k, c, len(v), f"{sum(v) / len(v):.3f}", f"{min(v):.3f}", f"{max(v):.3f}"])
+            if "fit_" in k:
+                md += f"| {k} | {c} | {len(v)} | {sum(v) / len(v):.1f} |\n"
+        md += "\n"
+    hf = os.path.join(src, "host_filter.txt")
+    if os.path.exists(hf):
+        shutil.copy(hf, os.path.join(dst, f"{tag}_host_filter.txt"))
+        md += "## the whole Filter through the C++ mirror (`host_bench`)\n\n```\n" + open(hf, errors="replace").read() + "\n```\n"
+    with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as out:
+        csv.writer(out).writerows(pmc_csv)
+    open(os.path.join(dst, f"{tag}_summary.md"), "w").write(md)
+    print(md)
 
 
 if __name__ == "__main__":
