@@ -163,6 +163,8 @@ const char *gf_last_error(gf_ctx *ctx);
  *   "minfrag_matrix", "minfrag_hist", "sparse_gpu", "zero_copy"   0 disables the respective structure
  *   "snapshot_finalize_host" 1: gf_snapshot_build* builds the slot tables through gf_orders_set on the host
  *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
+ *   "sort_fault"             1: fault injection — the priority sort's grid barrier cannot complete; gf_snapshot_build* then
+ *                            returns GF_ERR_HIP ("the priority sort's grid barrier gave up") instead of installing anything
  *   "rccl_selftest"          n: binds librccl at run time and checks a one-rank all-gather + reduce of n words on this device
  * GF_ERR_INVALID for an unknown key or a value out of range.  The only environment variables the library reads are
  * GANGFIT_WAIT=block (completion waits park the thread instead of polling) and GANGFIT_CHAIN_CACHE=0.  It never changes
@@ -271,8 +273,9 @@ int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
  * checkpoint inside the common prefix (the filtered driver of either queue excluded: nothing is committed behind it).
  * Every call that installs a snapshot, zones or orders (gf_snapshot_set, gf_zones_set, gf_orders_set, gf_snapshot_build*)
  * and gf_set_option drop the cache.  Results, placements, chain_failed_at and gf_residual_get are those of the full replay,
- * bit for bit: a checkpoint IS the table the replay holds at that application.  Served: tightly-pack and distribute-evenly
- * on the merged layout with every request in scaled form; everything else replays.
+ * bit for bit: a checkpoint IS the table the replay holds at that application.  Served: every packer's LDS chain (plain,
+ * zone-aware, minimal-fragmentation) on the merged layout with every request in scaled form; the wide / generic fallback
+ * kernels replay.
  * out[0] = chains served with the cache armed, out[1] = of those resumed from a checkpoint, out[2] = applications
  * evaluated, out[3] = applications skipped (taken from the cache).  reset != 0 zeroes the counters afterwards. */
 int gf_chain_cache_stats(gf_ctx *ctx, int reset, uint64_t out[4]);

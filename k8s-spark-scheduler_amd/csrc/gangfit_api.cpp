@@ -287,6 +287,7 @@ struct gf_ctx {
     uint32_t zd_row0 = 0;              // row of d_zmasks where the driver masks start (n_zones, or the zone count of a device build)
     bool host_stale = false;           // the host mirrors (avail / sched / h_node_slot) still sit on the device (gf_snapshot_build)
     bool snapshot_finalize_on_device = true;  // option "snapshot_finalize_host" = 1 builds the slot tables through gf_orders_set
+    int sort_fault = 0;                       // option "sort_fault" (tests): the priority sort's grid barrier cannot complete
     DeviceBuf<gf_result> d_zres;
     DeviceBuf<uint32_t> d_zexec;
     DeviceBuf<double> d_zavg, d_avg;
@@ -1507,6 +1508,8 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->zero_copy = value != 0;
     } else if (k == "snapshot_finalize_host") {
         ctx->snapshot_finalize_on_device = value == 0;
+    } else if (k == "sort_fault") {
+        ctx->sort_fault = value != 0 ? 1 : 0;
     } else if (k == "force_general_layout") {
         ctx->force_general_layout = value != 0;
     } else if (k == "chain_cache") {
@@ -3004,6 +3007,7 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     b.d_keys_b = d_keys_b;
     b.d_keys_c = d_keys_c;
     b.d_perm_c = d_perm_c;
+    b.sort_fault = ctx->sort_fault;
     GF_HIP(ctx, ctx->d_sortwork.reserve(gangfit::snapshot_sort_work_words()));
     b.d_sort_work = ctx->d_sortwork.ptr;
     GF_HIP(ctx, gangfit::launch_snapshot_build(b, st));

@@ -363,6 +363,8 @@ struct SnapshotBuild {
     int64_t* d_keys_c;           // n_nodes
     uint32_t* d_perm_c;          // n_nodes
     uint32_t* d_sort_work;       // snapshot_sort_work_words() uint32 (8-byte aligned): count tables, barrier, scalars
+    int sort_fault = 0;          // fault injection (tests): 1 = one workgroup of the sort never arrives at the grid barrier and
+                                 // the others give up after 2^12 instead of 2^24 probes -> the error word is set
 };
 // usage[node] += sign * entry for n_entries reservation entries (columns cpu | memory | gpu of d_req); entries on nodes
 // >= n_nodes are ignored.

@@ -1025,7 +1025,9 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 
 // One wave per app, 4 apps per workgroup.  Grid = ceil(n_apps / 4) >> 256 CUs at the target sizes.
 #ifndef GF_IND_PAIR_FROM
-#define GF_IND_PAIR_FROM 7168  // batches of at least this many applications run two per wavefront (0: never)
+#define GF_IND_PAIR_FROM 0  // experiment switch: batches of at least this many applications run two per wavefront (0: never).
+// Measured on config 3 (10 000 x 10 000, profiles/r4a_variants.txt): 11.5 us one application per wavefront, 13.0-13.2 us two — the
+// second decision of a wavefront starts behind the first one's stores, and the kernel drops from seven to five wavefronts per SIMD.
 #endif
 #ifndef GF_IND_PAIR_UNROLL
 #define GF_IND_PAIR_UNROLL 0  // experiment switch: 1 = two inlined copies of the decision instead of a two-trip loop

@@ -194,6 +194,7 @@ struct PrioritySort {
     unsigned long long* keys[3];
     uint32_t* perm[3];         // [0] holds the name order at launch, [1] receives the result: position -> node
     uint32_t* work;            // kSortHistWords + kSortStateWords uint32 + kSortScalars uint64; zero at launch but the ranges
+    uint32_t spin_limit;       // probes of the barrier word before a wavefront gives up (2^24: about half a second)
 };
 
 __device__ __forceinline__ uint32_t bits_of(unsigned long long v) { return v ? 64u - (uint32_t)__clzll(v) : 0u; }
@@ -202,7 +203,7 @@ __device__ __forceinline__ uint32_t bits_of(unsigned long long v) { return v ? 6
 // visible to every wavefront behind it (agent-scope release / acquire: the XCDs' L2s are written back and invalidated).
 // false = the others did not arrive in about half a second (a device saturated by someone else's endless kernel): the caller
 // flags the error and leaves.
-__device__ __forceinline__ bool sort_grid_sync(uint32_t* state, int lane) {
+__device__ __forceinline__ bool sort_grid_sync(uint32_t* state, int lane, uint32_t spin_limit) {
     int ok = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
@@ -215,7 +216,7 @@ __device__ __forceinline__ bool sort_grid_sync(uint32_t* state, int lane) {
             uint32_t spins = 0;
             while (__hip_atomic_load(&state[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) {
+                if (++spins > spin_limit) {
                     ok = 0;
                     break;
                 }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64) void priority_sort_kernel(PrioritySort A) {
     uint32_t* const state = A.work + kSortHistWords;
     const unsigned long long* const scal = reinterpret_cast<const unsigned long long*>(A.work + kSortHistWords + kSortStateWords);
 #define GF_SORT_SYNC()                                            \
-    if (!sort_grid_sync(state, (int)lane)) {                      \
+    if (!sort_grid_sync(state, (int)lane, A.spin_limit)) {        \
         if (lane == 0) atomicOr(&state[2], 1u);                   \
         return;                                                   \
     }
@@ -738,12 +739,14 @@ hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
     PrioritySort ps{n, b.n_zones, b.d_avail, b.d_avail + n, b.d_zone, b.d_zone_rank,
                     {reinterpret_cast<unsigned long long*>(b.d_keys_a), reinterpret_cast<unsigned long long*>(b.d_keys_b),
                      reinterpret_cast<unsigned long long*>(b.d_keys_c)},
-                    {b.d_perm_a, b.d_perm_b, b.d_perm_c}, b.d_sort_work};
+                    {b.d_perm_a, b.d_perm_b, b.d_perm_c}, b.d_sort_work, b.sort_fault ? (1u << 12) : (1u << 24)};
     // An ordinary launch: sixty-four one-wavefront workgroups become resident as soon as sixty-four wave slots are free (every
     // other kernel of this library terminates on its own), and the grid barrier gives up with an error flag instead of
     // spinning forever.  (hipLaunchCooperativeKernel would also promise residency, but rocprofv3 crashes at process exit
     // behind a cooperative launch.)
-    hipLaunchKernelGGL(priority_sort_kernel, dim3(kSortWG), dim3(64), 0, stream, ps);
+    // (sort_fault: the last workgroup is not launched, so the barrier can never complete — what an oversubscribed device
+    //  looks like to the other sixty-three; they flag the error and leave, and the host refuses the build)
+    hipLaunchKernelGGL(priority_sort_kernel, dim3(b.sort_fault ? kSortWG - 1u : kSortWG), dim3(64), 0, stream, ps);
     return hipGetLastError();
 }
 

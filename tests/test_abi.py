@@ -41,9 +41,8 @@ def test_version_and_struct_layout(lib_path):
 
 
 def test_code_object_is_gfx950(lib_path):
-    """Every device code object bundled into the library targets gfx950 (bundle ids `...amdhsa--<arch>`).  rocPRIM's
-    host-side arch-name table (pulled in by the radix sort of gangfit_snapshot.hip) mentions other arch names as plain
-    strings; those are not code objects."""
+    """Every device code object bundled into the library targets gfx950 (bundle ids `...amdhsa--<arch>`); no sorting or
+    scan library is linked in (the priority sort of gangfit_snapshot.hip is hand-written), so nothing else names an arch."""
     import re
 
     blob = open(lib_path, "rb").read()

@@ -324,3 +324,25 @@ def test_priority_sort_key_groups(gf_ctx, spread):
     avail, sched, rD, rX = ps.build(**c)
     assert np.array_equal(gf_ctx.snapshot()[0], avail)
     assert np.array_equal(D, rD) and np.array_equal(X, rX)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("want_orders", [True, False])
+def test_sort_barrier_timeout_is_reported_not_installed(gf_ctx, want_orders):
+    """The priority sort's grid barrier is an ordinary launch whose sixty-four workgroups are ASSUMED resident together; when they
+    are not (a device saturated by somebody's endless kernel) the barrier gives up and flags an error word.  `sort_fault`
+    provokes exactly that (one workgroup never arrives): the build must fail loudly on both paths that read the word — the
+    host-finalized one and the device-finalized one —, install nothing, and leave the context usable."""
+    c = _cluster(4242, 3000, 500, 3)
+    D0, X0 = gf_ctx.build_snapshot(**c)                    # a good snapshot first: it must survive the failed build
+    before = gf_ctx.snapshot()[0].copy()
+    gf_ctx.set_option("sort_fault", 1)
+    c2 = _cluster(4243, 3000, 500, 3)
+    with pytest.raises(gangfit.GangfitError) as e:
+        gf_ctx.build_snapshot(want_orders=want_orders, **c2)
+    assert "grid barrier gave up" in str(e.value)
+    gf_ctx.set_option("sort_fault", 0)
+    D, X = gf_ctx.build_snapshot(**c)                      # ... and the very next build on the same context is fine
+    avail, sched, rD, rX = ps.build(**c)
+    assert np.array_equal(D, rD) and np.array_equal(X, rX) and np.array_equal(D, D0) and np.array_equal(X, X0)
+    assert np.array_equal(gf_ctx.snapshot()[0], avail) and np.array_equal(before, avail)
