@@ -392,8 +392,9 @@ struct gf_ctx {
         std::vector<uint32_t> exec;
         DeviceBuf<int32_t> d_ckpt;    // [n][slot_words]
         size_t slot_words = 0;        // chain_ckpt_stride of the snapshot the buffer was laid out for
-        bool dirty_format = false;    // the checkpoints hold only the chunks that differ from the snapshot + their mask (the solo
-                                      // kernel on a table with a global tail): restored by a kernel instead of a copy
+        bool dirty_format = false;    // the checkpoints are DELTAS (the chunks touched since the previous checkpoint + a cumulative
+                                      // and a delta mask; the solo kernel on a table with a global tail): restored by a kernel
+                                      // that lays checkpoints 1 .. i over the snapshot instead of a copy
     } chain;
     uint64_t chain_stat[4] = {0, 0, 0, 0};  // chains | resumed chains | applications evaluated | applications skipped
     struct PlannedUnits {  // what chain_plan found for the call in progress: narrow_begin does not scan the queue again
@@ -646,7 +647,9 @@ int narrow_begin(gf_ctx* ctx, const gf_app* h_apps, uint32_t n_apps, hipStream_t
     }
     // ... or only the chunks that differ from the snapshot (in the chain's units), laid over it
     if (restore != nullptr && restore_dirty_chunks) {
-        io->overlay = restore;
+        io->overlay = ctx->chain.d_ckpt.ptr;  // checkpoints 1 .. count, the latest delta of a chunk wins (delta format)
+        io->overlay_stride = ctx->chain.slot_words;
+        io->overlay_count = (uint32_t)((size_t)(restore - ctx->chain.d_ckpt.ptr) / ctx->chain.slot_words) + 1u;
         io->overlay_dst = ctx->d_nwork.ptr;
         io->overlay_slots = ctx->n_slots;
         io->overlay_chunks = ctx->n_chunks;

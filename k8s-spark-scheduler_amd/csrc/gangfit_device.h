@@ -187,14 +187,19 @@ struct ChainCkpt {
     uint32_t a_base;
     uint32_t shift;
     size_t stride;                          // int32 words between two checkpoints (>= 3 * n_slots; chain_ckpt_stride)
-    const unsigned long long* resume_mask;  // solo kernel with a global table tail: the dirty-chunk mask of the checkpoint
-                                            // this launch resumes from (nullptr: from the snapshot)
+    const unsigned long long* resume_mask;  // solo kernel with a global table tail: the cumulative dirty-chunk mask of the
+                                            // checkpoint this launch resumes from (nullptr: from the snapshot)
 };
-// Checkpoint layout: cpu | mem | gpu (n_slots int32 each), then — 8-byte aligned — one bit per 64-slot chunk ("dirty":
-// the chunk differs from the snapshot; written by the solo kernel when the table has a global tail, where only those
-// chunks are dumped).
+// Checkpoint layout: cpu | mem | gpu (n_slots int32 each), then — 8-byte aligned — two masks of one bit per 64-slot chunk:
+//   cumulative  the chunk differs from the snapshot at this checkpoint,
+//   delta       the chunk was touched by a commit since the PREVIOUS checkpoint of the chain.
+// Written by the solo kernel when the table has a global tail (the DELTA format): only the delta chunks are dumped — a dump
+// costs what the last 2^shift applications touched, not what the chain has touched so far — and a chain that resumes from
+// checkpoint i starts from the snapshot with, for every chunk of cumulative(i), the copy in the LATEST checkpoint j <= i whose
+// delta names it (chain_prologue_kernel).  Kernels that dump whole tables leave the masks unused.
+inline size_t chain_ckpt_mask_words(uint32_t n_chunks) { return 2 * (size_t)((n_chunks + 63u) / 64u); }  // uint32 words of ONE mask
 inline size_t chain_ckpt_stride(uint32_t n_slots, uint32_t n_chunks) {
-    return 3 * (size_t)n_slots + (n_slots & 1u) + 2 * (size_t)((n_chunks + 63u) / 64u);
+    return 3 * (size_t)n_slots + (n_slots & 1u) + 2 * chain_ckpt_mask_words(n_chunks);
 }
 // What a chain launcher folds into its first and its last kernel, so that a Filter's chain is three launches instead of
 // nine runtime calls (each costs ~7 us of host time alone, several times that when eight threads enqueue eight chains):
@@ -209,7 +214,11 @@ struct ChainIo {
     const uint32_t* copy_src[2] = {nullptr, nullptr};
     uint32_t* copy_dst[2] = {nullptr, nullptr};
     size_t copy_words[2] = {0, 0};
-    const int32_t* overlay = nullptr;  // a checkpoint in the dirty-chunk format, laid over overlay_dst after the copies
+    const int32_t* overlay = nullptr;  // checkpoint 1 of a series in the delta format (chain_ckpt_stride): checkpoints
+                                       // 1 .. overlay_count are laid over overlay_dst after the copies, the latest delta of a
+                                       // chunk winning
+    size_t overlay_stride = 0;         // int32 words between two checkpoints
+    uint32_t overlay_count = 0;        // the checkpoint the chain resumes from (1-based)
     int32_t* overlay_dst = nullptr;
     uint32_t overlay_slots = 0, overlay_chunks = 0;
     int32_t* wide_clear = nullptr;     // the flag word the NEXT chain will use (zeroed here: the words alternate)

@@ -1730,7 +1730,7 @@ size_t fifo_v2_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
 size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
     const size_t nw = (n_chunks + 63u) / 64u, nwp = nw < 4 ? 4 : nw;
     size_t off = kFusedStage * sizeof(NApp) + sizeof(SoloShared) + 16 * (size_t)n_chunks + 8 * (size_t)kMaxShapes * nwp +
-                 8 * (size_t)n_chunks + 8 * nw + 8 * (size_t)kMaxShapes;
+                 8 * (size_t)n_chunks + 16 * nw + 8 * (size_t)kMaxShapes;
     off = (off + 15) & ~(size_t)15;
     off += sizeof(ShapeEntry) * (kShapeHashSlots + kMaxShapes) + 4 * kShapeHashSlots + 16 + 4 * kMaxShapes +
            4 * (size_t)n_chunks + 12 * (size_t)n_chunks;
@@ -1782,6 +1782,8 @@ hipError_t launch_chain_prologue(const ChainIo& io, uint32_t n_apps, const gf_ap
         most = std::max(most, io.copy_words[r] / 4);
     }
     p.overlay = io.overlay;
+    p.overlay_stride = io.overlay_stride;
+    p.overlay_count = io.overlay_count;
     p.overlay_dst = io.overlay_dst;
     p.overlay_slots = io.overlay_slots;
     p.overlay_chunks = io.overlay_chunks;
