@@ -247,6 +247,13 @@ struct gf_ctx {
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
     bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
+    // a lone blocking independent batch announces its own completion in pinned memory (gangfit::IndHostOut): the caller polls a
+    // word instead of waiting for the stream
+    bool host_flag = true;         // option "host_flag" = 0: gf_fit_batch waits for the stream as before
+    DeviceBuf<uint32_t> d_ind_done;             // arrival counters, all zero between launches
+    PinnedBuf<unsigned long long> h_ind_flag;   // [0] = sequence number of the last batch that announced itself
+    uint64_t ind_seq = 0;
+    double call_phase_us[5] = {0, 0, 0, 0, 0};  // last gf_fit_batch on the zero-copy path: stage | launch | wait | copy out | total
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (chain_prologue_kernel)
     DeviceBuf<int32_t> d_wide_needed;       // two words used alternately: set by the chain prologue when a request has no narrow
@@ -1021,7 +1028,7 @@ void chain_commit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, uint64_t total_k, 
 // run (nullable): gf_fit_batch's plan for a FIFO chain; d_apps / d_results are always the arrays of the WHOLE queue.
 int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, const gf_app* d_apps,
            gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream,
-           const ChainRun* run = nullptr) {
+           const ChainRun* run = nullptr, const gangfit::IndHostOut* host_out = nullptr) {
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
     const uint64_t half = exec_nodes_len + 1;
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
@@ -1062,7 +1069,7 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     if (mode == GF_MODE_INDEPENDENT) {
         if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;
         GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps,
-                                                    d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
+                                                    d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream, host_out));
     } else if (mode == GF_MODE_FIFO_CHAIN) {
         gangfit::FifoPlan plan{};
         plan.narrow = ctx->merged && ctx->narrow_ok && !ctx->fifo_generic;
@@ -1361,6 +1368,8 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_napps.release();
     ctx->chain.d_ckpt.release();
     ctx->d_flag32.release();
+    ctx->d_ind_done.release();
+    ctx->h_ind_flag.release();
     ctx->d_sortwork.release();
     ctx->d_wide_needed.release();
     ctx->d_capmat.release();
@@ -1509,6 +1518,8 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->sparse_gpu = value != 0;
     } else if (k == "zero_copy") {
         ctx->zero_copy = value != 0;
+    } else if (k == "host_flag") {
+        ctx->host_flag = value != 0;
     } else if (k == "snapshot_finalize_host") {
         ctx->snapshot_finalize_on_device = value == 0;
     } else if (k == "sort_fault") {
@@ -2103,6 +2114,7 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     if (n_apps > 0 && (!apps || !results)) return fail(ctx, GF_ERR_INVALID, "apps/results must not be NULL");
     if (chain_failed_at) *chain_failed_at = -1;
     if (n_apps == 0) return GF_OK;
+    const auto t_entry = std::chrono::steady_clock::now();
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, ctx->h_apps.reserve(n_apps));
     uint64_t total_k = 0;
@@ -2133,12 +2145,58 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         (uint64_t)n_apps * sizeof(gf_app) + total_k * sizeof(uint32_t) <= (UINT64_C(4) << 20)) {
         void *da = ctx->h_apps.dev, *dr = ctx->h_results.dev, *de = ctx->h_exec.dev;
         if (da != nullptr && dr != nullptr && de != nullptr) {
-            const int rc0 = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
-                                   static_cast<gf_result*>(dr), static_cast<uint32_t*>(de), total_k, ctx->d_failed.ptr, st);
+            using clk = std::chrono::steady_clock;
+            const auto t_staged = clk::now();
+            // the launch announces its own completion in pinned memory (IndHostOut): what a 5 us kernel otherwise waits longest
+            // for is the kernel-end release, the completion signal and the runtime's query
+            gangfit::IndHostOut ho{};
+            bool flagged = ctx->host_flag && !wait_blocking();
+            if (flagged) {
+                if (ctx->d_ind_done.ptr == nullptr) {
+                    const size_t words = (size_t)(gangfit::kIndDoneCounters + 1) * gangfit::kIndDoneStride;
+                    GF_HIP(ctx, ctx->d_ind_done.reserve(words));
+                    GF_HIP(ctx, hipMemsetAsync(ctx->d_ind_done.ptr, 0, words * sizeof(uint32_t), st));
+                    GF_HIP(ctx, ctx->h_ind_flag.reserve(8));
+                    ctx->h_ind_flag.ptr[0] = 0;
+                }
+                flagged = ctx->h_ind_flag.dev != nullptr;
+            }
+            if (flagged) {
+                ho.h_results = static_cast<gf_result*>(dr);
+                ho.h_exec = static_cast<uint32_t*>(de);
+                ho.counters = ctx->d_ind_done.ptr;
+                ho.flag = ctx->h_ind_flag.dev;
+                ho.seq = ++ctx->ind_seq;
+            }
+            const int rc0 = flagged ? launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
+                                             ctx->d_results.ptr, ctx->d_exec.ptr, total_k, ctx->d_failed.ptr, st, nullptr, &ho)
+                                    : launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
+                                             static_cast<gf_result*>(dr), static_cast<uint32_t*>(de), total_k, ctx->d_failed.ptr, st);
             if (rc0 != GF_OK) return rc0;
-            GF_HIP(ctx, gf_wait_stream(st));
+            const auto t_launched = clk::now();
+            bool seen = false;
+            if (flagged) {
+                const unsigned long long* f = ctx->h_ind_flag.ptr;
+                for (uint32_t spins = 0;; ++spins) {
+                    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == ho.seq) {
+                        seen = true;
+                        break;
+                    }
+                    // (a launch that faults never writes the word: the stream wait below reports it)
+                    if ((spins & 0x3FFu) == 0x3FFu && clk::now() - t_launched > std::chrono::milliseconds(5)) break;
+                }
+            }
+            if (!seen) GF_HIP(ctx, gf_wait_stream(st));
+            const auto t_done = clk::now();
             std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
             if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
+            const auto t_out = clk::now();
+            auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            ctx->call_phase_us[0] = us(t_entry, t_staged);
+            ctx->call_phase_us[1] = us(t_staged, t_launched);
+            ctx->call_phase_us[2] = us(t_launched, t_done);
+            ctx->call_phase_us[3] = us(t_done, t_out);
+            ctx->call_phase_us[4] = us(t_entry, t_out);
             return GF_OK;
         }
     }
@@ -2605,6 +2663,14 @@ int gf_worker_stats(gf_ctx* ctx, uint64_t out[4]) {
     out[1] = w.completed_upto;
     out[2] = w.launches;
     out[3] = (w.allocated && w.running && host_load(&w.h->state) != 2) ? 1 : 0;
+    return GF_OK;
+}
+
+int gf_call_phases(gf_ctx* ctx, double out_us[5]) {
+    GF_DELEGATE(ctx, gf_call_phases(ctx, out_us));
+    if (!ctx || !out_us) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    for (int i = 0; i < 5; ++i) out_us[i] = ctx->call_phase_us[i];
     return GF_OK;
 }
 

@@ -113,9 +113,22 @@ struct ScanStats {
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).
+// host (nullable): the answers of a lone blocking batch go straight to device-mapped pinned HOST memory as write-through stores
+// and the launch announces its own completion there — the caller polls `flag` for `seq` instead of waiting for the stream
+// (gf_fit_batch; the kernel-end release, the completion signal and the runtime's query are what a 5 us launch waits longest for).
+struct IndHostOut {
+    gf_result* h_results;      // [n_apps], device address of pinned host memory
+    uint32_t* h_exec;          // [sum of k]
+    uint32_t* counters;        // device memory, kIndDoneCounters + 1 words kIndDoneStride apart, all zero between launches
+    unsigned long long* flag;  // pinned host word (device address): receives seq when every answer has left
+    unsigned long long seq;
+};
+constexpr uint32_t kIndDoneCounters = 16;  // first-level arrival counters: one memory channel each
+constexpr uint32_t kIndDoneStride = 64;    // uint32 words between two counters (256 bytes)
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream,
+                                  const IndHostOut* host = nullptr);
 
 // ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gf_worker_* in gangfit_api.cpp)
 constexpr uint32_t kWorkerRing = 64;

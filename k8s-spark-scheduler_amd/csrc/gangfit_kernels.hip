@@ -1024,14 +1024,6 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // ------------------------------------------------------------------------------------------------ independent batch
 
 // One wave per app, 4 apps per workgroup.  Grid = ceil(n_apps / 4) >> 256 CUs at the target sizes.
-#ifndef GF_IND_PAIR_FROM
-#define GF_IND_PAIR_FROM 0  // experiment switch: batches of at least this many applications run two per wavefront (0: never).
-// Measured on config 3 (10 000 x 10 000, profiles/r4a_variants.txt): 11.5 us one application per wavefront, 13.0-13.2 us two — the
-// second decision of a wavefront starts behind the first one's stores, and the kernel drops from seven to five wavefronts per SIMD.
-#endif
-#ifndef GF_IND_PAIR_UNROLL
-#define GF_IND_PAIR_UNROLL 0  // experiment switch: 1 = two inlined copies of the decision instead of a two-trip loop
-#endif
 #ifndef GF_IND_WAVES_PER_EU
 #define GF_IND_WAVES_PER_EU 0  // experiment switch: > 0 asks the compiler for that many wavefronts per SIMD (VGPR and SGPR budget)
 #endif
@@ -1042,45 +1034,52 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 #else
 #define GF_IND_OCC
 #endif
-// A gf_app as eight 8-byte words in lanes 0..7 of one VGPR pair (a vector load: it can stay in flight, and later parked, while
-// another application is decided), and its fields handed out to the scalar side when its turn comes.
-__device__ __forceinline__ unsigned long long load_app_words(const gf_app* __restrict__ apps, uint32_t a, int lane) {
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(apps + a);
-    return lane < 8 ? p[lane] : 0ull;
-}
-__device__ __forceinline__ App app_from_words(unsigned long long w) {
-    App r;
-    r.drv0 = (int64_t)read_lane((int64_t)w, 0);
-    r.drv1 = (int64_t)read_lane((int64_t)w, 1);
-    r.drv2 = (int64_t)read_lane((int64_t)w, 2);
-    r.exe0 = (int64_t)read_lane((int64_t)w, 3);
-    r.exe1 = (int64_t)read_lane((int64_t)w, 4);
-    r.exe2 = (int64_t)read_lane((int64_t)w, 5);
-    const uint64_t kf = (uint64_t)read_lane((int64_t)w, 6);
-    r.k = (int32_t)(uint32_t)kf;
-    r.flags = (uint32_t)(kf >> 32);
-    r.exec_off = (uint64_t)read_lane((int64_t)w, 7);
-    r.rcp0 = r.exe0 > 0 ? fast_rcp((double)r.exe0) : 0.0;
-    r.rcp1 = r.exe1 > 0 ? fast_rcp((double)r.exe1) : 0.0;
-    r.rcp2 = r.exe2 > 0 ? fast_rcp((double)r.exe2) : 0.0;
-    return r;
-}
-
-// One wavefront per application, four wavefronts per workgroup — or, for batches that would otherwise need more than one
-// round of wavefronts on the device (APW = 2, launch_fit_independent): two applications per wavefront, a and a + n_waves, one
-// after the other.  Group 0 of the chunk index does not depend on the application and both records are requested together
-// (the second one parked in lanes 0..7 of a VGPR pair while the first is decided): the second decision starts one round trip
-// into its chain, and 10 000 applications are 5 000 wavefronts — all resident at once at seven per SIMD — instead of 1.4 rounds.
-template <int ALGO, int APW>
+// One wavefront per application, four wavefronts per workgroup.  (Round 4 measured two applications per wavefront for batches
+// that need more than one round of wavefronts — both records requested together, the second parked in two VGPR lanes while the
+// first is decided, 5 000 wavefronts for config 3 instead of 10 000: 13.0-13.2 us against 11.5 us, profiles/r4a_variants.txt.
+// The second decision starts behind the first one's stores and the kernel drops from seven to five wavefronts per SIMD; removed.)
+//
+// HOST (a lone blocking batch of gf_fit_batch): exec_nodes is private device memory, the placements are copied out — and the
+// 16-byte results written — as write-through stores into device-mapped pinned HOST memory (plain stores to host memory stay in
+// the L2 until the kernel-end release), and the launch announces its own completion: a wavefront drains its stores, the last
+// wavefront of a workgroup adds the workgroup to one of kIndDoneCounters counters (one memory channel each), the arrival that
+// completes a counter adds it to the final one, and the arrival that completes that writes the call's sequence number into a
+// pinned host word the caller polls (the machinery of the resident worker, gangfit_worker.inc).
+template <int ALGO, bool HOST>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independent_kernel(
     NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
     uint32_t* __restrict__ exec_nodes, uint32_t* __restrict__ scratch, uint64_t scratch_half,
-    ScanStats* __restrict__ stats) {
+    ScanStats* __restrict__ stats, IndHostOut H) {
+    __shared__ uint32_t s_arrived;
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
-    const uint32_t n_waves = APW == 1 ? n_apps : (n_apps + 1u) / 2u;
-    if (a >= n_waves) return;
+    const uint32_t n_waves = n_apps;
+    if (HOST) {
+        if (threadIdx.x == 0) s_arrived = 0;
+        __syncthreads();  // (before any wavefront may leave: every wavefront of the workgroup takes part)
+    }
+    // called by every wavefront of the grid in HOST mode, behind its last store
+    auto announce = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's write-through stores are acknowledged
+        if (lane != 0) return;
+        if (atomicAdd(&s_arrived, 1u) + 1u != (uint32_t)kWavesPerBlock) return;  // not the workgroup's last wavefront
+        const uint32_t n_blocks = gridDim.x;
+        const uint32_t ci = blockIdx.x % kIndDoneCounters;
+        const uint32_t expect = n_blocks / kIndDoneCounters + (ci < n_blocks % kIndDoneCounters ? 1u : 0u);  // workgroups on counter ci
+        uint32_t* c1 = H.counters + (size_t)ci * kIndDoneStride;
+        if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != expect) return;
+        __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        const uint32_t used = n_blocks < kIndDoneCounters ? n_blocks : kIndDoneCounters;
+        uint32_t* c2 = H.counters + (size_t)kIndDoneCounters * kIndDoneStride;
+        if (__hip_atomic_fetch_add(c2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != used) return;
+        __hip_atomic_store(c2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(H.flag, H.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    if (a >= n_waves) {
+        if (HOST) announce();
+        return;
+    }
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
@@ -1094,7 +1093,20 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
         Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
                                                             scratch + scratch_half + app.exec_off, lane, xvis, dvis,
                                                             merged ? &g0 : nullptr, &G);
-        if (lane == 0) {
+        if (HOST) {
+            if (dec.feasible)  // this wavefront's own placements, read back through its L1 / L2 and sent out write-through
+                for (int32_t i = lane; i < app.k; i += kWave)
+                    __hip_atomic_store(H.h_exec + app.exec_off + i, exec_nodes[app.exec_off + i], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane < 2) {  // the 16-byte result as two write-through words
+                if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
+                const unsigned long long lo = (unsigned long long)(uint32_t)(dec.feasible ? 1 : 0) |
+                                              ((unsigned long long)(dec.feasible ? dec.ds_node : GF_NO_NODE) << 32);
+                const unsigned long long hi = (unsigned long long)(dec.feasible ? (uint32_t)app.k : 0u) | (1ull << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(H.h_results + ai) + lane, lane == 0 ? lo : hi,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else if (lane == 0) {
             gf_result r;
             r.has_capacity = dec.feasible ? 1 : 0;
             if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
@@ -1104,33 +1116,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
             results[ai] = r;
         }
     };
-    if (APW == 1) {
-        decide(load_app(apps, a), a);
-    } else {
-        const uint32_t b = a + n_waves;  // (wave-uniform) the second application of this wavefront
-        const unsigned long long wa = load_app_words(apps, a, lane);
-        const unsigned long long wb = b < n_apps ? load_app_words(apps, b, lane) : 0ull;
-#if GF_IND_PAIR_UNROLL
-        decide(app_from_words(wa), a);
-        if (b < n_apps) decide(app_from_words(wb), b);
-#else
-        unsigned long long w = wa;
-        uint32_t ai = a;
-#pragma nounroll
-        for (int i = 0; i < 2; ++i) {  // ONE copy of the decision in the code (the instruction cache is shared by the CU's wavefronts)
-            if (i == 1) {
-                if (b >= n_apps) break;
-                w = wb;
-                ai = b;
-            }
-            decide(app_from_words(w), ai);
-        }
-#endif
-    }
+    decide(load_app(apps, a), a);
     if (stats != nullptr && lane == 0) {
         atomicAdd(&stats->exec_slots_visited, xvis);
         atomicAdd(&stats->driver_slots_visited, dvis);
     }
+    if (HOST) announce();
 }
 
 // ------------------------------------------------------------------------------------------------ FIFO chain
@@ -1697,22 +1688,27 @@ hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseT
 
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream) {
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, const IndHostOut* host) {
     if (n_apps == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
-    // two applications per wavefront once one per wavefront would need more than a round of the device (1 024 SIMDs x 7)
-    const bool pair = GF_IND_PAIR_FROM != 0 && n_apps >= (uint32_t)GF_IND_PAIR_FROM;
-    const uint32_t n_waves = pair ? (n_apps + 1u) / 2u : n_apps;
-    const dim3 grid((n_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-#define GF_IND(ALGO)                                                                                                          \
-    do {                                                                                                                      \
-        if (pair)                                                                                                             \
-            hipLaunchKernelGGL((fit_independent_kernel<ALGO, 2>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,      \
-                               d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);                                    \
-        else                                                                                                                  \
-            hipLaunchKernelGGL((fit_independent_kernel<ALGO, 1>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,      \
-                               d_results, d_exec_nodes, d_scratch, scratch_half, d_stats);                                    \
-    } while (0)
+    if (host != nullptr) {  // a lone blocking batch: one application per wavefront, answers and completion word to pinned host memory
+        const dim3 hgrid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+#define GF_IND_HOST(ALGO)                                                                                                   \
+    hipLaunchKernelGGL((fit_independent_kernel<ALGO, true>), hgrid, block, 0, stream, table, gpu_view, n_apps, d_apps,     \
+                       d_results, d_exec_nodes, d_scratch, scratch_half, d_stats, *host)
+        if (algo == GF_ALGO_TIGHTLY_PACK)
+            GF_IND_HOST(GF_ALGO_TIGHTLY_PACK);
+        else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+            GF_IND_HOST(GF_ALGO_MINIMAL_FRAGMENTATION);
+        else
+            GF_IND_HOST(GF_ALGO_DISTRIBUTE_EVENLY);
+#undef GF_IND_HOST
+        return hipGetLastError();
+    }
+    const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+#define GF_IND(ALGO)                                                                                                        \
+    hipLaunchKernelGGL((fit_independent_kernel<ALGO, false>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,        \
+                       d_results, d_exec_nodes, d_scratch, scratch_half, d_stats, IndHostOut{})
     if (algo == GF_ALGO_TIGHTLY_PACK)
         GF_IND(GF_ALGO_TIGHTLY_PACK);
     else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)

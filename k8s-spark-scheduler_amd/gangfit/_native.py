@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
     "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
     "gf_usage_reset", "gf_usage_apply", "gf_set_option", "gf_chain_cache_stats", "gf_generation", "gf_shard_count", "gf_ctx_view",
-    "gf_worker_fit", "gf_worker_submit_dev", "gf_worker_wait", "gf_worker_stop", "gf_worker_stats", "gf_worker_kernel_time",
+    "gf_worker_fit", "gf_worker_submit_dev", "gf_worker_wait", "gf_worker_stop", "gf_worker_stats", "gf_worker_kernel_time", "gf_call_phases",
 ]
 
 
@@ -195,6 +195,8 @@ def load() -> C.CDLL:
     L.gf_worker_stop.argtypes = [p]
     L.gf_worker_stats.restype = i32
     L.gf_worker_stats.argtypes = [p, p]
+    L.gf_call_phases.restype = i32
+    L.gf_call_phases.argtypes = [p, C.POINTER(C.c_double)]
     L.gf_worker_kernel_time.restype = i32
     L.gf_worker_kernel_time.argtypes = [p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     L.gf_shard_count.restype = i32

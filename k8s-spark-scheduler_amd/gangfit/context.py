@@ -379,6 +379,12 @@ class Context:
         self._check(self._lib.gf_worker_stats(self._h, out))
         return {"posted": int(out[0]), "complete": int(out[1]), "launches": int(out[2]), "resident": bool(out[3])}
 
+    def call_phases(self):
+        """Host-clock phases (us) of the last blocking independent gf_fit_batch on the zero-copy path."""
+        out = (C.c_double * 5)()
+        self._check(self._lib.gf_call_phases(self._h, out))
+        return {"stage": out[0], "launch": out[1], "wait": out[2], "copy_out": out[3], "total": out[4]}
+
     def worker_kernel_time(self):
         """(ms on the device, tickets relayed) of the worker's last finished launch — HIP events on the worker's stream."""
         ms, n = C.c_float(), C.c_uint64()
