@@ -15,7 +15,8 @@ HOST_BENCH_PATH = os.path.join(_PKG_ROOT, "host_bench")  # end-to-end Filter tim
 HOST_TEST_PATH = os.path.join(_PKG_ROOT, "host_test")  # C++ tests of the host mirror (host/tests/host_test.cpp)
 INCLUDE = os.path.join(_REPO_ROOT, "include")
 
-_SOURCES = ["gangfit_kernels.hip", "gangfit_snapshot.hip", "gangfit_api.cpp"]
+_SOURCES = ["gangfit_kernels.hip", "gangfit_snapshot.hip", "gangfit_api.cpp", "gangfit_api_snapshot.cpp", "gangfit_api_fit.cpp",
+            "gangfit_api_worker.cpp", "gangfit_api_group.cpp"]
 _HEADERS = [os.path.join(CSRC, "gangfit_device.h"), os.path.join(INCLUDE, "gangfit.h")]
 
 
@@ -34,13 +35,24 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_native(force: bool = False, extra_flags=()) -> str:
-    """hipcc --offload-arch=gfx950 ... -> k8s-spark-scheduler_amd/libgangfit.so"""
+    """hipcc --offload-arch=gfx950 ... -> k8s-spark-scheduler_amd/libgangfit.so.  The translation units are compiled side by side
+    (one hipcc process each: the two kernel files take most of a minute, the five host files a few seconds), then linked."""
     srcs = [os.path.join(CSRC, s) for s in _SOURCES]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + _HEADERS  # .inc files are #included by the .hip
     if force or extra_flags or _stale(LIB_PATH, deps):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
-               *extra_flags, *srcs, "-o", LIB_PATH]
-        subprocess.check_call(cmd)
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+
+        common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, *extra_flags]
+        with tempfile.TemporaryDirectory(prefix="gangfit_build_") as tmp:
+            objs = [os.path.join(tmp, os.path.basename(s) + ".o") for s in srcs]
+
+            def one(pair):
+                subprocess.check_call([*common, "-c", pair[0], "-o", pair[1]])
+
+            with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+                list(pool.map(one, zip(srcs, objs)))
+            subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
     return LIB_PATH
 
 
