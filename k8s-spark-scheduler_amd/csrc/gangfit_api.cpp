@@ -1,4 +1,4 @@
-// gangfit_api.cpp.new — the C ABI of libgangfit (include/gangfit.h): context life cycle, options, probes, recorded launch
+// gangfit_api.cpp — the C ABI of libgangfit (include/gangfit.h): context life cycle, options, probes, recorded launch
 // sequences, timers / counters / self-test.  The other entry points live in gangfit_api_{snapshot,fit,worker,group}.cpp
 // (map: gangfit_ctx.h).
 //

@@ -1,5 +1,5 @@
 // gangfit_device.h — shared declarations between the HIP kernels (gangfit_kernels.hip) and the C-ABI host
-// layer (gangfit_api.cpp).  gfx950 / CDNA4 only: wave64, no compatibility paths.
+// layer (gangfit_api*.cpp, gangfit_ctx.h).  gfx950 / CDNA4 only: wave64, no compatibility paths.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -130,7 +130,7 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
                                   uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream,
                                   const IndHostOut* host = nullptr);
 
-// ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gf_worker_* in gangfit_api.cpp)
+// ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gangfit_api_worker.cpp)
 constexpr uint32_t kWorkerRing = 64;
 constexpr int kWorkerWaves = 16;             // wavefronts per workgroup of the worker kernel (one workgroup fills a CU)
 constexpr uint32_t kWorkerCountStride = 64;  // words between two tickets' counters: one 256-byte line (one memory channel) each  // tickets in flight at most (host side waits for ticket t - kWorkerRing before it posts t)
