@@ -730,12 +730,8 @@ def main():
                 l_med = lat(host_batch)
                 try:  # where the last blocking call spent its time (host clock, gf_call_phases)
                     phases = ctx.call_phases()
-                    ctx.set_option("host_flag", 0)  # the same call waiting for its stream instead of polling the completion word
-                    l_med_wait = lat(host_batch)
-                    phases_wait = ctx.call_phases()
-                    ctx.set_option("host_flag", 1)
                 except Exception:
-                    phases = phases_wait = l_med_wait = None
+                    phases = None
                 # ... and ONE application per call (DoesPodExceedClusterCapacity for a single pod, gf_spark_binpack)
                 k1 = int(happs[0]["k"])
 
@@ -755,8 +751,6 @@ def main():
                 wk = {"ms_per_batch": w_med * 1e3, "decisions_per_s": len(happs) / w_med,
                       "gf_fit_batch_ms_per_batch_same_protocol": l_med * 1e3,
                       "gf_fit_batch_phases_us": phases,
-                      "gf_fit_batch_stream_wait_ms_per_batch": (l_med_wait * 1e3) if l_med_wait else None,
-                      "gf_fit_batch_stream_wait_phases_us": phases_wait,
                       "one_application_per_call_us": {"gf_worker_fit": w_one * 1e6, "gf_fit_batch": l_one * 1e6},
                       "results_equal": bool(np.array_equal(wres, hres) and np.array_equal(wexec, hexec)),
                       "protocol": "median of 300 blocking calls, one after the other, worker resident",
@@ -777,11 +771,10 @@ def main():
                             "value": len(happs) / ((wkd.get("gf_fit_batch_ms_per_batch_same_protocol") or e2e_wall / e2e_steps * 1e3) * 1e-3),
                             "phases_us": wkd.get("gf_fit_batch_phases_us"),
                             "phases_are": "host clock: stage = validate + copy 1 000 records into pinned memory; launch = the launch call; "
-                                          "wait = launch returned -> the completion word the kernel's last wavefront writes to pinned "
-                                          "memory (records read and answers written over the host link inside it); copy_out = 64 KB to "
-                                          "the caller's arrays",
-                            "stream_wait_instead_of_completion_word_us_per_call":
-                                (wkd.get("gf_fit_batch_stream_wait_ms_per_batch") * 1e3) if wkd.get("gf_fit_batch_stream_wait_ms_per_batch") else None,
+                                          "wait = the stream (dispatch, the kernel reading the records from and writing the answers to "
+                                          "pinned host memory over the host link, its completion signal); copy_out = 64 KB to the "
+                                          "caller's arrays.  Round 4 measured a kernel that announces its own completion in pinned "
+                                          "memory instead (write-through answers + a polled word): 30.3 us per call against 23.3 — removed",
                             "through_gf_worker_fit_us_per_call": (wkd.get("ms_per_batch") * 1e3) if wkd.get("ms_per_batch") else None,
                             "one_application_per_call_us": wkd.get("one_application_per_call_us")})
         except Exception as e:

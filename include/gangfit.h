@@ -161,8 +161,6 @@ const char *gf_last_error(gf_ctx *ctx);
  *   "fifo_generic"           1: FIFO chains run on the wide / generic global-memory kernels only
  *   "lds_budget"             bytes of LDS one workgroup may use (<= the device's): smaller table fronts, global tails
  *   "minfrag_matrix", "minfrag_hist", "sparse_gpu", "zero_copy"   0 disables the respective structure
- *   "host_flag"              0: a lone blocking independent batch waits for its stream instead of polling the completion
- *                            word its launch writes to pinned memory
  *   "snapshot_finalize_host" 1: gf_snapshot_build* builds the slot tables through gf_orders_set on the host
  *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
  *   "sort_fault"             1: fault injection — the priority sort's grid barrier cannot complete; gf_snapshot_build* then
@@ -483,7 +481,8 @@ int gf_worker_stop(gf_ctx *ctx);
 int gf_worker_stats(gf_ctx *ctx, uint64_t out[4]);
 /* Measurement helper: where the last blocking gf_fit_batch(GF_MODE_INDEPENDENT) of a plain packer on the zero-copy path spent
  * its time on the host's clock, in microseconds: [0] validation + staging of the records into pinned memory, [1] the launch
- * call, [2] from the launch's return to the completion word (or the stream wait), [3] copying results and placements to the
+ * call, [2] the wait for the stream (dispatch, the kernel — which reads the records from and writes the answers to pinned host
+ * memory —, its completion signal), [3] copying results and placements to the
  * caller's arrays, [4] the whole call. */
 int gf_call_phases(gf_ctx *ctx, double out_us[5]);
 /* Measurement helper (bench.py's roofline): HIP events on the worker's own stream around its launch.  *ms = how long the

@@ -86,44 +86,43 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
     if (!out) return GF_ERR_INVALID;
     *out = nullptr;
     if (n_dev > 1) {
-        // One context over several devices: sub-context i owns range i of n_dev of the priority order.  A device id may
-        // repeat (several shards on one GPU: how the path is exercised on a one-GPU box).
+        // One context over several devices: the priority order is cut into n_dev ranges (shards), id i names the device that
+        // scans range i.  One sub-context per DEVICE: a device whose id repeats (how the path is exercised on a one-GPU box)
+        // hosts several shards in one sub-context — one snapshot copy, one stream, one launch per step with a grid row per
+        // shard.  GANGFIT_TEST_GROUP_SPLIT=1 (tests) gives every listed id a sub-context, a stream and a submitting thread
+        // of its own instead: a repeated id then exercises what distinct devices exercise — events between streams, the
+        // host-side barriers of the submitting threads, pushes into several gathered tables, the pull of the placements.
         if (!device_ids || n_dev > (int)gangfit::kMaxGroupDevices) return GF_ERR_INVALID;
+        const bool split = std::getenv("GANGFIT_TEST_GROUP_SPLIT") != nullptr;
         gf_ctx* g = new (std::nothrow) gf_ctx();
         if (!g) return GF_ERR_HIP;
         g->device = device_ids[0];
+        g->g_total_shards = (uint32_t)n_dev;
         for (int i = 0; i < n_dev; ++i) {
-            gf_ctx* sub = nullptr;
-            const int rc = gf_init(&device_ids[i], 1, &sub);
-            if (rc != GF_OK) {
-                gf_destroy(g);
-                return rc;
-            }
-            sub->shard = (uint32_t)i;
-            sub->n_shards = (uint32_t)n_dev;
-            // what the other devices store into / read from lives in fine-grained memory: a posted peer store must not depend
-            // on what a kernel boundary does to this device's caches
-            sub->g_part_all.fine = sub->g_drv_all.fine = sub->g_exec2.fine = true;
-            // Shards on ONE device (a repeated id: how the path runs on a one-GPU box) share a stream: separate streams buy them
-            // nothing there, and with sixteen hardware queues every cross-stream event wait of the exchanges is a real
-            // cross-queue barrier (eight shards: 1.0 ms per headline batch with eight streams, 0.35 with the runtime's four
-            // queues).  Shards on different devices keep their own.
-            for (gf_ctx* earlier : g->group)
-                if (earlier->device == sub->device) {
-                    (void)hipSetDevice(sub->device);
-                    (void)hipStreamDestroy(sub->stream);
-                    sub->stream = earlier->stream;
-                    sub->stream_borrowed = true;
-                    break;
+            gf_ctx* host = nullptr;
+            if (!split)
+                for (gf_ctx* earlier : g->group)
+                    if (earlier->device == device_ids[i]) host = earlier;
+            if (host == nullptr) {
+                const int rc = gf_init(&device_ids[i], 1, &host);
+                if (rc != GF_OK) {
+                    gf_destroy(g);
+                    return rc;
                 }
-            g->group.push_back(sub);
-            g->g_devices.push_back(device_ids[i]);
-            bool ok = hipSetDevice(sub->device) == hipSuccess;
-            for (hipEvent_t& e : sub->g_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            if (!ok) {
-                gf_destroy(g);
-                return GF_ERR_HIP;
+                host->n_shards = (uint32_t)n_dev;
+                // what the other devices store into / read from lives in fine-grained memory: a posted peer store must not
+                // depend on what a kernel boundary does to this device's caches
+                host->g_part_all.fine = host->g_drv_all.fine = host->g_exec2.fine = true;
+                g->group.push_back(host);
+                g->g_devices.push_back(device_ids[i]);
+                bool ok = hipSetDevice(host->device) == hipSuccess;
+                for (hipEvent_t& e : host->g_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+                if (!ok) {
+                    gf_destroy(g);
+                    return GF_ERR_HIP;
+                }
             }
+            host->my_shards.push_back((uint32_t)i);
         }
         bool peers = std::getenv("GANGFIT_TEST_NO_PEER") == nullptr;  // (fault injection of host_test: "no device can reach another")
         for (int i = 0; i < n_dev && peers; ++i)  // every shard's kernels write into / read from every other shard's buffers
@@ -148,6 +147,7 @@ int gf_init(const int* device_ids, int n_dev, gf_ctx** out) {
             return rc;
         }
         g->info = g->group[0]->info;
+        if (g->group.size() > 1) g->g_pool = new (std::nothrow) gfapi::GroupPool((uint32_t)g->group.size());
         *out = g;
         return GF_OK;
     }
@@ -232,6 +232,8 @@ int gf_ctx_view(gf_ctx* parent, gf_ctx** out) {
 void gf_destroy(gf_ctx* ctx) {
     if (!ctx) return;
     if (!ctx->group.empty()) {
+        delete ctx->g_pool;
+        ctx->g_pool = nullptr;
         for (void* c : ctx->g_comms)
             if (c) (void)rccl().CommDestroy(c);
         ctx->g_comms.clear();
@@ -272,8 +274,6 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_napps.release();
     ctx->chain.d_ckpt.release();
     ctx->d_flag32.release();
-    ctx->d_ind_done.release();
-    ctx->h_ind_flag.release();
     ctx->d_sortwork.release();
     ctx->d_wide_needed.release();
     ctx->d_capmat.release();
@@ -391,6 +391,8 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
             ctx->g_comms.clear();
             ctx->g_verified_epoch = 0;  // the other exchange proves itself on its first batch
             if (value == 0) return GF_OK;
+            if (ctx->g_total_shards != ctx->group.size())
+                return fail(ctx, GF_ERR_UNSUPPORTED, "a device hosts several shards: the RCCL exchange wants one rank per physical device");
             if (!rccl().load()) return fail(ctx, GF_ERR_UNSUPPORTED, "librccl.so cannot be loaded");
             std::vector<void*> comms(ctx->group.size(), nullptr);
             const int rc = rccl().CommInitAll(comms.data(), (int)comms.size(), ctx->g_devices.data());
@@ -422,8 +424,6 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->sparse_gpu = value != 0;
     } else if (k == "zero_copy") {
         ctx->zero_copy = value != 0;
-    } else if (k == "host_flag") {
-        ctx->host_flag = value != 0;
     } else if (k == "snapshot_finalize_host") {
         ctx->snapshot_finalize_on_device = value == 0;
     } else if (k == "sort_fault") {
@@ -479,7 +479,7 @@ int gf_shard_count(gf_ctx* ctx) {
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (ctx->group.empty() || ctx->g_shard_off) return 1;
-    return (int)ctx->group.size();
+    return (int)ctx->g_total_shards;
 }
 
 int gf_generation(gf_ctx* ctx, uint64_t out[3]) {

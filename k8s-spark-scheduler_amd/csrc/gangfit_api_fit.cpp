@@ -539,7 +539,7 @@ void chain_commit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, uint64_t total_k, 
 // run (nullable): gf_fit_batch's plan for a FIFO chain; d_apps / d_results are always the arrays of the WHOLE queue.
 int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* h_apps, const gf_app* d_apps,
            gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_failed, hipStream_t stream,
-           const ChainRun* run = nullptr, const gangfit::IndHostOut* host_out = nullptr) {
+           const ChainRun* run = nullptr) {
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
     const uint64_t half = exec_nodes_len + 1;
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
@@ -580,7 +580,7 @@ int launch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_ap
     if (mode == GF_MODE_INDEPENDENT) {
         if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;
         GF_HIP(ctx, gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps,
-                                                    d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream, host_out));
+                                                    d_results, d_exec_nodes, ctx->d_scratch.ptr, half, stats, stream));
     } else if (mode == GF_MODE_FIFO_CHAIN) {
         gangfit::FifoPlan plan{};
         plan.narrow = ctx->merged && ctx->narrow_ok && !ctx->fifo_generic;
@@ -686,46 +686,11 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         if (da != nullptr && dr != nullptr && de != nullptr) {
             using clk = std::chrono::steady_clock;
             const auto t_staged = clk::now();
-            // the launch announces its own completion in pinned memory (IndHostOut): what a 5 us kernel otherwise waits longest
-            // for is the kernel-end release, the completion signal and the runtime's query
-            gangfit::IndHostOut ho{};
-            bool flagged = ctx->host_flag && !wait_blocking();
-            if (flagged) {
-                if (ctx->d_ind_done.ptr == nullptr) {
-                    const size_t words = (size_t)(gangfit::kIndDoneCounters + 1) * gangfit::kIndDoneStride;
-                    GF_HIP(ctx, ctx->d_ind_done.reserve(words));
-                    GF_HIP(ctx, hipMemsetAsync(ctx->d_ind_done.ptr, 0, words * sizeof(uint32_t), st));
-                    GF_HIP(ctx, ctx->h_ind_flag.reserve(8));
-                    ctx->h_ind_flag.ptr[0] = 0;
-                }
-                flagged = ctx->h_ind_flag.dev != nullptr;
-            }
-            if (flagged) {
-                ho.h_results = static_cast<gf_result*>(dr);
-                ho.h_exec = static_cast<uint32_t*>(de);
-                ho.counters = ctx->d_ind_done.ptr;
-                ho.flag = ctx->h_ind_flag.dev;
-                ho.seq = ++ctx->ind_seq;
-            }
-            const int rc0 = flagged ? launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
-                                             ctx->d_results.ptr, ctx->d_exec.ptr, total_k, ctx->d_failed.ptr, st, nullptr, &ho)
-                                    : launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
-                                             static_cast<gf_result*>(dr), static_cast<uint32_t*>(de), total_k, ctx->d_failed.ptr, st);
+            const int rc0 = launch(ctx, mode, algo, n_apps, ctx->h_apps.ptr, static_cast<const gf_app*>(da),
+                                   static_cast<gf_result*>(dr), static_cast<uint32_t*>(de), total_k, ctx->d_failed.ptr, st);
             if (rc0 != GF_OK) return rc0;
             const auto t_launched = clk::now();
-            bool seen = false;
-            if (flagged) {
-                const unsigned long long* f = ctx->h_ind_flag.ptr;
-                for (uint32_t spins = 0;; ++spins) {
-                    if (__atomic_load_n(f, __ATOMIC_ACQUIRE) == ho.seq) {
-                        seen = true;
-                        break;
-                    }
-                    // (a launch that faults never writes the word: the stream wait below reports it)
-                    if ((spins & 0x3FFu) == 0x3FFu && clk::now() - t_launched > std::chrono::milliseconds(5)) break;
-                }
-            }
-            if (!seen) GF_HIP(ctx, gf_wait_stream(st));
+            GF_HIP(ctx, gf_wait_stream(st));
             const auto t_done = clk::now();
             std::memcpy(results, ctx->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
             if (total_k) std::memcpy(exec_nodes, ctx->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));

@@ -21,10 +21,70 @@ int shard_ready(gf_ctx* ctx, gf_algo algo, gangfit::ShardRange* r) {
     return GF_OK;
 }
 
+// ---- the submitting threads (GroupPool, gangfit_ctx.h)
+GroupPool::GroupPool(uint32_t n_devices) : parties(n_devices) {
+    for (uint32_t d = 1; d < n_devices; ++d) threads.emplace_back([this, d] { worker(d); });
+}
+GroupPool::~GroupPool() {
+    {
+        std::lock_guard<std::mutex> l(m);
+        quit = true;
+        generation.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+    for (std::thread& t : threads) t.join();
+}
+void GroupPool::worker(uint32_t d) {
+    uint64_t seen = 0;
+    for (;;) {
+        // a short spin (batches that follow each other find the thread awake), then the condition variable
+        const auto t0 = std::chrono::steady_clock::now();
+        while (generation.load(std::memory_order_acquire) == seen) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return generation.load(std::memory_order_acquire) != seen; });
+                break;
+            }
+        }
+        seen = generation.load(std::memory_order_acquire);
+        if (quit) return;
+        (*job)(d);
+        remaining.fetch_sub(1, std::memory_order_acq_rel);
+    }
+}
+void GroupPool::run(const std::function<void(uint32_t)>& j) {
+    job = &j;
+    remaining.store(parties - 1, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> l(m);
+        generation.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+    j(0);
+    while (remaining.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+}
+void GroupPool::barrier() {
+    const uint32_t gen = bar_gen.load(std::memory_order_acquire);
+    if (bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == parties) {
+        bar_count.store(0, std::memory_order_relaxed);
+        bar_gen.fetch_add(1, std::memory_order_release);
+    } else {
+        uint32_t spins = 0;
+        while (bar_gen.load(std::memory_order_acquire) == gen)
+            if ((++spins & 0xFFFu) == 0) std::this_thread::yield();
+    }
+}
+
 // gf_fit_batch on a multi-device context.  Independent batches of the two plain packers are node-range sharded across the
-// sub-contexts (the four steps of gangfit_shard.inc with the three exchanges done by peer access,
-// see shard_push_kernel / shard_reduce_pull_kernel); everything else — FIFO chains (each commit must be visible to the next
-// scan), the zone-aware and minimal-fragmentation packers, orders that do not merge — runs on the first device.
+// sub-contexts (the four steps of gangfit_shard.inc with the three exchanges done by peer access — the
+// producing kernels write straight into every device's gathered table, shard_reduce_pull_kernel collects the placements — or
+// by RCCL); everything else — FIFO chains (each commit must be visible to the next scan), the zone-aware and
+// minimal-fragmentation packers, orders that do not merge — runs on the first device.
+//
+// One sub-context = one DEVICE and the shards it hosts: per step ONE launch per device (a grid row per hosted shard), one
+// upload of the records, one gathered table and one placement buffer per device.  With several devices device d's calls are
+// issued by submitting thread d (GroupPool); between the steps the threads meet at a host barrier, because stream t may only
+// be told to wait for event s once event s has been recorded.
 int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* apps, gf_result* results,
                     uint32_t* exec_nodes, uint64_t exec_nodes_cap, int32_t* chain_failed_at) {
     std::lock_guard<std::recursive_mutex> glock(g->mu);
@@ -39,7 +99,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
     }
     if (!apps || !results) return fail(g, GF_ERR_INVALID, "apps/results must not be NULL");
     if (chain_failed_at) *chain_failed_at = -1;
-    const uint32_t S = (uint32_t)g->group.size();
+    const uint32_t D = (uint32_t)g->group.size();  // devices (sub-contexts)
+    const uint32_t S = g->g_total_shards;          // shards of the priority order
     GF_HIP(g, hipSetDevice(first->device));
     GF_HIP(g, g->h_apps.reserve(n_apps));
     uint64_t total_k = 0;
@@ -60,124 +121,162 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
     const uint64_t half = total_k + 1;
     GF_HIP(g, g->h_results.reserve(n_apps));
     GF_HIP(g, g->h_exec.reserve(total_k + 1));
-    // ---- buffers and the app table on every device
-    gangfit::ShardRange range[gangfit::kMaxGroupDevices];
+    // ---- buffers on every device (growth only: no-ops from the second batch of a size on) and what each device's kernels
+    //      must know about the others: every gathered table, every placement buffer
+    gangfit::ShardSet set[gangfit::kMaxGroupDevices];
     gangfit::PeerPtrs part_all{}, drv_all{}, exec_others{};
-    for (uint32_t s = 0; s < S; ++s) {
-        gf_ctx* c = g->group[s];
+    for (uint32_t d = 0; d < D; ++d) {
+        gf_ctx* c = g->group[d];
         GF_HIP(g, hipSetDevice(c->device));
-        if (const int rc = shard_ready(c, algo, &range[s]); rc != GF_OK) {
-            g->err = c->err;
-            return rc;
+        set[d] = gangfit::ShardSet{};
+        set[d].n_shards = S;
+        for (uint32_t sh : c->my_shards) {
+            c->shard = sh;
+            c->n_shards = S;
+            gangfit::ShardRange r{};
+            if (const int rc = shard_ready(c, algo, &r); rc != GF_OK) {
+                g->err = c->err;
+                return rc;
+            }
+            const uint32_t q = set[d].n++;
+            set[d].c_lo[q] = r.c_lo;
+            set[d].c_hi[q] = r.c_hi;
+            set[d].shard[q] = sh;
         }
         GF_HIP(g, c->d_apps.reserve(n_apps));
         GF_HIP(g, c->d_results.reserve(n_apps));
-        GF_HIP(g, c->g_part_loc.reserve(n_apps));
-        GF_HIP(g, c->g_drv_loc.reserve(n_apps));
+        GF_HIP(g, c->g_part_loc.reserve((size_t)c->my_shards.size() * n_apps));
+        GF_HIP(g, c->g_drv_loc.reserve((size_t)c->my_shards.size() * n_apps));
         GF_HIP(g, c->g_part_all.reserve((size_t)S * n_apps));
         GF_HIP(g, c->g_drv_all.reserve((size_t)S * n_apps));
         GF_HIP(g, c->g_exec2.reserve(2 * half));
-        GF_HIP(g, hipMemcpyAsync(c->d_apps.ptr, g->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, c->stream));
-        part_all.p[s] = c->g_part_all.ptr;
-        drv_all.p[s] = c->g_drv_all.ptr;
-        if (s > 0) exec_others.p[exec_others.n++] = c->g_exec2.ptr;
+        part_all.p[d] = c->g_part_all.ptr;
+        drv_all.p[d] = c->g_drv_all.ptr;
+        if (d > 0) exec_others.p[exec_others.n++] = c->g_exec2.ptr;
     }
-    part_all.n = drv_all.n = S;
-    const bool use_rccl = g->g_comms.size() == S;
-    bool several_streams = false;  // (every shard on one device: one stream, nothing to order with events)
-    for (uint32_t s = 1; s < S; ++s) several_streams = several_streams || g->group[s]->stream != first->stream;
-    // RCCL exchange: every device's collective is enqueued on its own stream inside one group call; the library orders the
-    // streams against each other, so the event fan-out of the peer-store path is not needed
-    auto rccl_all_gather = [&](auto loc, auto all, size_t bytes_each) -> int {
-        if (rccl().GroupStart() != 0) return -1;
-        int bad = 0;
-        for (uint32_t s2 = 0; s2 < S; ++s2) {
-            gf_ctx* c = g->group[s2];
-            if (hipSetDevice(c->device) != hipSuccess) bad = 1;
-            bad |= rccl().AllGather(loc(c), all(c), bytes_each, Rccl::kChar, g->g_comms[s2], c->stream);
-        }
-        return rccl().GroupEnd() | bad;
+    part_all.n = drv_all.n = D;
+    const bool use_rccl = g->g_comms.size() == D && D == S;
+    const gangfit::PeerPtrs no_peers{};
+    std::vector<int> rc_of(D, GF_OK);
+    auto hip_ok = [&](uint32_t d, hipError_t e, const char* what) {
+        if (e == hipSuccess || rc_of[d] != GF_OK) return e == hipSuccess;
+        rc_of[d] = fail(g->group[d], GF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        return false;
     };
-    auto everyone_waits = [&](int which) -> hipError_t {  // stream t continues only behind event `which` of every other shard
-        // (S (S - 1) stream waits; joining the events on one stream first — 2 S + 1 calls — measured slower with eight shards on
-        //  one device: the extra hop costs more than the calls it saves)
-        for (uint32_t t = 0; t < S; ++t) {
-            hipError_t e = hipSetDevice(g->group[t]->device);
-            for (uint32_t s = 0; s < S && e == hipSuccess; ++s)
-                if (s != t && g->group[s]->stream != g->group[t]->stream)  // (shards on one device share a stream: already ordered)
-                    e = hipStreamWaitEvent(g->group[t]->stream, g->group[s]->g_ev[which], 0);
-            if (e != hipSuccess) return e;
+#define GF_STEP(d, call) hip_ok((d), (call), #call)
+    // the steps of ONE device, each issued on that device's stream by whichever thread runs them
+    auto step_partials = [&](uint32_t d) {
+        gf_ctx* c = g->group[d];
+        if (!GF_STEP(d, hipSetDevice(c->device))) return;
+        if (!GF_STEP(d, hipMemcpyAsync(c->d_apps.ptr, g->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, c->stream))) return;
+        if (!GF_STEP(d, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), set[d], n_apps, c->d_apps.ptr, c->g_part_loc.ptr,
+                                                       use_rccl ? no_peers : part_all, c->stream)))
+            return;
+        if (g->g_fault == 2 && d > 0 && !use_rccl) {  // fault injection: this device's capacity sums arrive as zeros everywhere
+            for (uint32_t t = 0; t < D; ++t)
+                for (uint32_t sh : c->my_shards)
+                    (void)GF_STEP(d, hipMemsetAsync(static_cast<gf_shard_partial*>(part_all.p[t]) + (size_t)sh * n_apps, 0,
+                                                   (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
+        } else if (g->g_fault == 2 && d > 0) {
+            (void)GF_STEP(d, hipMemsetAsync(c->g_part_loc.ptr, 0, (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
         }
-        return hipSuccess;
+        if (D > 1 && !use_rccl) (void)GF_STEP(d, hipEventRecord(c->g_ev[0], c->stream));
     };
-    // ---- step 1: per-range capacity sums, gathered everywhere
-    for (uint32_t s = 0; s < S; ++s) {
-        gf_ctx* c = g->group[s];
-        GF_HIP(g, hipSetDevice(c->device));
-        GF_HIP(g, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_loc.ptr, c->stream));
-        if (g->g_fault == 2 && s > 0)  // fault injection: this shard's capacity sums arrive as zeros
-            GF_HIP(g, hipMemsetAsync(c->g_part_loc.ptr, 0, (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
-        if (use_rccl) continue;
-        GF_HIP(g, gangfit::launch_shard_push(c->g_part_loc.ptr, part_all, (size_t)s * n_apps * sizeof(gf_shard_partial),
-                                             (size_t)n_apps * sizeof(gf_shard_partial), c->stream));
-        if (several_streams) GF_HIP(g, hipEventRecord(c->g_ev[0], c->stream));
-    }
+    auto wait_others = [&](uint32_t d, int which) {  // this device's stream continues only behind event `which` of every other
+        gf_ctx* c = g->group[d];
+        for (uint32_t s2 = 0; s2 < D; ++s2)
+            if (s2 != d && !GF_STEP(d, hipStreamWaitEvent(c->stream, g->group[s2]->g_ev[which], 0))) return;
+    };
+    auto step_drivers = [&](uint32_t d) {
+        gf_ctx* c = g->group[d];
+        if (rc_of[d] != GF_OK || !GF_STEP(d, hipSetDevice(c->device))) return;
+        if (D > 1 && !use_rccl) wait_others(d, 0);
+        if (!GF_STEP(d, gangfit::launch_shard_drivers(make_table(c, c->d_snap.ptr), set[d], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
+                                                      c->g_drv_loc.ptr, use_rccl ? no_peers : drv_all, c->stream)))
+            return;
+        if (D > 1 && !use_rccl) (void)GF_STEP(d, hipEventRecord(c->g_ev[1], c->stream));
+    };
+    auto step_emit = [&](uint32_t d) {
+        gf_ctx* c = g->group[d];
+        if (rc_of[d] != GF_OK || !GF_STEP(d, hipSetDevice(c->device))) return;
+        if (D > 1 && !use_rccl) wait_others(d, 1);
+        if (!GF_STEP(d, gangfit::launch_shard_emit(algo, make_table(c, c->d_snap.ptr), set[d], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
+                                                   c->g_drv_all.ptr, c->d_results.ptr, c->g_exec2.ptr, half, c->stream)))
+            return;
+        if (D > 1) (void)GF_STEP(d, hipEventRecord(c->g_ev[2], c->stream));
+    };
+    auto step_finish = [&]() {  // the first device only: sum of the slices (each entry written by exactly one shard), finish, D2H
+        if (rc_of[0] != GF_OK || !GF_STEP(0, hipSetDevice(first->device))) return;
+        if (!use_rccl) {
+            for (uint32_t s2 = 1; s2 < D; ++s2)
+                if (!GF_STEP(0, hipStreamWaitEvent(first->stream, g->group[s2]->g_ev[2], 0))) return;
+            if (g->g_fault != 1 && D > 1)  // fault injection: the other devices' placement slices never arrive
+                if (!GF_STEP(0, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream))) return;
+        }
+        if (!GF_STEP(0, gangfit::launch_shard_finish(algo, S, n_apps, first->d_apps.ptr, first->g_part_all.ptr, first->g_drv_all.ptr,
+                                                     first->d_results.ptr, first->g_exec2.ptr, half, first->stream)))
+            return;
+        if (!GF_STEP(0, hipMemcpyAsync(g->h_results.ptr, first->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, first->stream))) return;
+        if (total_k && !GF_STEP(0, hipMemcpyAsync(g->h_exec.ptr, first->g_exec2.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, first->stream))) return;
+        (void)GF_STEP(0, gf_wait_stream(first->stream));
+    };
     if (use_rccl) {
+        // RCCL exchange (one shard per device): every device's collective is enqueued on its own stream inside one group call
+        // issued by THIS thread; the library orders the streams against each other
+        auto rccl_all_gather = [&](auto loc, auto all, size_t bytes_each) -> int {
+            if (rccl().GroupStart() != 0) return -1;
+            int bad = 0;
+            for (uint32_t s2 = 0; s2 < D; ++s2) {
+                gf_ctx* c = g->group[s2];
+                if (hipSetDevice(c->device) != hipSuccess) bad = 1;
+                bad |= rccl().AllGather(loc(c), all(c), bytes_each, Rccl::kChar, g->g_comms[s2], c->stream);
+            }
+            return rccl().GroupEnd() | bad;
+        };
+        for (uint32_t d = 0; d < D; ++d) step_partials(d);
         if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_part_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_part_all.ptr; },
                             (size_t)n_apps * sizeof(gf_shard_partial)) != 0)
             return fail(g, GF_ERR_HIP, "ncclAllGather of the capacity sums failed");
-    } else {
-        if (several_streams) GF_HIP(g, everyone_waits(0));
-    }
-    // ---- step 2: first feasible driver of each range, gathered everywhere
-    for (uint32_t s = 0; s < S; ++s) {
-        gf_ctx* c = g->group[s];
-        GF_HIP(g, hipSetDevice(c->device));
-        GF_HIP(g, gangfit::launch_shard_drivers(make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr, c->g_drv_loc.ptr, c->stream));
-        if (use_rccl) continue;
-        GF_HIP(g, gangfit::launch_shard_push(c->g_drv_loc.ptr, drv_all, (size_t)s * n_apps * sizeof(gf_shard_driver),
-                                             (size_t)n_apps * sizeof(gf_shard_driver), c->stream));
-        if (several_streams) GF_HIP(g, hipEventRecord(c->g_ev[1], c->stream));
-    }
-    if (use_rccl) {
+        for (uint32_t d = 0; d < D; ++d) step_drivers(d);
         if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_drv_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_drv_all.ptr; },
                             (size_t)n_apps * sizeof(gf_shard_driver)) != 0)
             return fail(g, GF_ERR_HIP, "ncclAllGather of the driver records failed");
-    } else {
-        if (several_streams) GF_HIP(g, everyone_waits(1));
-    }
-    // ---- step 3: every shard emits its slice of the placements
-    for (uint32_t s = 0; s < S; ++s) {
-        gf_ctx* c = g->group[s];
-        GF_HIP(g, hipSetDevice(c->device));
-        GF_HIP(g, gangfit::launch_shard_emit(algo, make_table(c, c->d_snap.ptr), range[s], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
-                                             c->g_drv_all.ptr, c->d_results.ptr, c->g_exec2.ptr, half, c->stream));
-        if (several_streams) GF_HIP(g, hipEventRecord(c->g_ev[2], c->stream));
-    }
-    // ---- step 4 on the first device only: sum of the slices (each entry written by exactly one shard), finish, D2H
-    if (use_rccl) {  // the reduction north_star names: sum of the placement slices onto the first device, over xGMI
+        for (uint32_t d = 0; d < D; ++d) step_emit(d);
+        // the reduction north_star names: sum of the placement slices onto the first device, over xGMI
         if (rccl().GroupStart() != 0) return fail(g, GF_ERR_HIP, "ncclGroupStart failed");
         int bad = 0;
-        for (uint32_t s = 0; s < S; ++s) {
-            gf_ctx* c = g->group[s];
+        for (uint32_t d = 0; d < D; ++d) {
+            gf_ctx* c = g->group[d];
             GF_HIP(g, hipSetDevice(c->device));
-            bad |= rccl().Reduce(c->g_exec2.ptr, first->g_exec2.ptr, (size_t)(2 * half), Rccl::kUint32, Rccl::kSum, 0, g->g_comms[s], c->stream);
+            bad |= rccl().Reduce(c->g_exec2.ptr, first->g_exec2.ptr, (size_t)(2 * half), Rccl::kUint32, Rccl::kSum, 0, g->g_comms[d], c->stream);
         }
         if ((rccl().GroupEnd() | bad) != 0) return fail(g, GF_ERR_HIP, "ncclReduce of the placements failed");
-        GF_HIP(g, hipSetDevice(first->device));
+        step_finish();
+    } else if (D == 1 || g->g_pool == nullptr) {
+        for (uint32_t d = 0; d < D; ++d) step_partials(d);
+        for (uint32_t d = 0; d < D; ++d) step_drivers(d);
+        for (uint32_t d = 0; d < D; ++d) step_emit(d);
+        step_finish();
     } else {
-        GF_HIP(g, hipSetDevice(first->device));
-        for (uint32_t s = 1; s < S; ++s)
-            if (g->group[s]->stream != first->stream) GF_HIP(g, hipStreamWaitEvent(first->stream, g->group[s]->g_ev[2], 0));
-        if (g->g_fault != 1)  // fault injection: the other shards' placement slices never arrive
-            GF_HIP(g, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream));
+        // one submitting thread per device; a host barrier behind every step that records an event another device waits for
+        GroupPool& pool = *g->g_pool;
+        const std::function<void(uint32_t)> job = [&](uint32_t d) {
+            step_partials(d);
+            pool.barrier();
+            step_drivers(d);
+            pool.barrier();
+            step_emit(d);
+            pool.barrier();
+            if (d == 0) step_finish();
+        };
+        pool.run(job);
     }
-    GF_HIP(g, gangfit::launch_shard_finish(algo, S, n_apps, first->d_apps.ptr, first->g_part_all.ptr, first->g_drv_all.ptr,
-                                           first->d_results.ptr, first->g_exec2.ptr, half, first->stream));
-    GF_HIP(g, hipMemcpyAsync(g->h_results.ptr, first->d_results.ptr, (size_t)n_apps * sizeof(gf_result), hipMemcpyDeviceToHost, first->stream));
-    if (total_k)
-        GF_HIP(g, hipMemcpyAsync(g->h_exec.ptr, first->g_exec2.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, first->stream));
-    GF_HIP(g, gf_wait_stream(first->stream));
+#undef GF_STEP
+    for (uint32_t d = 0; d < D; ++d)
+        if (rc_of[d] != GF_OK) {
+            g->err = g->group[d]->err;
+            return rc_of[d];
+        }
     std::memcpy(results, g->h_results.ptr, (size_t)n_apps * sizeof(gf_result));
     if (total_k) std::memcpy(exec_nodes, g->h_exec.ptr, (size_t)total_k * sizeof(uint32_t));
     // ---- self-check: the first sharded batch on every newly installed snapshot is also answered by the first device alone.
@@ -235,7 +334,8 @@ int gf_shard_partials_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_a
     const int rc = shard_ready(ctx, algo, &r);
     if (rc != GF_OK) return rc;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    GF_HIP(ctx, gangfit::launch_shard_partials(algo, make_table(ctx, ctx->d_snap.ptr), r, n_apps, d_apps, d_out, st));
+    GF_HIP(ctx, gangfit::launch_shard_partials(algo, make_table(ctx, ctx->d_snap.ptr), gangfit::shard_set_of(r), n_apps, d_apps, d_out,
+                                               gangfit::PeerPtrs{}, st));
     return GF_OK;
 }
 
@@ -250,7 +350,8 @@ int gf_shard_drivers_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_ap
     const int rc = shard_ready(ctx, algo, &r);
     if (rc != GF_OK) return rc;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    GF_HIP(ctx, gangfit::launch_shard_drivers(make_table(ctx, ctx->d_snap.ptr), r, n_apps, d_apps, d_all_partials, d_out, st));
+    GF_HIP(ctx, gangfit::launch_shard_drivers(make_table(ctx, ctx->d_snap.ptr), gangfit::shard_set_of(r), n_apps, d_apps, d_all_partials,
+                                              d_out, gangfit::PeerPtrs{}, st));
     return GF_OK;
 }
 
@@ -266,7 +367,7 @@ int gf_shard_emit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* 
     const int rc = shard_ready(ctx, algo, &r);
     if (rc != GF_OK) return rc;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    GF_HIP(ctx, gangfit::launch_shard_emit(algo, make_table(ctx, ctx->d_snap.ptr), r, n_apps, d_apps, d_all_partials,
+    GF_HIP(ctx, gangfit::launch_shard_emit(algo, make_table(ctx, ctx->d_snap.ptr), gangfit::shard_set_of(r), n_apps, d_apps, d_all_partials,
                                            d_all_drivers, d_results, d_exec2, half, st));
     return GF_OK;
 }

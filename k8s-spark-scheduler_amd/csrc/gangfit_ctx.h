@@ -17,7 +17,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <shared_mutex>
@@ -184,6 +186,31 @@ inline Rccl& rccl() {
 using gfapi::DeviceBuf;
 using gfapi::PinnedBuf;
 
+namespace gfapi {
+// The submitting threads of a multi-device context (gangfit_api_group.cpp): a sharded batch is ~6 runtime calls per device and
+// three points where every device's stream must wait for every other device's event.  One host thread issuing all of it is
+// ~50 serial runtime calls per batch on an 8-GPU box; here device d's calls are issued by thread d (the caller's thread is
+// device 0's), all of them meeting at host-side barriers between the steps — an event must have been RECORDED before another
+// stream can be told to wait for it.  Threads park on a condition variable between batches after a short spin.
+struct GroupPool {
+    explicit GroupPool(uint32_t n_devices);
+    ~GroupPool();
+    void run(const std::function<void(uint32_t)>& job);  // job(d) on every device's thread; returns when all have returned
+    void barrier();                                      // called from inside job by EVERY device, the same number of times
+    uint32_t parties;
+private:
+    void worker(uint32_t d);
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<uint32_t> remaining{0};
+    std::atomic<uint32_t> bar_count{0}, bar_gen{0};
+    const std::function<void(uint32_t)>* job = nullptr;
+    bool quit = false;
+};
+}  // namespace gfapi
+
 struct gf_ctx {
     std::recursive_mutex mu;  // recursive: gf_snapshot_build installs its result through the public setters
     std::mutex seq_m;         // gf_ctx_lock / gf_ctx_unlock: a flag, not a held mutex, so any thread may release it
@@ -191,7 +218,7 @@ struct gf_ctx {
     bool seq_held = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    bool stream_borrowed = false;  // a shard of a multi-device context on a device an earlier shard is on: it uses that one's stream
+    bool stream_borrowed = false;  // (unused since the shards of one device live in ONE sub-context; kept for gf_destroy's symmetry)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // The resident worker of the independent batch (gf_worker_*; gangfit_worker.inc).
     struct Worker {
@@ -257,12 +284,6 @@ struct gf_ctx {
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
     bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
-    // a lone blocking independent batch announces its own completion in pinned memory (gangfit::IndHostOut): the caller polls a
-    // word instead of waiting for the stream
-    bool host_flag = true;         // option "host_flag" = 0: gf_fit_batch waits for the stream as before
-    DeviceBuf<uint32_t> d_ind_done;             // arrival counters, all zero between launches
-    PinnedBuf<unsigned long long> h_ind_flag;   // [0] = sequence number of the last batch that announced itself
-    uint64_t ind_seq = 0;
     double call_phase_us[5] = {0, 0, 0, 0, 0};  // last gf_fit_batch on the zero-copy path: stage | launch | wait | copy out | total
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (chain_prologue_kernel)
@@ -344,7 +365,10 @@ struct gf_ctx {
 
     // ---- multi-device context (gf_init with n_dev > 1): this object only routes; one sub-context per device id does the
     //      work and owns shard `shard` of `n_shards` of the priority order.  The g_* members live in the sub-contexts.
-    std::vector<gf_ctx*> group;
+    std::vector<gf_ctx*> group;               // one sub-context per DEVICE (per listed id with GANGFIT_TEST_GROUP_SPLIT=1)
+    std::vector<uint32_t> my_shards;          // (in a sub-context) the shards — ranges of the priority order — this device scans
+    uint32_t g_total_shards = 0;              // (in the routing object) the ids gf_init was given = shards of the order
+    gfapi::GroupPool* g_pool = nullptr;       // (in the routing object) one submitting thread per device but the first
     DeviceBuf<gf_shard_partial> g_part_loc, g_part_all;  // this shard's records | [n_shards][n_apps] gathered
     DeviceBuf<gf_shard_driver> g_drv_loc, g_drv_all;
     DeviceBuf<uint32_t> g_exec2;                         // 2 * half: placements (node + 1) | capacities

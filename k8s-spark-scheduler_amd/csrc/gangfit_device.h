@@ -113,22 +113,9 @@ struct ScanStats {
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).
-// host (nullable): the answers of a lone blocking batch go straight to device-mapped pinned HOST memory as write-through stores
-// and the launch announces its own completion there — the caller polls `flag` for `seq` instead of waiting for the stream
-// (gf_fit_batch; the kernel-end release, the completion signal and the runtime's query are what a 5 us launch waits longest for).
-struct IndHostOut {
-    gf_result* h_results;      // [n_apps], device address of pinned host memory
-    uint32_t* h_exec;          // [sum of k]
-    uint32_t* counters;        // device memory, kIndDoneCounters + 1 words kIndDoneStride apart, all zero between launches
-    unsigned long long* flag;  // pinned host word (device address): receives seq when every answer has left
-    unsigned long long seq;
-};
-constexpr uint32_t kIndDoneCounters = 16;  // first-level arrival counters: one memory channel each
-constexpr uint32_t kIndDoneStride = 64;    // uint32 words between two counters (256 bytes)
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream,
-                                  const IndHostOut* host = nullptr);
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream);
 
 // ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gangfit_api_worker.cpp)
 constexpr uint32_t kWorkerRing = 64;
@@ -317,33 +304,49 @@ hipError_t launch_node_efficiencies(bool reserve_execs, const EffTables& eff_by_
                                     const gf_app* d_app, const gf_result* d_result, const uint32_t* d_exec_nodes,
                                     int64_t* d_reserved, double* d_eff_out, hipStream_t stream);
 
-// Node-range sharding of an independent batch (gangfit_shard.inc): this GPU owns the 64-slot
-// chunks [c_lo, c_hi) of the merged slot order.
+// Node-range sharding of an independent batch (gangfit_shard.inc): a GPU owns one or more ranges
+// [c_lo, c_hi) of 64-slot chunks of the merged slot order — one per shard it hosts (one shard per device on a real box; a
+// repeated device id, the one-GPU stand-in, makes one device host several: its kernels then run ONE launch per step with a
+// grid row per hosted shard, one app upload, one gathered table and one placement buffer per device).
+constexpr uint32_t kMaxGroupDevices = 16;
 struct ShardRange {
     uint32_t c_lo, c_hi;
     uint32_t shard, n_shards;
 };
-hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
-                                 const gf_app* d_apps, gf_shard_partial* d_out, hipStream_t stream);
-hipError_t launch_shard_drivers(const NodeTable& table, const ShardRange& range, uint32_t n_apps, const gf_app* d_apps,
-                                const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, hipStream_t stream);
-hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
+struct ShardSet {  // the shards one device hosts (grid row q of a step's launch handles entry q)
+    uint32_t n, n_shards;
+    uint32_t c_lo[kMaxGroupDevices], c_hi[kMaxGroupDevices], shard[kMaxGroupDevices];
+};
+inline ShardSet shard_set_of(const ShardRange& r) {
+    ShardSet s{};
+    s.n = 1;
+    s.n_shards = r.n_shards;
+    s.c_lo[0] = r.c_lo;
+    s.c_hi[0] = r.c_hi;
+    s.shard[0] = r.shard;
+    return s;
+}
+// Exchanges of the in-process multi-device context: up to 16 peer pointers by value.  The producing kernels write their
+// 16-byte records straight into row `shard` of EVERY device's gathered table (posted stores over xGMI; dsts.n == 0: into the
+// local array d_out instead, row = grid row — the one-process-per-GPU path and the RCCL exchange gather them afterwards).
+struct PeerPtrs {
+    void* p[kMaxGroupDevices];
+    uint32_t n;
+};
+hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
+                                 const gf_app* d_apps, gf_shard_partial* d_out, const PeerPtrs& dsts, hipStream_t stream);
+hipError_t launch_shard_drivers(const NodeTable& table, const ShardSet& set, uint32_t n_apps, const gf_app* d_apps,
+                                const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, const PeerPtrs& dsts,
+                                hipStream_t stream);
+// (zeroes d_exec2 first; every hosted shard writes its slice of the ONE buffer, row 0 also the results)
+hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
                              const gf_app* d_apps, const gf_shard_partial* d_all_partials,
                              const gf_shard_driver* d_all_drivers, gf_result* d_results, uint32_t* d_exec2, uint64_t half,
                              hipStream_t stream);
 hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps, const gf_app* d_apps,
                                const gf_shard_partial* d_all_partials, const gf_shard_driver* d_all_drivers,
                                const gf_result* d_results, uint32_t* d_exec2, uint64_t half, hipStream_t stream);
-
-// Exchanges of the in-process multi-device context (gangfit_shard.inc): up to 16 peer pointers by value.
-constexpr uint32_t kMaxGroupDevices = 16;
-struct PeerPtrs {
-    void* p[kMaxGroupDevices];
-    uint32_t n;
-};
-// every shard's `bytes` (multiple of 16) at src -> byte offset dst_offset of each pointer in dsts
-hipError_t launch_shard_push(const void* d_src, const PeerPtrs& dsts, size_t dst_offset, size_t bytes, hipStream_t stream);
-// d_dst[i] += sum over srcs of src[i], n uint32 entries
+// d_dst[i] += sum over srcs of src[i], n uint32 entries (only the first device finishes a batch: the all-reduce is a reduce)
 hipError_t launch_shard_reduce_pull(const PeerPtrs& srcs, uint32_t* d_dst, size_t n, hipStream_t stream);
 
 // Placing one executor per request (gangfit_executor.inc): first fit or the minimal-fragmentation choice.

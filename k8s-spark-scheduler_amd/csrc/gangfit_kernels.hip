@@ -1038,48 +1038,20 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // that need more than one round of wavefronts — both records requested together, the second parked in two VGPR lanes while the
 // first is decided, 5 000 wavefronts for config 3 instead of 10 000: 13.0-13.2 us against 11.5 us, profiles/r4a_variants.txt.
 // The second decision starts behind the first one's stores and the kernel drops from seven to five wavefronts per SIMD; removed.)
-//
-// HOST (a lone blocking batch of gf_fit_batch): exec_nodes is private device memory, the placements are copied out — and the
-// 16-byte results written — as write-through stores into device-mapped pinned HOST memory (plain stores to host memory stay in
-// the L2 until the kernel-end release), and the launch announces its own completion: a wavefront drains its stores, the last
-// wavefront of a workgroup adds the workgroup to one of kIndDoneCounters counters (one memory channel each), the arrival that
-// completes a counter adds it to the final one, and the arrival that completes that writes the call's sequence number into a
-// pinned host word the caller polls (the machinery of the resident worker, gangfit_worker.inc).
-template <int ALGO, bool HOST>
+// (Round 4 also measured a variant that sends the answers of a lone blocking batch to pinned host memory as write-through
+// stores and announces its own completion there — arrival counters, a sequence word the caller polls — instead of the stream
+// wait: 30.3 us per blocking 1 000-application call against 23.3 us; 13 000 dword write-through stores over the host link and
+// their acknowledgement cost more than the kernel-end write-back and the completion signal they replace; removed.)
+template <int ALGO>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independent_kernel(
     NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
     uint32_t* __restrict__ exec_nodes, uint32_t* __restrict__ scratch, uint64_t scratch_half,
-    ScanStats* __restrict__ stats, IndHostOut H) {
-    __shared__ uint32_t s_arrived;
+    ScanStats* __restrict__ stats) {
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     const uint32_t n_waves = n_apps;
-    if (HOST) {
-        if (threadIdx.x == 0) s_arrived = 0;
-        __syncthreads();  // (before any wavefront may leave: every wavefront of the workgroup takes part)
-    }
-    // called by every wavefront of the grid in HOST mode, behind its last store
-    auto announce = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's write-through stores are acknowledged
-        if (lane != 0) return;
-        if (atomicAdd(&s_arrived, 1u) + 1u != (uint32_t)kWavesPerBlock) return;  // not the workgroup's last wavefront
-        const uint32_t n_blocks = gridDim.x;
-        const uint32_t ci = blockIdx.x % kIndDoneCounters;
-        const uint32_t expect = n_blocks / kIndDoneCounters + (ci < n_blocks % kIndDoneCounters ? 1u : 0u);  // workgroups on counter ci
-        uint32_t* c1 = H.counters + (size_t)ci * kIndDoneStride;
-        if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != expect) return;
-        __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        const uint32_t used = n_blocks < kIndDoneCounters ? n_blocks : kIndDoneCounters;
-        uint32_t* c2 = H.counters + (size_t)kIndDoneCounters * kIndDoneStride;
-        if (__hip_atomic_fetch_add(c2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != used) return;
-        __hip_atomic_store(c2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(H.flag, H.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    if (a >= n_waves) {
-        if (HOST) announce();
-        return;
-    }
+    if (a >= n_waves) return;
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
@@ -1093,20 +1065,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
         Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
                                                             scratch + scratch_half + app.exec_off, lane, xvis, dvis,
                                                             merged ? &g0 : nullptr, &G);
-        if (HOST) {
-            if (dec.feasible)  // this wavefront's own placements, read back through its L1 / L2 and sent out write-through
-                for (int32_t i = lane; i < app.k; i += kWave)
-                    __hip_atomic_store(H.h_exec + app.exec_off + i, exec_nodes[app.exec_off + i], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
-            if (lane < 2) {  // the 16-byte result as two write-through words
-                if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
-                const unsigned long long lo = (unsigned long long)(uint32_t)(dec.feasible ? 1 : 0) |
-                                              ((unsigned long long)(dec.feasible ? dec.ds_node : GF_NO_NODE) << 32);
-                const unsigned long long hi = (unsigned long long)(dec.feasible ? (uint32_t)app.k : 0u) | (1ull << 32);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(H.h_results + ai) + lane, lane == 0 ? lo : hi,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        } else if (lane == 0) {
+        if (lane == 0) {
             gf_result r;
             r.has_capacity = dec.feasible ? 1 : 0;
             if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
@@ -1121,7 +1080,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
         atomicAdd(&stats->exec_slots_visited, xvis);
         atomicAdd(&stats->driver_slots_visited, dvis);
     }
-    if (HOST) announce();
 }
 
 // ------------------------------------------------------------------------------------------------ FIFO chain
@@ -1688,27 +1646,13 @@ hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseT
 
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, const IndHostOut* host) {
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream) {
     if (n_apps == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
-    if (host != nullptr) {  // a lone blocking batch: one application per wavefront, answers and completion word to pinned host memory
-        const dim3 hgrid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
-#define GF_IND_HOST(ALGO)                                                                                                   \
-    hipLaunchKernelGGL((fit_independent_kernel<ALGO, true>), hgrid, block, 0, stream, table, gpu_view, n_apps, d_apps,     \
-                       d_results, d_exec_nodes, d_scratch, scratch_half, d_stats, *host)
-        if (algo == GF_ALGO_TIGHTLY_PACK)
-            GF_IND_HOST(GF_ALGO_TIGHTLY_PACK);
-        else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
-            GF_IND_HOST(GF_ALGO_MINIMAL_FRAGMENTATION);
-        else
-            GF_IND_HOST(GF_ALGO_DISTRIBUTE_EVENLY);
-#undef GF_IND_HOST
-        return hipGetLastError();
-    }
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
 #define GF_IND(ALGO)                                                                                                        \
-    hipLaunchKernelGGL((fit_independent_kernel<ALGO, false>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,        \
-                       d_results, d_exec_nodes, d_scratch, scratch_half, d_stats, IndHostOut{})
+    hipLaunchKernelGGL((fit_independent_kernel<ALGO>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps, d_results,   \
+                       d_exec_nodes, d_scratch, scratch_half, d_stats)
     if (algo == GF_ALGO_TIGHTLY_PACK)
         GF_IND(GF_ALGO_TIGHTLY_PACK);
     else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
@@ -2105,43 +2049,44 @@ namespace {
 inline dim3 app_grid(uint32_t n_apps) { return dim3((n_apps + kWavesPerBlock - 1) / kWavesPerBlock); }
 }  // namespace
 
-hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
-                                 const gf_app* d_apps, gf_shard_partial* d_out, hipStream_t stream) {
-    if (n_apps == 0) return hipSuccess;
+inline dim3 shard_grid(uint32_t n_apps, const ShardSet& set) { return dim3((n_apps + kWavesPerBlock - 1) / kWavesPerBlock, set.n); }
+
+hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
+                                 const gf_app* d_apps, gf_shard_partial* d_out, const PeerPtrs& dsts, hipStream_t stream) {
+    if (n_apps == 0 || set.n == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_TIGHTLY_PACK>, app_grid(n_apps), block, 0, stream, table,
-                           range.c_lo, range.c_hi, n_apps, d_apps, d_out);
+        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_TIGHTLY_PACK>, shard_grid(n_apps, set), block, 0, stream, table, set,
+                           n_apps, d_apps, d_out, dsts);
     else
-        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, app_grid(n_apps), block, 0, stream, table,
-                           range.c_lo, range.c_hi, n_apps, d_apps, d_out);
+        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, shard_grid(n_apps, set), block, 0, stream, table,
+                           set, n_apps, d_apps, d_out, dsts);
     return hipGetLastError();
 }
 
-hipError_t launch_shard_drivers(const NodeTable& table, const ShardRange& range, uint32_t n_apps, const gf_app* d_apps,
-                                const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, hipStream_t stream) {
-    if (n_apps == 0) return hipSuccess;
-    hipLaunchKernelGGL(shard_drivers_kernel, app_grid(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table, range.c_lo,
-                       range.c_hi, range.n_shards, n_apps, d_apps, d_all_partials, d_out);
+hipError_t launch_shard_drivers(const NodeTable& table, const ShardSet& set, uint32_t n_apps, const gf_app* d_apps,
+                                const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, const PeerPtrs& dsts,
+                                hipStream_t stream) {
+    if (n_apps == 0 || set.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(shard_drivers_kernel, shard_grid(n_apps, set), dim3(kWave * kWavesPerBlock), 0, stream, table, set,
+                       n_apps, d_apps, d_all_partials, d_out, dsts);
     return hipGetLastError();
 }
 
-hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardRange& range, uint32_t n_apps,
+hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
                              const gf_app* d_apps, const gf_shard_partial* d_all_partials,
                              const gf_shard_driver* d_all_drivers, gf_result* d_results, uint32_t* d_exec2, uint64_t half,
                              hipStream_t stream) {
-    if (n_apps == 0) return hipSuccess;
+    if (n_apps == 0 || set.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_exec2, 0, 2 * half * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const dim3 block(kWave * kWavesPerBlock);
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_TIGHTLY_PACK>, app_grid(n_apps), block, 0, stream, table, range.c_lo,
-                           range.c_hi, range.shard, range.n_shards, n_apps, d_apps, d_all_partials, d_all_drivers,
-                           d_results, d_exec2, half);
+        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_TIGHTLY_PACK>, shard_grid(n_apps, set), block, 0, stream, table, set,
+                           n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
     else
-        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, app_grid(n_apps), block, 0, stream, table,
-                           range.c_lo, range.c_hi, range.shard, range.n_shards, n_apps, d_apps, d_all_partials,
-                           d_all_drivers, d_results, d_exec2, half);
+        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, shard_grid(n_apps, set), block, 0, stream, table,
+                           set, n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
     return hipGetLastError();
 }
 
@@ -2186,14 +2131,6 @@ hipError_t launch_narrow_rescale(const int32_t* d_src, int32_t* d_dst, uint32_t 
     const unsigned blocks = (unsigned)((n_all + 255) / 256 < 2048 ? (n_all + 255) / 256 : 2048);
     hipLaunchKernelGGL(narrow_rescale_kernel, dim3(blocks), dim3(256), 0, stream, d_src, d_dst, n_slots, d_cmax_src, d_cmax_dst,
                        n_chunks, factor[0], factor[1], factor[2]);
-    return hipGetLastError();
-}
-
-hipError_t launch_shard_push(const void* d_src, const PeerPtrs& dsts, size_t dst_offset, size_t bytes, hipStream_t stream) {
-    const size_t n16 = bytes / 16;
-    if (n16 == 0 || dsts.n == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
-    hipLaunchKernelGGL(shard_push_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)d_src, dsts, dst_offset / 16, n16);
     return hipGetLastError();
 }
 

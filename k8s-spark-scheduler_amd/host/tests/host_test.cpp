@@ -1106,8 +1106,61 @@ static void TestMultiDeviceContext() {
                gf_orders_set(c, order.data(), n, order.data(), n) == GF_OK &&
                gf_fit_batch(c, GF_MODE_INDEPENDENT, algo, n_apps, apps.data(), res->data(), exec->data(), total_k, nullptr) == GF_OK;
     };
+    // every shard on device 0: the one-GPU form of the eight-GPU context — first with the shards of the device in ONE sub-context
+    // (a launch per step, a grid row per shard), then with every listed id in a sub-context, stream and submitting thread of its
+    // own (GANGFIT_TEST_GROUP_SPLIT: events between streams, host barriers, pushes into several tables, the placement pull)
+    for (int pass = 0; pass < 2; ++pass)
     for (int n_dev : {2, 5, 8}) {
-        std::vector<int> ids((size_t)n_dev, 0);  // every shard on device 0: the one-GPU form of the eight-GPU context
+        if (pass == 1)
+            (void)setenv("GANGFIT_TEST_GROUP_SPLIT", "1", 1);
+        else
+            (void)unsetenv("GANGFIT_TEST_GROUP_SPLIT");
+    // ---- a box nobody has tried the context on: (a) devices that cannot reach each other's memory degrade the context to its
+    //      first device; (b) a wrong exchange (1: the placement pull never runs, 2: the other devices' capacity sums arrive as
+    //      zeros) is caught by the self-check of the first sharded batch — right answers, sharding off, the context says why
+    auto same_as_one_device = [&](gf_ctx* g, gf_algo algo) {
+        std::vector<gf_result> r1, rg;
+        std::vector<uint32_t> e1, eg;
+        if (!run(g_ctx, algo, &r1, &e1) || !run(g, algo, &rg, &eg)) return false;
+        bool same = true;
+        uint64_t off = 0;
+        for (uint32_t a = 0; a < n_apps; ++a) {
+            same = same && r1[a].has_capacity == rg[a].has_capacity && r1[a].driver_node == rg[a].driver_node;
+            if (r1[a].has_capacity)
+                for (uint32_t i = 0; i < r1[a].exec_len; ++i) same = same && e1[off + i] == eg[off + i];
+            off += (uint64_t)apps[a].k;
+        }
+        return same;
+    };
+    {
+        (void)setenv("GANGFIT_TEST_NO_PEER", "1", 1);
+        const int ids[3] = {0, 0, 0};
+        gf_ctx* g = nullptr;
+        CHECK(gf_init(ids, 3, &g) == GF_OK);
+        (void)unsetenv("GANGFIT_TEST_NO_PEER");
+        if (g) {
+            CHECK(gf_shard_count(g) == 1);
+            CHECK(std::string(gf_last_error(g)).find("peer access") != std::string::npos);
+            CHECK(same_as_one_device(g, GF_ALGO_TIGHTLY_PACK));
+            gf_destroy(g);
+        }
+    }
+    (void)setenv("GANGFIT_TEST_GROUP_SPLIT", "1", 1);
+    for (int fault : {1, 2}) {
+        const int ids[4] = {0, 0, 0, 0};
+        gf_ctx* g = nullptr;
+        CHECK(gf_init(ids, 4, &g) == GF_OK);
+        if (!g) continue;
+        CHECK(same_as_one_device(g, GF_ALGO_TIGHTLY_PACK));
+        CHECK(gf_shard_count(g) == 4);
+        CHECK(gf_set_option(g, "group_fault", fault) == GF_OK);
+        CHECK(same_as_one_device(g, GF_ALGO_TIGHTLY_PACK));  // the self-check serves the first device's answer
+        CHECK(gf_shard_count(g) == 1);
+        CHECK(std::string(gf_last_error(g)).find("disagreed") != std::string::npos);
+        gf_destroy(g);
+    }
+    (void)unsetenv("GANGFIT_TEST_GROUP_SPLIT");
+        std::vector<int> ids((size_t)n_dev, 0);
         gf_ctx* g = nullptr;
         CHECK(gf_init(ids.data(), n_dev, &g) == GF_OK);
         if (!g) continue;
@@ -1138,6 +1191,7 @@ static void TestMultiDeviceContext() {
         CHECK(gf_fit_batch(g, GF_MODE_FIFO_CHAIN, GF_ALGO_TIGHTLY_PACK, n_apps, apps.data(), rc.data(), ec.data(), total_k, &failed) == GF_OK);
         gf_destroy(g);
     }
+    (void)unsetenv("GANGFIT_TEST_GROUP_SPLIT");
 }
 
 int main(int argc, char** argv) {

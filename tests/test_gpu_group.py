@@ -14,12 +14,26 @@ pytestmark = pytest.mark.gpu
 IND, FIFO = gangfit.GF_MODE_INDEPENDENT, gangfit.GF_MODE_FIFO_CHAIN
 
 
+@pytest.fixture(params=["one-sub-context-per-device", "one-per-listed-id"])
+def split(request, monkeypatch):
+    """A repeated device id is how a one-GPU box exercises the multi-device context.  By default the shards of ONE device live in
+    one sub-context (one launch per step, a grid row per shard); GANGFIT_TEST_GROUP_SPLIT=1 gives every listed id a sub-context,
+    a stream and a submitting thread of its own — events between streams, the host barriers of the submitting threads, pushes
+    into several gathered tables, the pull of the placements: what distinct devices exercise."""
+    if request.param == "one-per-listed-id":
+        monkeypatch.setenv("GANGFIT_TEST_GROUP_SPLIT", "1")
+    else:
+        monkeypatch.delenv("GANGFIT_TEST_GROUP_SPLIT", raising=False)
+    return request.param == "one-per-listed-id"
+
+
 @pytest.mark.parametrize("algo", [0, 1])
 @pytest.mark.parametrize("n_dev", [2, 3, 8, 16])
 @pytest.mark.parametrize("n", [5, 64, 130, 1000])
-def test_group_matches_oracle(algo, n_dev, n):
+def test_group_matches_oracle(algo, n_dev, n, split):
     rng = np.random.default_rng(4321 + 17 * n_dev + algo + n)
     with gangfit.Context(devices=[0] * n_dev) as g:
+        assert g.shard_count() == n_dev
         for layout in ("merged", "identical"):
             for tight_cluster in (True, False):
                 avail, D, X, drv, exe, k = _random_problem(rng, n, 150, tight_cluster, layout)
@@ -58,7 +72,7 @@ def test_group_general_layout_and_other_modes_run_on_the_first_device():
             g._check(g._lib.gf_shard_set(g._h, 0, 2))
 
 
-def test_group_device_built_snapshot_and_headline_size():
+def test_group_device_built_snapshot_and_headline_size(split):
     w = wl.headline(10000, 1000)
     s = w.snapshot
     apps = gangfit.make_apps(w.drv, w.exe, w.k)
@@ -112,11 +126,13 @@ def test_group_argument_errors():
 
 
 @pytest.mark.parametrize("fault", [1, 2])
-def test_a_wrong_exchange_is_caught_and_sharding_switched_off(fault):
+def test_a_wrong_exchange_is_caught_and_sharding_switched_off(fault, monkeypatch):
     """Self-check of a multi-device context: the first sharded batch on a newly installed snapshot is also answered by the
     first device alone.  With an exchange made to fail (option "group_fault": 1 = the placement reduction never runs, 2 = the
     other shards' capacity sums arrive as zeros) the answers must still be the right ones, the context must say so and stop
-    sharding; without the fault it keeps sharding."""
+    sharding; without the fault it keeps sharding.  (Every listed id its own sub-context: with the four shards in ONE
+    sub-context there is no exchange between devices to break.)"""
+    monkeypatch.setenv("GANGFIT_TEST_GROUP_SPLIT", "1")
     rng = np.random.default_rng(700 + fault)
     avail, D, X, drv, exe, k = _random_problem(rng, 1000, 150, False, "merged")
     apps = gangfit.make_apps(drv, exe, k)
@@ -154,6 +170,25 @@ def test_no_peer_access_degrades_to_the_first_device(monkeypatch):
         g.set_orders(D, X)
         apps = gangfit.make_apps(drv, exe, k)
         _assert_same(g.fit_batch(IND, 1, apps), ob.fit_independent(1, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True), apps)
+
+
+def test_many_batches_keep_the_submitting_threads_in_step(monkeypatch):
+    """Two hundred sharded batches of changing size back to back on one context (every listed id its own sub-context and
+    thread): the host barriers between the steps and the event waits between the streams must hold for every one of them."""
+    monkeypatch.setenv("GANGFIT_TEST_GROUP_SPLIT", "1")
+    rng = np.random.default_rng(77)
+    avail, D, X, drv, exe, k = _random_problem(rng, 1500, 400, False, "merged")
+    with gangfit.Context(devices=[0] * 5) as g:
+        g.set_snapshot(avail)
+        g.set_orders(D, X)
+        g.set_option("group_verify", 0)  # the answers are compared here, every time
+        for i in range(200):
+            n = int(rng.integers(1, 400))
+            lo = int(rng.integers(0, 400 - n + 1))
+            algo = i & 1
+            apps = gangfit.make_apps(drv[lo:lo + n], exe[lo:lo + n], k[lo:lo + n])
+            ref = ob.fit_independent(algo, avail, ob.make_apps(drv[lo:lo + n], exe[lo:lo + n], k[lo:lo + n]), D, X, closed_form=True)
+            _assert_same(g.fit_batch(IND, algo, apps), ref, apps)
 
 
 def test_rccl_binding_and_exchange_selection():

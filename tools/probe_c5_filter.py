@@ -86,7 +86,7 @@ def run(calls=100, ctx=None):
     # ... and with the chain cache off: no checkpoint is dumped while the chain runs
     ctx.set_option("chain_cache", 0)
     nock = []
-    for i in range(min(calls, 30) + 2):
+    for i in range(min(calls, 60) + 2):  # (the same rotations as the loop above: the chain's time depends on the head)
         t0 = time.perf_counter()
         ctx.fit_batch(FIFO, TIGHT, rolled[i])
         if i >= 2:
