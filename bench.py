@@ -1195,18 +1195,56 @@ def main():
                 ctx.fit_batch(FIFO, TIGHT, rolled)
                 if i >= 3:
                     latu.append((time.perf_counter() - t0) * 1e3)
-            # the chain by itself, on the snapshot the last build left (gf_snapshot_build returns before its kernels finish, so
-            # the second half of a Filter call above is not the chain alone)
-            for i in range(min(n_calls5, 60) + 2):
+            # the same Filter with a device synchronise behind every phase (so that a phase's kernels are charged to it), and the
+            # chain by itself on the snapshot the last build left — over the SAME heads as the loop above: the chain's time
+            # depends on the head (3.6 .. 6.1 ms over the rotations of this queue, two clusters), so medians over different
+            # sets of heads are not comparable (round 3 compared 100 heads with 60 and read the difference as a regression)
+            n_u = min(n_calls5, 100) + 3
+            ph5 = {"usage_apply_x2": [], "snapshot_build_resident": [], "chain_first_on_fresh_epoch": []}
+            for i in range(n_u):
+                rolled = np.roll(q5, -i)
+                j = i % len(ks)
+                sl = slice(int(starts5[j]), int(starts5[j + 1]))
+                dn, dc = rnode[sl], [c[sl] for c in rcols5]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.usage_apply(dn, res_cols=dc, sign=-1)
+                ctx.usage_apply(dn, res_cols=dc, sign=+1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.build_snapshot_resident(resident_usage=True, want_orders=False)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                ctx.fit_batch(FIFO, TIGHT, rolled)
+                t3 = time.perf_counter()
+                if i >= 3:
+                    ph5["usage_apply_x2"].append((t1 - t0) * 1e3)
+                    ph5["snapshot_build_resident"].append((t2 - t1) * 1e3)
+                    ph5["chain_first_on_fresh_epoch"].append((t3 - t2) * 1e3)
+            for i in range(n_u):
                 rolled = np.roll(q5, -i)
                 t1 = time.perf_counter()
                 ctx.fit_batch(FIFO, TIGHT, rolled)
-                if i >= 2:
+                if i >= 3:
                     chain5.append((time.perf_counter() - t1) * 1e3)
+            ctx.set_option("chain_cache", 0)  # ... and without the checkpoints a chain dumps for the next Filter
+            nock5 = []
+            for i in range(n_u):
+                rolled = np.roll(q5, -i)
+                t1 = time.perf_counter()
+                ctx.fit_batch(FIFO, TIGHT, rolled)
+                if i >= 3:
+                    nock5.append((time.perf_counter() - t1) * 1e3)
+            ctx.set_option("chain_cache", 1)
             c5 = {"nodes": n5, "reservation_entries": int(len(rnode)), "earlier_drivers": len(q5) - 1, "calls": len(lat5),
                   "filter_p50_ms": _percentile(lat5, 0.5), "filter_p99_ms": _percentile(lat5, 0.99),
                   "chain_only_p50_ms": _percentile(chain5, 0.5), "chain_only_p99_ms": _percentile(chain5, 0.99),
+                  "chain_only_quartiles_ms": [_percentile(chain5, q) for q in (0.0, 0.25, 0.5, 0.75, 1.0)],
+                  "chain_only_no_checkpoints_p50_ms": _percentile(nock5, 0.5),
+                  "chain_only_heads": f"the {len(chain5)} heads of the resident-usage loop (same rotations: the chain's time depends on the head)",
                   "filter_resident_usage_p50_ms": _percentile(latu, 0.5), "filter_resident_usage_p99_ms": _percentile(latu, 0.99),
+                  "filter_resident_usage_phases_p50_ms": {k: _percentile(v, 0.5) for k, v in ph5.items()},
+                  "filter_resident_usage_phases_p99_ms": {k: _percentile(v, 0.99) for k, v in ph5.items()},
                   "filter_resident_usage": "two gf_usage_apply calls (one application's entries out, one's in) + "
                                            "gf_snapshot_build_resident(GF_RESIDENT_USAGE) + the chain: no reservation list travels",
                   "filter": "gf_snapshot_build_resident (reservation replay + metadata + sort + slot tables on the device; the cluster's "
