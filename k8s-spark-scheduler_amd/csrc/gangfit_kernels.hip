@@ -1950,20 +1950,35 @@ hipError_t launch_fit_fifo_zoned_lds(bool az_aware, const NodeTable& table, cons
     const size_t lds = fifo_zoned_lds_bytes(lds_slots, table.n_chunks, zones.n_zones, n_cand, n_shapes);
     // ... plus one that expands the winner's placement next to the commit (none left with 16 views)
     const int wg_waves = fifo_zoned_waves(n_cand);
-#define GF_ZL(AZ, NWV)                                                                                                      \
-    e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<AZ, NWV>, NWV, lds, stream, table, ntable, zones, d_sched, lds_slots, \
-                             n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,      \
+    const bool res = lds_slots >= table.n_slots;  // the whole table in LDS: the global-tail branch of every slot access compiles away
+#define GF_ZL2(AZ, NWV, RS)                                                                                                     \
+    e = launch_one_workgroup(fit_fifo_zoned_lds_kernel<AZ, NWV, RS>, NWV, lds, stream, table, ntable, zones, d_sched, lds_slots, \
+                             n_apps, n_shapes, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,          \
                              d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, ck, d_stats)
+#define GF_ZL(AZ, NWV)       \
+    if (res)                 \
+        GF_ZL2(AZ, NWV, true); \
+    else                     \
+        GF_ZL2(AZ, NWV, false)
     if (az_aware) {
-        if (wg_waves == 4) GF_ZL(true, 4);
-        else if (wg_waves == 8) GF_ZL(true, 8);
-        else GF_ZL(true, 16);
+        if (wg_waves == 4) {
+            GF_ZL(true, 4);
+        } else if (wg_waves == 8) {
+            GF_ZL(true, 8);
+        } else {
+            GF_ZL(true, 16);
+        }
     } else {
-        if (wg_waves == 4) GF_ZL(false, 4);
-        else if (wg_waves == 8) GF_ZL(false, 8);
-        else GF_ZL(false, 16);
+        if (wg_waves == 4) {
+            GF_ZL(false, 4);
+        } else if (wg_waves == 8) {
+            GF_ZL(false, 8);
+        } else {
+            GF_ZL(false, 16);
+        }
     }
 #undef GF_ZL
+#undef GF_ZL2
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed, chain_out_of(io, d_chain_failed_at));
