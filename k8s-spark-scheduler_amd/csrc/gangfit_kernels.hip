@@ -2008,14 +2008,23 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
     hipError_t e = launch_chain_prologue(io, n_apps, d_apps, d_napps, ntable.unit, d_wide_needed, nullptr, 0, stream);
     if (e != hipSuccess) return e;
     const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_idx);
-    if (zoned)
-        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<true>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
-                                 n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats);
-    else
-        e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<false>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched, lds_slots,
-                                 n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed, d_results,
-                                 d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats);
+    const bool res = lds_slots >= table.n_slots;
+#define GF_MFL(ZO, RS)                                                                                                         \
+    e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<ZO, RS>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched,       \
+                             lds_slots, n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,  \
+                             d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats)
+    if (zoned) {
+        if (res)
+            GF_MFL(true, true);
+        else
+            GF_MFL(true, false);
+    } else {
+        if (res)
+            GF_MFL(false, true);
+        else
+            GF_MFL(false, false);
+    }
+#undef GF_MFL
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
                        n_apps, d_apps, d_results, d_exec_nodes, (const int32_t*)d_wide_needed, chain_out_of(io, d_chain_failed_at));
