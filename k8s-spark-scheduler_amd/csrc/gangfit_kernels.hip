@@ -193,6 +193,16 @@ __device__ __forceinline__ int32_t cap3(int64_t a0, int64_t a1, int64_t a2, cons
 }
 
 // cap >= 1 without any division: base + exe <= avail in every dimension (the first add-then-compare step).
+// Lane masks in scalar registers (the compares write them there) instead of per-lane booleans that a __ballot turns back into a
+// mask by way of a select and a second compare: "every component at least r" for 64 lanes at once, ANDed with a wave-uniform
+// candidate word; low_lanes(n) = the lanes below n.
+__device__ __forceinline__ uint64_t ge3_mask(int64_t a0, int64_t a1, int64_t a2, int64_t r0, int64_t r1, int64_t r2) {
+    constexpr int kSGE = 39;  // signed >=
+    return __builtin_amdgcn_sicmpl(a0, r0, kSGE) & __builtin_amdgcn_sicmpl(a1, r1, kSGE) & __builtin_amdgcn_sicmpl(a2, r2, kSGE);
+}
+__device__ __forceinline__ uint64_t low_lanes(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+__device__ __forceinline__ bool lane_in(uint64_t uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
+
 __device__ __forceinline__ bool cap_ge1(int64_t a0, int64_t a1, int64_t a2, const App& app) {
     return app.exe0 <= a0 && app.exe1 <= a1 && app.exe2 <= a2;
 }
@@ -633,7 +643,8 @@ __device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const 
             const uint32_t j = c * kWave + lane;
             const uint64_t cxm = (uint64_t)read_lane((int64_t)cand, bit);
             const bool have = pre.on && (int)c == pre.c;  // wave-uniform
-            const bool in = j < O.n_x && ((cxm >> lane) & 1ull);
+            const uint64_t in_m = cxm & low_lanes(chunk_len(O.n_x, c * kWave, kWave));  // candidate slots of the order in this chunk
+            const bool in = lane_in(in_m);
             int64_t a0 = 0, a1 = 0, a2 = 0;
             uint32_t node = 0;
             if (in) {
@@ -653,8 +664,8 @@ __device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const 
                 }
             }
             visited += chunk_len(O.n_x, c * kWave, kWave);
-            const bool fit = in && cap_ge1(a0, a1, a2, app);
-            const uint64_t fm = __ballot(fit);
+            const uint64_t fm = ge3_mask(a0, a1, a2, app.exe0, app.exe1, app.exe2) & in_m;
+            const bool fit = lane_in(fm);
             const uint32_t n = (uint32_t)__popcll((unsigned long long)fm);
             if (n == 0) continue;
             const uint32_t id = SLOTS ? j : node;
@@ -894,10 +905,15 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
         const Group0 g0 = g0p != nullptr ? *g0p : load_group0(V, O, lane);
         const uint64_t dcand = g0.dcand;
         pre.cand = g0.xcand;
-        const bool okd = g0.ind & (g0.m0 >= app.drv0) & (g0.m1 >= app.drv1) & (g0.m2 >= app.drv2) & (dcand != 0);
-        const bool okx = !sparse & g0.inx & (g0.m0 >= app.exe0) & (g0.m1 >= app.exe1) & (g0.m2 >= app.exe2) & (pre.cand != 0);
-        const uint64_t md = __ballot(okd);
-        pre.m = __ballot(okx);
+        // (g0.ind / g0.inx = "lane < chunks of the order, and < chunks of the table": scalar masks)
+        const uint32_t xc0 = (O.n_x + kWave - 1) / kWave;
+        const uint64_t ind_m = low_lanes(dc < V.n_chunks ? dc : V.n_chunks), inx_m = low_lanes(xc0 < V.n_chunks ? xc0 : V.n_chunks);
+        constexpr int kNE = 33;
+        const uint64_t md = ge3_mask(g0.m0, g0.m1, g0.m2, app.drv0, app.drv1, app.drv2) & ind_m &
+                            __builtin_amdgcn_uicmpl((unsigned long)dcand, 0ul, kNE);
+        pre.m = sparse ? 0ull
+                       : (ge3_mask(g0.m0, g0.m1, g0.m2, app.exe0, app.exe1, app.exe2) & inx_m &
+                          __builtin_amdgcn_uicmpl((unsigned long)pre.cand, 0ul, kNE));
         pre.on = !sparse;
         dvis += kWave;
         const int bd = md ? __ffsll((unsigned long long)md) - 1 : -1;
@@ -923,9 +939,9 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
         uint32_t from = dc > (uint32_t)kWave ? (uint32_t)kWave * kWave : O.n_d;  // where the generic search resumes
         if (bd >= 0) {
             const uint64_t cdm = (uint64_t)read_lane((int64_t)dcand, bd);
-            const bool fit = id < O.n_d && ((cdm >> lane) & 1ull) && driver_fits(d0, d1, d2, app);
             dvis += chunk_len(O.n_d, (uint32_t)bd * kWave, kWave);
-            const uint64_t fm = __ballot(fit);
+            // (lanes whose position is below n_d, candidate bits of the chunk, the driver-fit check of binpack.go:69: masks)
+            const uint64_t fm = ge3_mask(d0, d1, d2, app.drv0, app.drv1, app.drv2) & cdm & low_lanes(chunk_len(O.n_d, (uint32_t)bd * kWave, kWave));
             if (fm) {
                 const int fl = __ffsll((unsigned long long)fm) - 1;
                 p0 = (int64_t)bd * kWave + fl;
