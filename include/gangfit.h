@@ -116,8 +116,12 @@ int gf_version(void);
  *     peers' tables) and one reduction of the placement buffer onto the first device.  Same gf_result / ExecutorNodes as on
  *     one device, bit for bit.  Everything else (FIFO chains — each commit must be visible to the next scan —, zone-aware
  *     and minimal-fragmentation packers, orders that do not merge into one, single executors, findNodes, efficiencies, the
- *     *_dev entry points) runs on the first device.  A device id may repeat (several shards on one GPU): that is how the
- *     path is tested on a one-GPU box.  When two distinct devices cannot access each other's memory the context DEGRADES
+ *     *_dev entry points) runs on the first device.  One submitting thread per device issues that device's launches
+ *     (the calling thread is the first device's; the others park between batches), so a batch costs the host about what
+ *     one device's half a dozen runtime calls cost.  A device id may repeat (several shards on one GPU): that is how the
+ *     path is tested on a one-GPU box — the shards of one device then share a sub-context (one launch per step with a grid
+ *     row per shard; the environment variable GANGFIT_TEST_GROUP_SPLIT=1, a test switch, gives every listed id a
+ *     sub-context, a stream and a submitting thread of its own instead).  gf_shard_count returns the number of listed ids.  When two distinct devices cannot access each other's memory the context DEGRADES
  *     to the first device (GF_OK; gf_shard_count returns 1, gf_last_error says why): a host must not lose the accelerator
  *     because a topology lacks peer access.  The exchange buffers live in fine-grained memory.  Self-check: the first
  *     sharded batch on every newly installed snapshot is also answered by the first device alone; on a mismatch the

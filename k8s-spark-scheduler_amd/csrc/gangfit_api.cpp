@@ -344,7 +344,7 @@ void gf_destroy(gf_ctx* ctx) {
         if (ctx->worker.ev1) (void)hipEventDestroy(ctx->worker.ev1);
         if (ctx->worker.stream) (void)hipStreamDestroy(ctx->worker.stream);
     }
-    if (ctx->stream && !ctx->stream_borrowed) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 

@@ -218,7 +218,6 @@ struct gf_ctx {
     bool seq_held = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    bool stream_borrowed = false;  // (unused since the shards of one device live in ONE sub-context; kept for gf_destroy's symmetry)
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     // The resident worker of the independent batch (gf_worker_*; gangfit_worker.inc).
     struct Worker {
