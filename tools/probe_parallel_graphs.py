@@ -1,6 +1,10 @@
 """Independent batches on several VIEWS of one context (gf_ctx_view: own stream, own scratch) at once: K headline batches per
 window split over B views, each view's share recorded as one graph; a window = B graph launches + a synchronise.  A 1 000-application
 batch is ~1 000 wavefronts on 7 000 wavefront slots and latency-bound, so batches on different hardware queues should overlap.
+Measured (profiles/r4_parallel_views.txt): at the driver's K=20 a window is B graph launches + a synchronise and the
+resident worker wins (3.5 us/step); in 200-step windows 4 views reach 1.8 us/step.  ONE recording with B forked branches (event
+fork/join inside the capture) was also tried: the runtime's graph executor puts its own cross-queue markers between the branches
+and it is slower than a plain one-stream graph (6.1 us/step at 2-4 branches) -- that entry point was not kept.
 Run on the MI355X box:  python tools/probe_parallel_graphs.py"""
 import os, sys, time
 import numpy as np
