@@ -275,3 +275,45 @@ def test_zoned_fifo_chains_many_zones(gf_ctx, nz):
             assert gpu.failed_at == ref.failed_at
             _assert_same(gpu, ref, apps)
             assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+
+
+@pytest.mark.parametrize("nz", [2, 3, 5])
+def test_zoned_fifo_chain_equal_zones_take_the_exact_sums(gf_ctx, nz):
+    """Zones made of the same nodes in the same relative order: their candidates' averages are EQUAL, the chain kernels'
+    (tree sum, bound) pairs cannot separate them and the reference's slice-order sums decide (the first zone of the driver
+    order wins, single_az.go:75-97).  Second cluster: one zone's schedulable memory differs by one byte — a gap of ~1e-11
+    relative, far above the bound, decided without the exact sums.  Third: quantities available beyond the schedulable ones
+    (negative terms: no bound)."""
+    from test_gpu_minfrag import SAZMF
+    rng = np.random.default_rng(1000 + nz)
+    per = 70
+    for variant in ("equal", "one_byte", "negative"):
+        base_sched = np.stack([rng.choice([16000, 32000, 64000], per), rng.choice([64, 128, 256], per) * GIB, np.zeros(per, dtype=np.int64)], axis=1).astype(np.int64)
+        used = (rng.random((per, 3)) * 0.8 * base_sched).astype(np.int64)
+        base_avail = base_sched - used
+        n = per * nz
+        avail = np.repeat(base_avail, nz, axis=0)
+        sched = np.repeat(base_sched, nz, axis=0)
+        zone = (np.arange(n) % nz).astype(np.uint32) + 11
+        if variant == "one_byte":
+            sched[zone == 11 + (nz - 1), 1] += 1
+        if variant == "negative":
+            sched[::7, 0] = avail[::7, 0] - 1000  # more available than schedulable
+        order = np.arange(n)
+        a = 90
+        drv = np.stack([rng.choice([1000, 2000], a), rng.choice([2, 4], a) * GIB, np.zeros(a, dtype=np.int64)], axis=1).astype(np.int64)
+        exe = np.stack([rng.choice([1000, 4000, 8000], a), rng.choice([4, 16], a) * GIB, np.zeros(a, dtype=np.int64)], axis=1).astype(np.int64)
+        k = rng.integers(0, 9, a).astype(np.int32)
+        flags = np.ones(a, dtype=np.uint32)
+        _setup(gf_ctx, avail, sched, zone, order, order)
+        apps = gangfit.make_apps(drv, exe, k, flags)
+        for algo, oalgo in ((SAZ, O_ALGO[SAZ]), (AZA, O_ALGO[AZA]), (SAZMF, ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION)):
+            for length in (1, 2, a):
+                gpu = gf_ctx.fit_batch(gangfit.GF_MODE_FIFO_CHAIN, algo, apps[:length])
+                ref = ob.fit_fifo_chain(oalgo, avail, ob.make_apps(drv[:length], exe[:length], k[:length], flags[:length]), order, order,
+                                        sched=sched, zone=zone)
+                assert gpu.failed_at == ref.failed_at
+                _assert_same(gpu, ref, apps[:length])
+                assert np.array_equal(gf_ctx.residual(), ref.avail_after)
+            if variant == "equal":
+                assert ref.results["has_capacity"].any()
