@@ -81,8 +81,8 @@ struct NApp {  // 64 bytes, produced by the chain prologue (prepare_app): reques
     int32_t k;
     int32_t exe[3];  // >= 0
     uint32_t flags;
-    float rcp[3];    // 1.0f / exe (0 when exe == 0)
-    float kf1;       // (float)(k + 1)
+    uint32_t mag[3];  // division by exe as a multiplication (narrow_magic, gangfit_fifo_common.inc): 2 * ceil(2^(30 + l) / exe), 0 when exe == 0
+    uint32_t msh;     // the three post-shifts l = ceil(log2(exe)), 8 bits each
     uint64_t exec_off;
     uint64_t pad;
 };

@@ -1624,6 +1624,41 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
         }
         if (cap_dim(a, e, rcp, k) != want) ++bad;
         if (cap_dim(a, 0, 0.0, k) != (a < 0 ? 0 : k)) ++bad;
+        // (c) the narrow domain's division by multiplication (narrow_magic): |a| < 2^30, 0 < e < 2^30, the same operand families
+        {
+            const int nbits = 1 + (int)((r0 >> 16) % 30);
+            int32_t ne = (int32_t)((r1 >> 3) & ((1u << nbits) - 1u));
+            if (ne == 0) ne = 1;
+            if ((r0 >> 24) % 7 == 0) ne = 1 << (nbits - 1);  // powers of two: m = 2^30 exactly
+            const int32_t nlim = (1 << 30) - 1;
+            int32_t na;
+            switch ((r0 >> 32) % 4) {
+            case 0: na = (int32_t)(splitmix64(s) & (uint64_t)nlim); break;
+            case 1: {
+                const int32_t maxq = nlim / ne;
+                const int32_t mult = (int32_t)(splitmix64(s) % (uint64_t)(2 * (int64_t)k + 3));
+                const int64_t t = (int64_t)(mult < maxq ? mult : maxq) * ne + (int64_t)(splitmix64(s) % 3) - 1;
+                na = t > nlim ? nlim : (int32_t)t;
+                break;
+            }
+            case 2: na = nlim - (int32_t)(splitmix64(s) % 3); break;  // the largest dividends
+            default: na = -(int32_t)(splitmix64(s) & (uint64_t)nlim); break;
+            }
+            uint32_t mag, sh;
+            narrow_magic(ne, mag, sh);
+            const int32_t nwant = na < 0 ? 0 : ((na / ne) < k ? (na / ne) : k);
+            if (ncap_dim(na, ne, mag, sh, k) != nwant) ++bad;
+            if (ncap_dim(na, 0, 0u, 0u, k) != (na < 0 ? 0 : k)) ++bad;
+            if (na >= 0 && ncap_full_dim(na, ne, mag, sh) != na / ne) ++bad;
+            if (na >= ne) {  // a slot that fits: the variant the scans use
+                NAppR q{};
+                q.k = k;
+                q.mag0 = mag;
+                q.mag1 = 0;
+                q.mag2 = mag;
+                if (ncap3_fit(na, 5, na, q, sh, 0u, sh, 0u, 0xFFFFFFFFu, 0u) != nwant) ++bad;
+            }
+        }
     }
     if (bad) atomicAdd(mismatch, bad);
 }
