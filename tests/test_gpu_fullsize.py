@@ -170,3 +170,34 @@ def test_config5_replay_then_fifo_999_plus_1(gf_ctx, algo):
             # the plain packers can still host the first such gangs on the gpu nodes the replay left empty; the one that
             # aborts the chain cannot be hosted by any packer
             assert not gpu.results["has_capacity"][800] and not gpu.results["has_capacity"][401]
+
+
+def test_100k_nodes_three_zones_chains_stay_on_the_lds_kernels():
+    """The LDS-resident chain kernels of the zone-aware and minimal-fragmentation packers fit next to the per-view masks of a
+    100 000-node table with a few dozen bytes of LDS to spare (MfShared, gangfit_fifo_minfrag.inc).  A kilobyte more and the
+    queue silently takes the generic kernel: the same answers, 16 ms -> 1.3 s.  Nothing else notices, so this does: every
+    packer's cold 1 000-application chain at that size stays far below what the generic kernel needs, and the
+    single-AZ minimal-fragmentation chain agrees with the oracle on a prefix."""
+    import time
+    n_nodes, nz = 100000, 3
+    w = wl.headline(n_nodes, 1000)
+    s = w.snapshot
+    zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32)
+    order = wl.reference_node_order(s.avail, zone)
+    flags = np.ones(len(w.k), dtype=np.uint32)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, flags)
+    with gangfit.Context(0, options={"chain_cache": 0}) as ctx:
+        ctx.set_snapshot(s.avail, s.sched)
+        ctx.set_zones(zone)
+        ctx.set_orders(order, order)
+        for algo in (0, 1, 2, 3, 4, 5):
+            ctx.fit_batch(FIFO, algo, apps)
+            t0 = time.perf_counter()
+            gpu = ctx.fit_batch(FIFO, algo, apps)
+            ms = (time.perf_counter() - t0) * 1e3
+            assert ms < 150.0, (algo, ms)
+            if algo == 5:
+                n = 40
+                ref = ob.fit_fifo_chain(ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION, s.avail, ob.make_apps(w.drv[:n], w.exe[:n], w.k[:n], flags[:n]),
+                                        order, order, sched=s.sched, zone=zone)
+                assert np.array_equal(gpu.results[:n - 1], ref.results[:n - 1])

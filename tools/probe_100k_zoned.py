@@ -1,0 +1,18 @@
+import sys, time, os
+import numpy as np
+sys.path[:0] = ["/root/repo", "/root/repo/k8s-spark-scheduler_amd"]
+import gangfit
+from gangfit import workloads as wl
+n_nodes, nz = 100000, 3
+w = wl.headline(n_nodes, 1000)
+s = w.snapshot
+ctx = gangfit.Context(0, options={"chain_cache": 0})
+ctx.set_snapshot(s.avail, s.sched)
+zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32)
+ctx.set_zones(zone)
+order = wl.reference_node_order(s.avail, zone)
+ctx.set_orders(order, order)
+apps = gangfit.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+for algo in (2, 5, 4):
+    ctx.fit_batch(1, algo, apps)
+    t0 = time.perf_counter(); ctx.fit_batch(1, algo, apps); print(algo, (time.perf_counter() - t0) * 1e3, flush=True)
