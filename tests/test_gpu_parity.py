@@ -296,6 +296,31 @@ def test_headline_size_against_closed_form_oracle(gf_ctx, algo, congested):
     assert np.array_equal(gf_ctx.residual(), ref.avail_after)
 
 
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_headline_size_against_the_literal_oracle(gf_ctx, algo):
+    """The size the metric is quoted on against the LITERAL restatement, end to end (all 1 000 applications, independent
+    batch and FIFO chain with its residual table): on the nominal cluster every gang fits, so the literal loops — the ones
+    bench.py times as the CPU baseline — finish in milliseconds.  (The congested cluster keeps the closed form above: an
+    infeasible gang costs the literal retry loop O(|D| N).)"""
+    w = wl.headline()
+    s = w.snapshot
+    gf_ctx.set_snapshot(s.avail, s.sched)
+    gf_ctx.set_orders(s.driver_order, s.exec_order)
+    apps = _gpu_apps(w.drv, w.exe, w.k, w.flags)
+    oapps = ob.make_apps(w.drv, w.exe, w.k, w.flags)
+    gpu = gf_ctx.fit_batch(IND, algo, apps)
+    lit = ob.fit_independent(algo, s.avail, oapps, s.driver_order, s.exec_order, closed_form=False)
+    _assert_same(gpu, lit, apps)
+    assert lit.results["has_capacity"].all()
+    apps["flags"] = 1
+    oapps["flags"] = 1
+    gpu = gf_ctx.fit_batch(FIFO, algo, apps)
+    lit = ob.fit_fifo_chain(algo, s.avail, oapps, s.driver_order, s.exec_order, closed_form=False)
+    assert gpu.failed_at == lit.failed_at == -1
+    _assert_same(gpu, lit, apps)
+    assert np.array_equal(gf_ctx.residual(), lit.avail_after)
+
+
 def _check_properties(algo, w, out: gangfit.BatchOut):
     """Size-independent properties of a feasible placement (no oracle involved)."""
     s = w.snapshot

@@ -107,6 +107,24 @@ def test_literal_and_closed_form_agree_on_batches(algo):
             assert np.array_equal(lit.placement(i)[2], clo.placement(i)[2])
 
 
+@pytest.mark.parametrize("algo", [0, 1])
+def test_literal_and_closed_form_agree_at_the_headline_size(algo):
+    """10 000 nodes x 1 000 applications (the size the metric is quoted on), independent batch and FIFO chain: the literal loops
+    and the closed form give the same results, placements and residual table (the GPU tests hold the kernels to both)."""
+    from gangfit import workloads as wl
+    w = wl.headline()
+    s = w.snapshot
+    apps = ob.make_apps(w.drv, w.exe, w.k, np.ones(len(w.k), dtype=np.uint32))
+    lit = ob.fit_independent(algo, s.avail, apps, s.driver_order, s.exec_order, closed_form=False)
+    clo = ob.fit_independent(algo, s.avail, apps, s.driver_order, s.exec_order, closed_form=True)
+    assert np.array_equal(lit.results, clo.results) and np.array_equal(lit.exec_nodes, clo.exec_nodes)
+    lit = ob.fit_fifo_chain(algo, s.avail, apps, s.driver_order, s.exec_order, closed_form=False)
+    clo = ob.fit_fifo_chain(algo, s.avail, apps, s.driver_order, s.exec_order, closed_form=True)
+    assert lit.failed_at == clo.failed_at == -1
+    assert np.array_equal(lit.results, clo.results) and np.array_equal(lit.exec_nodes, clo.exec_nodes)
+    assert np.array_equal(lit.avail_after, clo.avail_after)
+
+
 def test_fifo_quirk_k7():
     c = kats.FIFO_K7
     apps = ob.make_apps([a["drv"] for a in c["apps"]], [a["exe"] for a in c["apps"]], [a["k"] for a in c["apps"]],
