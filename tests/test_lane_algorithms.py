@@ -4,6 +4,8 @@ these models document WHY the routines are exact, step by step, and run without 
 
   wave_serial_sum_runs   the slice-order sum of ComputeAvgPackingEfficiency (efficiency.go:114-156) as a systolic pass
   zoned_choose_best      chooseBestResult (single_az.go:75-97) as a row max-scan
+  narrow_magic           floor(a / e) as a multiplication (gangfit_fifo_common.inc), the chain kernels' capacity arithmetic
+  zoned_choose_bounded   chooseBestResult from (tree sum, error bound) pairs: never a different winner than the exact sums
 """
 import numpy as np
 import pytest
@@ -113,3 +115,119 @@ def test_choose_best_scan_matches_the_reference_loop(seed):
     pool = np.array([0.0, 0.25, 0.5, 0.5, 0.75, 0.9, 1.0, 1.5])   # ties and zeros on purpose
     mx = rng.choice(pool, size=n) if seed % 2 else rng.random(n)
     assert scan_choose_best(feas, mx) == reference_choose_best(feas, mx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# narrow_magic: floor(a / e) == mulhi(2 m, 2 a) >> l with l = ceil(log2 e), m = ceil(2^(30 + l) / e), for 0 <= a < 2^30, 0 < e < 2^30
+
+
+def narrow_magic(e: int):
+    l = 0 if e <= 1 else (e - 1).bit_length()
+    m = ((1 << (30 + l)) + e - 1) // e
+    assert m < (1 << 31)
+    return 2 * m, l
+
+
+def magic_div(a: int, mag: int, l: int) -> int:
+    assert 0 <= a < (1 << 30) and 0 <= mag < (1 << 32)
+    return ((mag * ((2 * a) & 0xFFFFFFFF)) >> 32) >> l
+
+
+def test_narrow_magic_is_exact_on_edges_and_random_operands():
+    rng = np.random.default_rng(2024)
+    lim = (1 << 30) - 1
+    divisors = [1, 2, 3, 5, 7, 1000, 1023, 1024, 1025, 4096, 65535, 65536, 65537, (1 << 29) - 1, 1 << 29, (1 << 29) + 1, lim]
+    divisors += [int(x) for x in rng.integers(1, lim + 1, size=300)]
+    divisors += [int(1 << int(b)) for b in rng.integers(0, 30, size=20)]
+    for e in divisors:
+        mag, l = narrow_magic(e)
+        cands = [0, 1, e - 1, e, e + 1, 2 * e - 1, 2 * e, lim, lim - 1, (lim // e) * e, (lim // e) * e - 1]
+        cands += [int(x) for x in rng.integers(0, lim + 1, size=40)]
+        cands += [int(q) * e + d for q in rng.integers(0, max(lim // e, 1), size=20) for d in (-1, 0, 1)]
+        for a in cands:
+            if 0 <= a <= lim:
+                assert magic_div(a, mag, l) == a // e, (a, e)
+
+
+def test_narrow_magic_exhaustive_small():
+    for e in range(1, 200):
+        mag, l = narrow_magic(e)
+        a = np.arange(0, 5000, dtype=np.int64)
+        got = ((mag * ((2 * a) & 0xFFFFFFFF)) >> 32) >> l
+        assert np.array_equal(got, a // e), e
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# zoned_choose_bounded: the winner from (value, bound) pairs is the exact chooser's winner whenever it answers at all
+
+
+def choose_exact(feas, mx):
+    """chooseBestResult: best_max starts at 0, a candidate wins on best_max < max: the FIRST of the largest, if above 0."""
+    best, best_max = -1, 0.0
+    for i, (f, m) in enumerate(zip(feas, mx)):
+        if f and best_max < m:
+            best, best_max = i, m
+    return best
+
+
+UNDECIDED = -2
+
+
+def choose_bounded(feas, approx, err):
+    cand = [i for i, f in enumerate(feas) if f]
+    if not cand:
+        return -1
+    top = max(approx[i] for i in cand)
+    w = next(i for i in cand if approx[i] == top)
+    lo = approx[w] - err[w]
+    if not lo > 0.0:
+        if top == 0.0 and all(err[i] == 0.0 for i in cand):
+            return -1
+        return UNDECIDED
+    for i in cand:
+        if i != w and not (approx[i] + err[i] < lo) and not (err[w] == 0.0 and err[i] == 0.0):
+            return UNDECIDED
+    return w
+
+
+def tree_sum(values):
+    v = list(values) + [0.0] * (WAVE - len(values))
+    v = np.array(v, dtype=np.float64)
+    step = 1
+    while step < WAVE:  # any pairing order: the bound only counts roundings
+        v = v + np.concatenate((np.zeros(step), v[:-step]))
+        step *= 2
+    return np.float64(v[-1])
+
+
+def test_bounded_chooser_never_disagrees_with_the_slice_order_sums():
+    rng = np.random.default_rng(7)
+    decided = undecided = 0
+    for trial in range(3000):
+        nz = int(rng.integers(1, 6))
+        feas, exact, approx, err = [], [], [], []
+        shared = None
+        for z in range(nz):
+            n = int(rng.integers(1, 40))
+            counts = rng.integers(1, 6, size=n)
+            values = rng.random(n) * rng.choice([1.0, 1e-3, 5.0])
+            if trial % 7 == 0 and shared is not None:  # zones of equal nodes: exact ties
+                counts, values = shared
+            shared = (counts, values)
+            k1 = int(counts.sum())
+            ex = sequential_sum(0.0, values, counts) / np.float64(k1)
+            ap = tree_sum(values * counts.astype(np.float64)) / np.float64(k1)
+            bound = np.float64(4 * (k1 - 1) + 64) * 2.0 ** -53 * ap
+            assert abs(ex - ap) <= bound / 2  # the proven bound, with the factor two the chooser's own roundings get
+            feas.append(rng.random() < 0.9)
+            exact.append(ex)
+            approx.append(ap)
+            err.append(bound)
+        got = choose_bounded(feas, approx, err)
+        want = choose_exact(feas, exact)
+        if got == UNDECIDED:
+            undecided += 1
+        else:
+            decided += 1
+            assert got == want, (feas, exact, approx, err)
+    assert decided > 1500 and undecided > 50  # both branches exercised (the ties are undecided by construction)
