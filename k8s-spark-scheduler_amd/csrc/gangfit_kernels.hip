@@ -2060,21 +2060,34 @@ hipError_t launch_fit_fifo_minfrag_lds(bool zoned, const NodeTable& table, const
     if (e != hipSuccess) return e;
     const size_t lds = fifo_minfrag_lds_bytes(lds_slots, table.n_chunks, zoned ? zones.n_zones : 0u, n_idx);
     const bool res = lds_slots >= table.n_slots;
-#define GF_MFL(ZO, RS)                                                                                                         \
-    e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<ZO, RS>, (int)kMfNW, lds, stream, table, ntable, zones, d_sched,       \
+    // eight wavefronts (a 256-VGPR budget: no spills) when the candidate views, four patch helpers and the emitter fit, else sixteen
+    const uint32_t n_cand_mf = zoned ? zones.n_zones : 1u;
+    // ... and the whole table sits in LDS: on a 100 000-node table the block-cooperative parts (row fills, checkpoint dumps,
+    // patches) want the sixteen (measured: 9.7 -> 10.2 ms plain, 15.0 -> 16.6 ms with three zones on eight)
+    const bool eight = res && fifo_minfrag_waves(n_cand_mf) == 8u;
+#define GF_MFL2(ZO, RS, NWV)                                                                                                   \
+    e = launch_one_workgroup(fit_fifo_minfrag_lds_kernel<ZO, RS, NWV>, NWV, lds, stream, table, ntable, zones, d_sched,         \
                              lds_slots, n_apps, n_shapes, n_idx, d_apps, (const NApp*)d_napps, (const int32_t*)d_wide_needed,  \
                              d_results, d_exec_nodes, d_spill, spill_stride, d_chain_failed_at, d_capmat, d_hist, ck, d_stats)
+#define GF_MFL(ZO, RS)          \
+    if (eight)                  \
+        GF_MFL2(ZO, RS, 8);     \
+    else                        \
+        GF_MFL2(ZO, RS, (int)kMfNWmax)
     if (zoned) {
-        if (res)
+        if (res) {
             GF_MFL(true, true);
-        else
+        } else {
             GF_MFL(true, false);
+        }
     } else {
-        if (res)
+        if (res) {
             GF_MFL(false, true);
-        else
+        } else {
             GF_MFL(false, false);
+        }
     }
+#undef GF_MFL2
 #undef GF_MFL
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(zoned_translate_kernel, app_grid_of(n_apps), dim3(kWave * kWavesPerBlock), 0, stream, table.slot_node,
