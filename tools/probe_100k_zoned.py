@@ -1,6 +1,10 @@
+"""Cold 1 000-application chains at 100 000 nodes x 3 zones (the reference's AZ-major order): minimal-fragmentation,
+single-AZ minimal-fragmentation, single-az-tightly-pack — the size at which the LDS chain kernels sit next to the per-view masks
+with a few dozen bytes to spare (tests/test_gpu_fullsize.py guards it).  Prints algo id and milliseconds per chain."""
 import sys, time, os
 import numpy as np
-sys.path[:0] = ["/root/repo", "/root/repo/k8s-spark-scheduler_amd"]
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "k8s-spark-scheduler_amd")]
 import gangfit
 from gangfit import workloads as wl
 n_nodes, nz = 100000, 3
