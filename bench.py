@@ -873,7 +873,9 @@ def main():
                 "why": "one controlling wavefront (the chain is sequential in the applications, resource.go:224-262) on one SIMD: its "
                        "issue fraction is instructions / (1 SIMD x clock x kernel time); a LONE wavefront cannot issue faster than one "
                        "instruction per ~4.3 cycles, so `lone_wavefront_issue_frac` = instructions x 4.3 / cycles says how much of the "
-                       "chain's time is issue at that rate (the rest: LDS round trips and taken branches)",
+                       "chain's time is issue at that rate (the rest: vector -> scalar -> branch hand-overs, LDS round trips, taken branches — "
+                       "DESIGN.md 4.2, second pass; the instruction count is that of ALL sixteen wavefronts, prologue and epilogue "
+                       "included, so the controlling wavefront's own share is lower)",
                 "lone_wavefront_issue_frac": (instr_per_app * ISSUE / cyc_per_app) if (instr_per_app and cyc_per_app) else None,
                 "filter_p50_ms": ff["p50_ms"], "filter_p99_ms": ff["p99_ms"],
                 "filter_warm_p50_ms": ff["warm_creation_order_heads"]["p50_ms"], "filter_warm_p99_ms": ff["warm_creation_order_heads"]["p99_ms"],
