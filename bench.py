@@ -122,9 +122,10 @@ def cpu_baseline(w, budget_s: float = 10.0):
         "unit": "decisions/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{n_done // len(apps)} passes over the same {len(apps)}-app x {len(s.avail)}-node batch, "
-                  f"literal C restatement of SparkBinPack+tightlyPackExecutors on dense arrays (oracle/gangfit_oracle.c; the "
-                  f"reference's string-keyed maps and per-call allocations are NOT reproduced: conservative), {dt:.1f} s",
+        "sample": f"{n_done // len(apps)} passes over the same {len(apps)}-app x {len(s.avail)}-node batch, literal C port "
+                  f"(oracle/gangfit_oracle.c), 1 thread, {dt:.1f} s",
+        "note": "literal C restatement of SparkBinPack+tightlyPackExecutors on dense arrays; the reference's string-keyed maps and "
+                "per-call allocations are NOT reproduced: conservative",
     }
 
 
@@ -283,6 +284,106 @@ def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
     return c3
 
 
+# ------------------------------------------------------------------------------------------------ the contract line
+# The driver parses ONE JSON line from stdout.  Round 4's line carried every leg of the run (26 KB) and could not be parsed;
+# the line is now the contract's fields only (< 4 KB, tests/test_bench_line.py) and everything measured goes to
+# bench_full.json next to this file (GANGFIT_BENCH_FULL names another path).
+
+LINE_LIMIT = 4096
+
+
+def _r(x, digits=6):
+    """Numbers of the line with `digits` significant digits (the full precision is in bench_full.json)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _trim_roofline(rf):
+    """kernel, its time, bound / achieved / peak / unit / frac / traffic, the three fractions, the wait fraction."""
+    if not rf:
+        return None
+    out = {k: _r(rf.get(k)) for k in ("kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic", "wait_fraction")}
+    fr = rf.get("fractions") or {}
+    out["fractions"] = {k: _r(v.get("frac")) for k, v in fr.items()}
+    return out
+
+
+def compact_line(full):
+    """The ONE line of the contract from the full result dict: metric, value, unit, n_gpus, steps, warmup, ms_per_step, dtype,
+    config, a trimmed roofline (+ the FIFO chain's) and cpu_baseline.  Never longer than LINE_LIMIT characters."""
+    line = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    line["config"] = {k: _r(v) for k, v in cfg.items()}
+    rf = full.get("roofline") or {}
+    t = _trim_roofline(rf) or {}
+    reg = rf.get("regimes") or {}
+    t["regimes"] = {name: {"value": _r((reg.get(name) or {}).get("value")), "kernel_ms": _r((reg.get(name) or {}).get("kernel_ms"))}
+                    for name in ("streamed_tickets", "launch_per_batch") if reg.get(name)}
+    bc = reg.get("blocking_call") or {}
+    if bc.get("us_per_call") is not None:
+        t["regimes"]["blocking_call"] = {"value": _r(bc.get("value")), "us_per_call": _r(bc.get("us_per_call"))}
+    fc = rf.get("fifo_chain")
+    if fc:
+        c = _trim_roofline(fc)
+        for k in ("filter_p50_ms", "filter_p99_ms", "filter_warm_p50_ms", "lone_wavefront_issue_frac", "kernel_ms_le_filter_p50"):
+            c[k] = _r(fc.get(k))
+        t["fifo_chain"] = c
+    line["roofline"] = t
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+        c["sample"] = str(cb.get("sample") or "")[:160]
+        f = cb.get("fifo_chain") or {}
+        if f:
+            c["fifo_chain"] = {k: _r(f.get(k)) for k in ("literal_p50_ms", "with_efficiency_maps_p50_ms", "reference_shaped_p50_ms",
+                                                         "gpu_cold_p50_ms", "speedup_cold_p50", "cores", "kind")}
+        line["cpu_baseline"] = c
+    line["full"] = full.get("full_results_file")
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:  # cannot happen with the fields above; a guard, so that the driver always gets a line it can parse
+        for k in ("sample",):
+            if "cpu_baseline" in line:
+                line["cpu_baseline"].pop(k, None)
+        line["config"] = {k: v for k, v in line["config"].items() if not isinstance(v, str) or len(v) < 80}
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(full):
+    """Write everything to bench_full.json, print the contract line (the LAST thing on stdout)."""
+    path = os.environ.get("GANGFIT_BENCH_FULL", os.path.join(REPO, "bench_full.json"))
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["full_results_file"] = os.path.relpath(path, REPO) if path.startswith(REPO) else path
+    except OSError as e:
+        full["full_results_file"] = f"not written: {e}"
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start N ranks of this same command, one per GPU, the way
+    the driver would (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P).
+    Returns the exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 # ------------------------------------------------------------------------------------------------ main
 
 def main():
@@ -310,6 +411,8 @@ def main():
     args = ap.parse_args()
     if args.headline_only:
         args.no_extras = args.no_cpu_baseline = True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
 
@@ -320,23 +423,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` without WORLD_SIZE in the "
+                         "environment (it launches its own ranks) or under torch.distributed.run with --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only product path (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    n_visible = torch.cuda.device_count()
+    dev_index = local_rank % max(1, n_visible)  # one rank per GPU; ranks only share a device in the one-GPU smoke run
+    torch.cuda.set_device(dev_index)
     dist = None
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" (= RCCL over xGMI) always, except for the smoke test of this N > 1 control flow on a ONE-GPU box, where both
-        # ranks share cuda:0 (RCCL refuses that) and GANGFIT_BENCH_BACKEND=gloo stands in
-        backend = os.environ.get("GANGFIT_BENCH_BACKEND", "nccl")
+        # "nccl" (= RCCL over xGMI) whenever every rank has a GPU of its own.  RCCL refuses two ranks on one device, so the
+        # smoke run of this N > 1 control flow on a ONE-GPU box (tools/smoke_two_ranks_one_gpu.sh) runs over gloo: chosen
+        # by itself when the box has fewer GPUs than ranks, or by GANGFIT_BENCH_BACKEND=gloo.  The line says which it was.
+        backend = os.environ.get("GANGFIT_BENCH_BACKEND", "nccl" if n_visible >= world else "gloo")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
 
     # ---- workload: same node table everywhere, a different slice of the pending queue per rank
     w = wl.headline(args.nodes, args.apps, seed=0x5EED0010 + 7919 * rank)
@@ -641,7 +750,10 @@ def main():
                    "nodes": args.nodes, "apps_per_gpu": args.apps, "algo": "tightly-pack", "mode": "independent",
                    "batches_in_flight": args.worker_sets if used_worker else 1,
                    "regime": "streamed_tickets (resident worker)" if used_worker else "launch_per_batch (one graph of K launches)",
-                   "sharding": "pending apps across ranks, node table replicated, no collective"},
+                   "sharding": "pending apps across ranks, node table replicated, no collective",
+                   # what the process group was: "nccl" = RCCL over xGMI with one rank per GPU (rccl_ranks = its world size);
+                   # "gloo" only in the one-GPU smoke run of the N > 1 control flow; "none" for N = 1
+                   "backend": backend, "rccl_ranks": (dist.get_world_size() if (dist is not None and backend == "nccl") else 0)},
         "timing": {"windows": len(walls), "steps_per_window": args.steps, "statistic": "median of the windows (max over ranks each)",
                    "submission": ("resident worker: K tickets per window, one doorbell; the worker's launch and its departure are "
                                   "inside the window (gf_worker_submit_dev + gf_worker_stop)" if used_worker else
@@ -844,7 +956,23 @@ def main():
                   "warm_creation_order_heads": dict(summary(warm, st_warm, warm_n), heads=f"drivers {n_q - span} .. {n_q - 1} in creation order, cyclically; "
                                                     f"chains of {n_q - span + 1} .. {n_q} applications resumed from the previous chain's checkpoints"),
                   "warm_same_head": summary(retry, st_retry, warm_n)}
-            # shader cycles of one cold chain (in-kernel clock of the profiled variant of the same kernel)
+            # ---- the chain's roofline, over the time of the SHIPPED kernel: HIP events on the context's stream around the
+            #      device work of whole cold Filters (the chain kernel and the small launches before / behind it), checkpoints
+            #      off, rotated heads.  (Round 4 divided by the in-kernel cycle count of the instrumented variant, which runs
+            #      longer than the Filter it is part of; that count now only splits the time into phases, in `phases`.)
+            chain_ms = None
+            try:
+                ctx.set_option("chain_cache", 0)
+                evs = []
+                for i in range(12):
+                    ctx.timer_begin(0)
+                    chain_call(N.ptr(rolled_all[i]), n_q)
+                    evs.append(ctx.timer_end())
+                chain_ms = _median(evs[2:])
+            except Exception:
+                chain_ms = None
+            finally:
+                ctx.set_option("chain_cache", 1)
             cyc = ticks = 0
             if protos >= {"cold", "warm", "retry"}:  # (left out of the counter passes: their launches are all plain cold chains)
                 ctx.set_option("chain_cache", 0)
@@ -855,36 +983,43 @@ def main():
                 cyc, ticks = ctx.last_fifo_clock
             pmc = load_profile("pmc_chain.json")
             instr_per_app = (pmc or {}).get("fit_fifo_solo_instructions_per_app")
-            cyc_per_app = cyc / n_q if cyc else None
             clock_ghz = (cyc / (ticks * 10.0)) if ticks else CLOCK_GHZ
             ISSUE = 4.3  # cycles between two instructions of a lone wavefront (tools/micro/probe_issue.hip)
-            # the same three fractions as everywhere, per chain, over the kernel's own duration (in-kernel clock of this run):
-            # ONE SIMD's issue slots — fifteen of the sixteen wavefronts sleep at a barrier while wavefront 0 walks the chain
-            chain_s = (cyc / (clock_ghz * 1e9)) if cyc else None
+            # the same three fractions as everywhere, per chain: ONE SIMD's issue slots — the other wavefronts of the workgroup
+            # sleep at a barrier while wavefront 0 walks the chain
             cfr, cbound, cfrac = ({}, None, None)
-            if chain_s:
-                cfr, cbound, cfrac = three_fractions(chain_s, (pmc or {}).get("hbm_bytes_per_chain"), (pmc or {}).get("l2_request_bytes_per_chain"),
+            if chain_ms:
+                cfr, cbound, cfrac = three_fractions(chain_ms * 1e-3, (pmc or {}).get("hbm_bytes_per_chain"),
+                                                     (pmc or {}).get("l2_request_bytes_per_chain"),
                                                      instr_per_app * n_q if instr_per_app else None, simds=1)
             roofline["fifo_chain"] = {
-                "kernel": "fit_fifo_solo_kernel<tightly-pack>", "bound": cbound, "frac": cfrac, "fractions": cfr,
+                "kernel": "fit_fifo_solo_kernel<tightly-pack>", "kernel_ms": chain_ms,
+                "kernel_ms_is": "HIP events on the context's stream around the device work of one cold Filter (gf_timer_begin / "
+                                "gf_fit_batch / gf_timer_end), median of 10 rotated heads, checkpoints off: the shipped kernel",
+                "kernel_ms_le_filter_p50": (chain_ms <= ff["p50_ms"]) if chain_ms else None,
+                "bound": cbound, "frac": cfrac, "fractions": cfr,
                 "achieved": cfr[cbound]["achieved"] if cbound else None, "peak": cfr[cbound]["peak"] if cbound else None,
                 "unit": cfr[cbound]["unit"] if cbound else None,
                 "traffic": (pmc or {}).get("hbm_bytes_per_chain"),
                 "why": "one controlling wavefront (the chain is sequential in the applications, resource.go:224-262) on one SIMD: its "
                        "issue fraction is instructions / (1 SIMD x clock x kernel time); a LONE wavefront cannot issue faster than one "
-                       "instruction per ~4.3 cycles, so `lone_wavefront_issue_frac` = instructions x 4.3 / cycles says how much of the "
-                       "chain's time is issue at that rate (the rest: vector -> scalar -> branch hand-overs, LDS round trips, taken branches — "
-                       "DESIGN.md 4.2, second pass; the instruction count is that of ALL sixteen wavefronts, prologue and epilogue "
-                       "included, so the controlling wavefront's own share is lower)",
-                "lone_wavefront_issue_frac": (instr_per_app * ISSUE / cyc_per_app) if (instr_per_app and cyc_per_app) else None,
+                       "instruction per ~4.3 cycles, so `lone_wavefront_issue_frac` = instructions x 4.3 / (kernel time x clock) says "
+                       "how much of the chain's time is issue at that rate (the rest: vector -> scalar -> branch hand-overs, LDS round "
+                       "trips, taken branches — DESIGN.md 4.2; the instruction count is that of ALL the workgroup's wavefronts, "
+                       "prologue and epilogue included, so the controlling wavefront's own share is lower)",
+                "lone_wavefront_issue_frac": (instr_per_app * n_q * ISSUE / (chain_ms * 1e-3 * clock_ghz * 1e9))
+                                             if (instr_per_app and chain_ms) else None,
                 "filter_p50_ms": ff["p50_ms"], "filter_p99_ms": ff["p99_ms"],
                 "filter_warm_p50_ms": ff["warm_creation_order_heads"]["p50_ms"], "filter_warm_p99_ms": ff["warm_creation_order_heads"]["p99_ms"],
                 "filter_same_head_p50_ms": ff["warm_same_head"]["p50_ms"], "filter_same_head_p99_ms": ff["warm_same_head"]["p99_ms"],
-                "applications_per_chain": n_q, "shader_cycles_per_application": cyc_per_app,
-                "shader_clock_GHz": (cyc / (ticks * 10.0)) if ticks else None,
+                "applications_per_chain": n_q,
+                "phases": {"instrumented_variant_shader_cycles_per_application": (cyc / n_q) if cyc else None,
+                           "note": "in-kernel clock of the INSTRUMENTED variant (gf_scan_stats): slower than the shipped kernel, "
+                                   "information only — never a divisor of frac"},
+                "shader_clock_GHz": clock_ghz,
                 "instructions_per_application": instr_per_app, "issue_cycles_per_instruction": ISSUE,
                 "counters_from": (f"profiles/pmc_chain.json ({pmc.get('tag')}): rocprofv3 --pmc passes of `bench.py --no-extras "
-                                  "--fifo-protocols cold` — a committed profile, not this run; cycles ARE this run's") if pmc else None,
+                                  "--fifo-protocols cold` — a committed profile, not this run; the kernel time IS this run's") if pmc else None,
             }
             if not args.no_cpu_baseline:
                 ff["cpu_baseline"] = cpu_chain_baseline(0, s.avail, s.sched, None, s.driver_order, s.exec_order, w.drv, w.exe, w.k,
@@ -910,7 +1045,7 @@ def main():
         def _bail():
             if rank == 0:
                 out["node_sharded"] = {"error": "timeout: the node-sharded leg did not finish within 240 s"}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
 
         watchdog = threading.Timer(240.0 if rank == 0 else 250.0, _bail)
@@ -993,6 +1128,13 @@ def main():
                     except Exception as e:
                         grp[cfgname] = {"error": f"{type(e).__name__}: {e}"}
                 node_sharded["in_library_multi_device_context"] = grp
+                # the verdict of the in-library node-range sharding in the contract line: how many shards served,
+                # and whether each exchange's first sharded batch agreed with the first device's own answer
+                g_h = grp.get("headline") or {}
+                out["config"]["shard_count"] = (g_h.get("group") or {}).get("shard_count")
+                out["config"]["shard_devices"] = len(set(g_h.get("devices") or []))
+                out["config"]["group_selfcheck"] = {ex: bool((g_h.get(name) or {}).get("results_equal_one_device"))
+                                                    for ex, name in (("peer_stores", "group"), ("rccl", "group_rccl")) if name in g_h}
             out["node_sharded"] = node_sharded
         except Exception as e:  # the headline number above must survive a failure of this optional leg
             out["node_sharded"] = {"error": f"{type(e).__name__}: {e}"}
@@ -1291,7 +1433,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -1,11 +1,12 @@
 #!/bin/bash
-# Smoke test of bench.py's N > 1 control flow on a ONE-GPU box: two ranks, both on cuda:0, gloo instead of RCCL.
-# Checks that the run ends and rank 0 prints the one JSON line (numbers are meaningless: the ranks share the device).
+# Smoke test of bench.py's N > 1 control flow on a ONE-GPU box: `python bench.py --gpus 2` starts its own two ranks
+# (torch.distributed.run on 127.0.0.1); the box has fewer GPUs than ranks, so both ranks share cuda:0 and the process group
+# is gloo (RCCL refuses two ranks on one device).  Checks that the run ends with one parseable contract line, n_gpus = 2.
+# The numbers are meaningless: the ranks share the device.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-export MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 WORLD_SIZE=2 GANGFIT_BENCH_BACKEND=gloo
-RANK=1 LOCAL_RANK=0 timeout 400 python bench.py --gpus 2 --steps 20 --warmup 3 --windows 3 --filter-calls 5 --no-cpu-baseline > /tmp/rank1.log 2>&1 &
-RANK=0 LOCAL_RANK=0 timeout 400 python bench.py --gpus 2 --steps 20 --warmup 3 --windows 3 --filter-calls 5 --no-cpu-baseline
+GANGFIT_BENCH_FULL=${GANGFIT_BENCH_FULL:-/tmp/bench_full_two_ranks.json} \
+  timeout 500 python bench.py --gpus 2 --steps 20 --warmup 3 --windows 3 --filter-calls 5 --no-cpu-baseline > /tmp/two_ranks.out 2> /tmp/two_ranks.err
 rc=$?
-wait
-echo "rank0 rc=$rc"; tail -3 /tmp/rank1.log
+echo "rc=$rc"
+tail -1 /tmp/two_ranks.out | python -c "import sys, json; l = json.loads(sys.stdin.read()); print('parsed: n_gpus', l['n_gpus'], 'backend', l['config']['backend'], 'rccl_ranks', l['config']['rccl_ranks'], 'value', l['value'])" || tail -5 /tmp/two_ranks.err
