@@ -220,6 +220,23 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         if (total_k && !GF_STEP(0, hipMemcpyAsync(g->h_exec.ptr, first->g_exec2.ptr, (size_t)total_k * sizeof(uint32_t), hipMemcpyDeviceToHost, first->stream))) return;
         (void)GF_STEP(0, gf_wait_stream(first->stream));
     };
+    // An error must not return while the other devices' kernels, their peer stores into every gathered table, or pending
+    // reads of the pinned records are still running: the next batch reuses all of those buffers.  Every stream is waited
+    // for first; when even that fails the context stops sharding and serves from its first device.
+    auto drain_all = [&]() {
+        bool ok = true;
+        for (uint32_t d = 0; d < D; ++d) {
+            gf_ctx* c = g->group[d];
+            if (hipSetDevice(c->device) != hipSuccess || gf_wait_stream(c->stream) != hipSuccess) ok = false;
+        }
+        (void)hipGetLastError();
+        (void)hipSetDevice(first->device);
+        if (!ok) g->g_shard_off = true;
+    };
+    auto fail_drained = [&](const char* what) {
+        drain_all();
+        return fail(g, GF_ERR_HIP, "%s", what);
+    };
     if (use_rccl) {
         // RCCL exchange (one shard per device): every device's collective is enqueued on its own stream inside one group call
         // issued by THIS thread; the library orders the streams against each other
@@ -236,21 +253,21 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         for (uint32_t d = 0; d < D; ++d) step_partials(d);
         if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_part_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_part_all.ptr; },
                             (size_t)n_apps * sizeof(gf_shard_partial)) != 0)
-            return fail(g, GF_ERR_HIP, "ncclAllGather of the capacity sums failed");
+            return fail_drained("ncclAllGather of the capacity sums failed");
         for (uint32_t d = 0; d < D; ++d) step_drivers(d);
         if (rccl_all_gather([](gf_ctx* c) { return (const void*)c->g_drv_loc.ptr; }, [](gf_ctx* c) { return (void*)c->g_drv_all.ptr; },
                             (size_t)n_apps * sizeof(gf_shard_driver)) != 0)
-            return fail(g, GF_ERR_HIP, "ncclAllGather of the driver records failed");
+            return fail_drained("ncclAllGather of the driver records failed");
         for (uint32_t d = 0; d < D; ++d) step_emit(d);
         // the reduction north_star names: sum of the placement slices onto the first device, over xGMI
-        if (rccl().GroupStart() != 0) return fail(g, GF_ERR_HIP, "ncclGroupStart failed");
+        if (rccl().GroupStart() != 0) return fail_drained("ncclGroupStart failed");
         int bad = 0;
         for (uint32_t d = 0; d < D; ++d) {
             gf_ctx* c = g->group[d];
-            GF_HIP(g, hipSetDevice(c->device));
+            if (hipSetDevice(c->device) != hipSuccess) bad = 1;
             bad |= rccl().Reduce(c->g_exec2.ptr, first->g_exec2.ptr, (size_t)(2 * half), Rccl::kUint32, Rccl::kSum, 0, g->g_comms[d], c->stream);
         }
-        if ((rccl().GroupEnd() | bad) != 0) return fail(g, GF_ERR_HIP, "ncclReduce of the placements failed");
+        if ((rccl().GroupEnd() | bad) != 0) return fail_drained("ncclReduce of the placements failed");
         step_finish();
     } else if (D == 1 || g->g_pool == nullptr) {
         for (uint32_t d = 0; d < D; ++d) step_partials(d);
@@ -274,6 +291,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
 #undef GF_STEP
     for (uint32_t d = 0; d < D; ++d)
         if (rc_of[d] != GF_OK) {
+            drain_all();  // (step_finish returned without waiting for anything when an earlier step had failed)
             g->err = g->group[d]->err;
             return rc_of[d];
         }

@@ -74,10 +74,11 @@ class GangfitError(RuntimeError):
 
 _lib: Optional[C.CDLL] = None
 
-# The deployment's part ("Deployment"): sixteen hardware queues, so that concurrent views' chains do not share
-# one.  The HIP runtime reads it when it initialises (its first call in the process — torch's, if torch gets there first), so
-# it is set when this package is imported; the library itself never touches the environment.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# GPU_MAX_HW_QUEUES=16 (sixteen hardware queues, so that concurrent views' chains do not share one) is the DEPLOYMENT's
+# setting ("Deployment"): neither the library nor this package changes the process environment.  The HIP
+# runtime reads the variable when it initialises, so whoever starts the process sets it — tests/conftest.py and bench.py do
+# so explicitly, host_test.cpp's main() does, a Go host's unit file does.  gf_ctx_view leaves a note in gf_last_error when it
+# finds fewer than 8.
 
 
 def library_path() -> str:

@@ -77,9 +77,8 @@ SelectNodeResult SparkSchedulerExtender::selectDriverNode(const std::string& ins
             apps.push_back(a);
         }
     }
-    // pods come and go: entries no request has used lately are dropped once the map outgrows the pods it is asked about
-    if (parsed_apps_.size() > 2 * pods.size() + 64)
-        for (auto it = parsed_apps_.begin(); it != parsed_apps_.end();) it = it->second.seen == flat_calls_ ? std::next(it) : parsed_apps_.erase(it);
+    // (this route parses every pod afresh and never touches parsed_apps_: the cache and its prune belong to the flat route,
+    //  under flat_mu_)
     gf_app cur{};
     if (!resources->DriverResources.canonical(cur.drv) || !resources->ExecutorResources.canonical(cur.exe) ||
         resources->MinExecutorCount < 0 || resources->MinExecutorCount > GF_MAX_K) {

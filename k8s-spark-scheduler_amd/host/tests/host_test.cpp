@@ -1106,15 +1106,6 @@ static void TestMultiDeviceContext() {
                gf_orders_set(c, order.data(), n, order.data(), n) == GF_OK &&
                gf_fit_batch(c, GF_MODE_INDEPENDENT, algo, n_apps, apps.data(), res->data(), exec->data(), total_k, nullptr) == GF_OK;
     };
-    // every shard on device 0: the one-GPU form of the eight-GPU context — first with the shards of the device in ONE sub-context
-    // (a launch per step, a grid row per shard), then with every listed id in a sub-context, stream and submitting thread of its
-    // own (GANGFIT_TEST_GROUP_SPLIT: events between streams, host barriers, pushes into several tables, the placement pull)
-    for (int pass = 0; pass < 2; ++pass)
-    for (int n_dev : {2, 5, 8}) {
-        if (pass == 1)
-            (void)setenv("GANGFIT_TEST_GROUP_SPLIT", "1", 1);
-        else
-            (void)unsetenv("GANGFIT_TEST_GROUP_SPLIT");
     // ---- a box nobody has tried the context on: (a) devices that cannot reach each other's memory degrade the context to its
     //      first device; (b) a wrong exchange (1: the placement pull never runs, 2: the other devices' capacity sums arrive as
     //      zeros) is caught by the self-check of the first sharded batch — right answers, sharding off, the context says why
@@ -1160,6 +1151,16 @@ static void TestMultiDeviceContext() {
         gf_destroy(g);
     }
     (void)unsetenv("GANGFIT_TEST_GROUP_SPLIT");
+    // every shard on device 0: the one-GPU form of the eight-GPU context — first with the shards of the device in ONE sub-context
+    // (a launch per step, a grid row per shard), then with every listed id in a sub-context, stream and submitting thread of its
+    // own (GANGFIT_TEST_GROUP_SPLIT: events between streams, host barriers, pushes into several tables, the placement pull)
+    for (int pass = 0; pass < 2; ++pass)
+    for (int n_dev : {2, 5, 8}) {
+        // gf_init reads the switch: set (or cleared) right before it
+        if (pass == 1)
+            (void)setenv("GANGFIT_TEST_GROUP_SPLIT", "1", 1);
+        else
+            (void)unsetenv("GANGFIT_TEST_GROUP_SPLIT");
         std::vector<int> ids((size_t)n_dev, 0);
         gf_ctx* g = nullptr;
         CHECK(gf_init(ids.data(), n_dev, &g) == GF_OK);

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the deployment's setting ("Deployment"), made here because this process IS the deployment of the test run:
+# before anything initialises the HIP runtime
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "k8s-spark-scheduler_amd"), os.path.join(REPO, "tests")):
     if p not in sys.path:

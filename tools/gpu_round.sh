@@ -1,9 +1,11 @@
 #!/bin/bash
 # One GPU visit: the -m gpu parity suite, the torch-free host tests, the driver's bench command and the default one, then
 # the profiling recipe.  Everything lands under gpurun_out/<tag>/ (merged back by gpurun).
-#   tools/gpu_round.sh <tag> [tests|bench|prof ...]   (default: all three)
+#   tools/gpu_round.sh <tag> [go|tests|bench|two|prof ...]   (default: tests bench prof)
+#     go    is there a Go toolchain on the box (integration/go/run_pins.sh needs Go 1.19)?
+#     two   `python bench.py --gpus 2` on this one-GPU box: the N > 1 control flow starting its own ranks
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 shift || true
 WHAT=${*:-tests bench prof}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -20,11 +22,21 @@ for w in $WHAT; do
       tail -2 "$OUT/host_test_gpu.log"
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -1 "$OUT/smoke.log"
       ;;
+    go)
+      { command -v go; ls -d /usr/local/go /usr/lib/go* 2>/dev/null; go version 2>&1; } > "$OUT/go_probe.txt" 2>&1; cat "$OUT/go_probe.txt"
+      # (run_pins.sh also needs a checkout of the reference, which does not travel to the box: the probe only records
+      #  whether the toolchain exists there)
+      ;;
     bench)
-      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"; echo "bench20 rc=$?"
-      cut -c1-700 "$OUT/bench_steps20.json"
-      timeout 900 python bench.py --no-extras --no-cpu-baseline > "$OUT/bench_default_headline.json" 2> "$OUT/bench_default.err"; echo "bench rc=$?"
-      cut -c1-400 "$OUT/bench_default_headline.json"
+      t0=$(date +%s.%N)
+      GANGFIT_BENCH_FULL="$OUT/bench_full_steps20.json" timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"; echo "bench20 rc=$? wall=$(echo "$(date +%s.%N) - $t0" | bc) s"
+      tail -1 "$OUT/bench_steps20.json" | wc -c; tail -1 "$OUT/bench_steps20.json"
+      GANGFIT_BENCH_FULL="$OUT/bench_full_default_headline.json" timeout 900 python bench.py --no-extras --no-cpu-baseline > "$OUT/bench_default_headline.json" 2> "$OUT/bench_default.err"; echo "bench rc=$?"
+      tail -1 "$OUT/bench_default_headline.json" | cut -c1-600
+      ;;
+    two)
+      GANGFIT_BENCH_FULL="$OUT/bench_full_two_ranks.json" bash tools/smoke_two_ranks_one_gpu.sh > "$OUT/two_ranks.log" 2>&1; cat "$OUT/two_ranks.log"
+      cp /tmp/two_ranks.out "$OUT/two_ranks.out" 2>/dev/null; tail -30 /tmp/two_ranks.err > "$OUT/two_ranks.err" 2>/dev/null
       ;;
     prof)
       bash tools/profile_round.sh "$TAG" ${PROF_GROUPS:-} > "$OUT/profile.log" 2>&1; tail -12 "$OUT/profile.log"
