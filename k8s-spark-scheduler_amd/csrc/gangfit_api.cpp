@@ -211,6 +211,7 @@ int gf_ctx_view(gf_ctx* parent, gf_ctx** out) {
         v->fifo_minfrag_hist = parent->fifo_minfrag_hist;
         v->chain_cache_on = parent->chain_cache_on;
         v->zero_copy = parent->zero_copy;
+        v->zoned_fused = parent->zoned_fused;
     }
     v->view_of = parent;
     // The HIP runtime multiplexes streams over a few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise, read when
@@ -424,6 +425,8 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->sparse_gpu = value != 0;
     } else if (k == "zero_copy") {
         ctx->zero_copy = value != 0;
+    } else if (k == "zoned_fused") {
+        ctx->zoned_fused = value != 0;
     } else if (k == "snapshot_finalize_host") {
         ctx->snapshot_finalize_on_device = value == 0;
     } else if (k == "sort_fault") {

@@ -325,6 +325,17 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     const int inner = algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ? GF_ALGO_MINIMAL_FRAGMENTATION : GF_ALGO_TIGHTLY_PACK;
     const uint64_t half = exec_nodes_len + 1;
     const uint32_t nz = ctx->n_zones;
+    if (mode == GF_MODE_INDEPENDENT && ctx->zoned_fused && nz + 1 <= 64) {
+        // one launch: a workgroup per application decides every candidate view, chooses and writes the final answer
+        // (fit_zoned_fused_kernel) — d_apps / d_results / d_exec_nodes may be device-mapped host memory (gf_fit_batch)
+        GF_HIP(ctx, ctx->d_zexec.reserve(((uint64_t)nz + 1) * half));
+        gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)ctx->zd_row0 * ctx->zstride, nz, ctx->zstride};
+        if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;
+        GF_HIP(ctx, gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), zt,
+                                                    ctx->d_sched.ptr, ctx->d_zexec.ptr, half, n_apps, d_apps, d_results,
+                                                    d_exec_nodes, ctx->d_scratch.ptr, half, stream));
+        return GF_OK;
+    }
     const uint64_t n_dec = (uint64_t)n_apps * (nz ? nz : 1);
     GF_HIP(ctx, ctx->d_zres.reserve(n_dec));
     GF_HIP(ctx, ctx->d_zexec.reserve(((uint64_t)nz + 1) * half));
@@ -680,7 +691,8 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     // Small independent batches of the plain packers skip the three staging copies: the kernel reads the app records from
     // the pinned staging buffer and writes results and placements straight into pinned host memory (posted PCIe writes,
     // visible when the kernel has completed).  A copy engine round trip costs more than the whole kernel at these sizes.
-    if (ctx->zero_copy && mode == GF_MODE_INDEPENDENT && !is_zone_algo(algo) && ctx->have_orders &&
+    if (ctx->zero_copy && mode == GF_MODE_INDEPENDENT && ctx->have_orders &&
+        (!is_zone_algo(algo) || (ctx->zoned_fused && ctx->have_sched && ctx->n_zones + 1 <= 64)) &&
         (uint64_t)n_apps * sizeof(gf_app) + total_k * sizeof(uint32_t) <= (UINT64_C(4) << 20)) {
         void *da = ctx->h_apps.dev, *dr = ctx->h_results.dev, *de = ctx->h_exec.dev;
         if (da != nullptr && dr != nullptr && de != nullptr) {

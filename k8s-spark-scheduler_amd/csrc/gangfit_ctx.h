@@ -283,6 +283,7 @@ struct gf_ctx {
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
     bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
+    bool zoned_fused = true;       // option "zoned_fused" = 0: independent batches of the zone-aware packers take the four-kernel path
     double call_phase_us[5] = {0, 0, 0, 0, 0};  // last gf_fit_batch on the zero-copy path: stage | launch | wait | copy out | total
     PinnedBuf<uint64_t> h_masks;
     DeviceBuf<gangfit::NApp> d_napps;       // FIFO chain: app records in the narrow domain (chain_prologue_kernel)

@@ -253,6 +253,14 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
                             const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                             uint64_t scratch_half, hipStream_t stream);
 
+// The same as ONE launch (fit_zoned_fused_kernel): a workgroup per application, a wavefront per candidate view, the choice
+// through LDS, the winner's placements written as node indices to d_exec_nodes / d_results — which may be device-mapped host
+// memory.  d_zexec: (n_zones + 1) rows of zexec_stride uint32 (the candidates' placements as slot ids).  At most 64 views.
+hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const ZoneTable& zones,
+                                  const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
+                                  const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                                  uint64_t scratch_half, hipStream_t stream);
+
 // FIFO chain for any packer (zone-aware ones included): one workgroup, one wavefront per candidate view of the current
 // app (each zone, plus the plain pack for az-aware), working table in global memory.  buf.zexec needs
 // (n_zones + 1) rows, buf.cnt at least 16 rows.  Writes final results / placements as node indices.

@@ -1938,6 +1938,28 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
     return hipGetLastError();
 }
 
+hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const ZoneTable& zones,
+                                  const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
+                                  const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
+                                  uint64_t scratch_half, hipStream_t stream) {
+    if (n_apps == 0) return hipSuccess;
+    if (inner_algo != GF_ALGO_TIGHTLY_PACK && inner_algo != GF_ALGO_MINIMAL_FRAGMENTATION) return hipErrorInvalidValue;
+    if (az_aware && inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
+    if (zones.n_zones + (az_aware ? 1u : 0u) > 64u) return hipErrorInvalidValue;
+    const dim3 grid(n_apps), block(kWave * kFusedWaves);
+#define GF_FUSED(ALGO, AZ)                                                                                             \
+    hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ>), grid, block, 0, stream, table, zones, d_sched, n_apps, d_apps, \
+                       d_results, d_exec_nodes, d_zexec, zexec_stride, d_scratch, scratch_half)
+    if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+        GF_FUSED(GF_ALGO_MINIMAL_FRAGMENTATION, false);
+    else if (az_aware)
+        GF_FUSED(GF_ALGO_TIGHTLY_PACK, true);
+    else
+        GF_FUSED(GF_ALGO_TIGHTLY_PACK, false);
+#undef GF_FUSED
+    return hipGetLastError();
+}
+
 hipError_t launch_fit_fifo_generic(int inner_algo, bool zoned, bool az_aware, bool reserve_execs, const NodeTable& table,
                                    const ZoneTable& zones, const int64_t* d_sched, const ZoneBuffers& buf,
                                    uint32_t n_apps, const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes,

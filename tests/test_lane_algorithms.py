@@ -231,3 +231,61 @@ def test_bounded_chooser_never_disagrees_with_the_slice_order_sums():
             decided += 1
             assert got == want, (feas, exact, approx, err)
     assert decided > 1500 and undecided > 50  # both branches exercised (the ties are undecided by construction)
+
+
+# ---------------------------------------------------------------------------------------------- reserved counts without a table
+# fit_zoned_fused_kernel (csrc/gangfit_zones.inc, wave_avg_efficiency_runs) needs, for the average packing efficiency of a
+# tightly-pack result, the number of executors on every node of the list (reserved[n] = count x exe, efficiency.go:79-103).
+# Instead of counting them in a per-wavefront table it uses what tightlyPackExecutors guarantees (pack_tightly.go:45-61): every
+# node of the list is one contiguous run filled to its capacity — computed with the driver reserved on the driver's node —,
+# except the LAST node, which holds K minus the index of its first entry.  Checked here against the literal oracle.
+
+def _cap(avail_row, exe, k):
+    c = k
+    for a, e in zip(avail_row, exe):
+        if a < 0:
+            return 0
+        if e > 0:
+            c = min(c, int(a) // int(e))
+    return c
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tightly_pack_counts_follow_from_capacities(seed):
+    import os
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (repo, os.path.join(repo, "k8s-spark-scheduler_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gangfit import workloads as wl
+    from oracle import binding as ob
+
+    w = wl.headline(200 + 37 * seed, 120, seed=0xC0FFEE + seed)
+    s = w.snapshot
+    apps = ob.make_apps(w.drv, w.exe, w.k, w.flags)
+    ref = ob.fit_independent(0, s.avail, apps, s.driver_order, s.exec_order, closed_form=False)
+    checked = multi = driver_listed = 0
+    for a in np.nonzero(ref.results["has_capacity"])[0]:
+        _, driver, nodes = ref.placement(int(a))
+        k = int(w.k[a])
+        if k == 0:
+            continue
+        nodes = [int(n) for n in nodes]
+        # one contiguous run per node
+        firsts = [i for i in range(k) if i == 0 or nodes[i - 1] != nodes[i]]
+        assert len(set(nodes[i] for i in firsts)) == len(firsts)
+        last, last_first = nodes[-1], firsts[-1]
+        for i in firsts:
+            n = nodes[i]
+            true_count = nodes.count(n)
+            row = s.avail[n].astype(np.int64).copy()
+            if n == driver:
+                row -= np.asarray(w.drv[a], dtype=np.int64)
+            rule = (k - last_first) if n == last else _cap(row, w.exe[a], k)
+            assert rule == true_count, (int(a), n, rule, true_count)
+            checked += 1
+            multi += true_count > 1
+        driver_listed += driver in nodes
+    assert checked > 100 and multi > 10 and driver_listed > 0
