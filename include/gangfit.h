@@ -426,6 +426,14 @@ int gf_timer_end(gf_ctx *ctx, float *elapsed_ms);
  * out may be NULL. */
 int gf_scan_stats(gf_ctx *ctx, int enable, int reset, uint64_t out[10]);
 
+/* Measurement helper (tools/probe_c5_heads.py): what the last FIFO chain of a plain packer did besides its common path, taken by
+ * the instrumented kernel variant (gf_scan_stats enabled before the chain).  out[0..4] = applications that left the common path,
+ * by ending: [1] a request without a shape id, [2] rejected by the capacity bound, [3] no driver candidate, [4] the gang did not
+ * fit behind its first driver candidate (rollback + the generic decision); out[5..9] = shader cycles spent in those endings, same
+ * index; out[10] / out[11] = the HW_ID / XCC_ID hardware registers of the chain's controlling wavefront (which compute unit of
+ * which XCD the one workgroup ran on).  Nothing in the reference corresponds to it. */
+int gf_chain_profile(gf_ctx *ctx, uint64_t out[12]);
+
 /* On-device self-test of the wave primitives (DPP prefix scan, exact clamped 64-bit division) against plain
  * reference code on n_cases adversarial inputs per lane.  *mismatches == 0 means pass. */
 int gf_selftest(gf_ctx *ctx, uint64_t seed, uint32_t n_cases, uint32_t *mismatches);

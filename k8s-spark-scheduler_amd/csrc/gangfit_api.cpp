@@ -677,6 +677,23 @@ int gf_scan_stats(gf_ctx* ctx, int enable, int reset, uint64_t out[10]) {
     return GF_OK;
 }
 
+int gf_chain_profile(gf_ctx* ctx, uint64_t out[12]) {
+    GF_DELEGATE(ctx, gf_chain_profile(ctx, out));
+    if (!ctx || !out) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, gf_wait_stream(ctx->stream));
+    ScanStats s;
+    GF_HIP(ctx, hipMemcpy(&s, ctx->d_stats.ptr, sizeof s, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; ++i) {
+        out[i] = s.fifo_rare_count[i];
+        out[5 + i] = s.fifo_rare_cycles[i];
+    }
+    out[10] = s.fifo_hw_id & 0xFFFFFFFFull;
+    out[11] = s.fifo_hw_id >> 32;
+    return GF_OK;
+}
+
 int gf_selftest(gf_ctx* ctx, uint64_t seed, uint32_t n_cases, uint32_t* mismatches) {
     GF_DELEGATE(ctx, gf_selftest(ctx, seed, n_cases, mismatches));
     if (!ctx || !mismatches) return GF_ERR_INVALID;

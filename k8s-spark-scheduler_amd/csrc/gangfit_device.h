@@ -110,6 +110,11 @@ struct ScanStats {
     unsigned long long fifo_shader_cycles;    // s_memtime delta over the last FIFO chain kernel (shader clock)
     unsigned long long fifo_realtime_ticks;   // s_memrealtime delta over the same span (constant 100 MHz)
     unsigned long long fifo_phase_cycles[6];  // wave-0 shader cycles: stage | driver scan | executor scan | slow path | commit | steps
+    // the solo chain's rare endings (gangfit_fifo_solo.inc, instrumented variant only), by return code: [1] a request without
+    // a shape id, [2] the capacity bound, [3] no driver candidate, [4] the gang does not fit behind its first driver
+    unsigned long long fifo_rare_count[5];
+    unsigned long long fifo_rare_cycles[5];   // shader cycles inside solo_rare_app, same index
+    unsigned long long fifo_hw_id;            // HW_ID of the chain's controlling wavefront (CU, SE, ...) | XCC_ID << 32
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).

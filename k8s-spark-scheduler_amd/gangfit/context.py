@@ -421,6 +421,15 @@ class Context:
         self.last_fifo_phases = [int(v) for v in out[4:10]]  # stage, driver scan, executor scan, slow path, commit
         return int(out[0]), int(out[1])
 
+    def chain_profile(self) -> dict:
+        """gf_chain_profile: the rare endings of the last instrumented FIFO chain and where its workgroup ran."""
+        out = np.zeros(12, dtype=np.uint64)
+        self._check(self._lib.gf_chain_profile(self._h, N.ptr(out)))
+        names = ("", "unindexed", "bound", "no_driver", "short")
+        return {"rare_count": {names[i]: int(out[i]) for i in range(1, 5)},
+                "rare_cycles": {names[i]: int(out[5 + i]) for i in range(1, 5)},
+                "hw_id": int(out[10]), "xcc_id": int(out[11])}
+
     def hbm_probe(self, nbytes: int = 2 << 30, iters: int = 10):
         """(read-only stream GB/s, copy read + write GB/s) this device delivers on `nbytes` buffers."""
         rd, cp = C.c_double(0.0), C.c_double(0.0)

@@ -85,9 +85,24 @@ for i in range(n_heads):
     xv, dv = ctx.scan_stats(enable=False, reset=False)
     cyc, ticks = ctx.last_fifo_clock
     ph = ctx.last_fifo_phases
+    prof = ctx.chain_profile()
     rows[i].update({"exec_slots_visited": xv, "driver_slots_visited": dv, "kernel_ms_instrumented": ticks / 1e5,
                     "phase_cycles": {"stage": ph[0], "driver_scan": ph[1], "executor_scan": ph[2], "slow_path": ph[3], "commit": ph[4],
-                                     "spare": ph[5]}})
+                                     "spare": ph[5]},
+                    "rare_count": prof["rare_count"], "rare_cycles": prof["rare_cycles"], "hw_id": prof["hw_id"], "xcc_id": prof["xcc_id"]})
+# is a head slow every time?  the first 24 heads three times each, instrumented, back to back
+repeats = []
+for i in range(min(24, n_heads)):
+    q = np.roll(q5, -(i + 3))
+    trio = []
+    for _ in range(3):
+        ctx.scan_stats(enable=True, reset=True)
+        ctx.fit_batch(FIFO, TIGHT, q)
+        ctx.scan_stats(enable=False, reset=False)
+        pr = ctx.chain_profile()
+        trio.append({"kernel_ms": ctx.last_fifo_clock[1] / 1e5, "short": pr["rare_count"]["short"], "short_cycles": pr["rare_cycles"]["short"],
+                     "xcc": pr["xcc_id"] & 0xF, "hw_id": pr["hw_id"]})
+    repeats.append({"head": i + 3, "runs": trio})
 ctx.close()
 
 lat = np.array([r["ms_cache_off"] for r in rows])
@@ -111,8 +126,21 @@ for pk in ("stage", "driver_scan", "executor_scan", "slow_path", "commit", "spar
     c = float(np.corrcoef(v, lat)[0, 1]) if v.std() > 0 else 0.0
     summary["cycles_" + pk] = {"fast_mean": f, "slow_mean": s_, "corr_with_ms": c}
     print(f"{'cycles ' + pk:32s} {f:14.0f} {s_:14.0f} {c:13.3f}")
+for code in ("unindexed", "bound", "no_driver", "short"):
+    n_ = np.array([float(r["rare_count"][code]) for r in rows])
+    cy = np.array([float(r["rare_cycles"][code]) for r in rows])
+    ki = np.array([float(r["kernel_ms_instrumented"]) for r in rows])
+    sl = ki > 1.2 * np.median(ki)
+    print(f"rare ending {code:10s}: count fast {n_[~sl].mean():7.2f} slow {n_[sl].mean():7.2f}   cycles fast {cy[~sl].mean():12.0f} slow {cy[sl].mean():12.0f}"
+          f"   (clusters by the instrumented kernel's own time: {int(sl.sum())} slow heads)")
+ki = np.array([float(r["kernel_ms_instrumented"]) for r in rows])
+xcc = np.array([r["xcc_id"] & 0xF for r in rows])
+print("# instrumented kernel ms by XCC_ID[3:0]:", {int(x): (int((xcc == x).sum()), round(float(ki[xcc == x].mean()), 3), round(float(ki[xcc == x].max()), 3)) for x in np.unique(xcc)})
+print("# the first heads three times each (kernel ms / 'short' endings / XCC):")
+for r in repeats:
+    print("  head", r["head"], " | ".join(f"{t['kernel_ms']:.3f} ms short={t['short']} ({t['short_cycles']} cyc) xcc={t['xcc']}" for t in r["runs"]))
 print("# quartiles (cache off):", [round(float(np.percentile(lat, p)), 3) for p in (0, 25, 50, 75, 100)])
 print("# quartiles (cache on) :", [round(float(np.percentile([r['ms_cache_on'] for r in rows], p)), 3) for p in (0, 25, 50, 75, 100)])
 if out_path:
     with open(out_path, "w") as f:
-        json.dump({"device": info, "n_heads": n_heads, "median_ms": med, "summary": summary, "heads": rows}, f, indent=1)
+        json.dump({"device": info, "n_heads": n_heads, "median_ms": med, "summary": summary, "heads": rows, "repeats": repeats}, f, indent=1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe of one round (run on the MI355X box through gpurun; outputs under gpurun_out/prof_<tag>/).
-#   tools/profile_round.sh <tag> [headline chain config3 full host ...]      (default: all five groups)
+#   tools/profile_round.sh <tag> [headline chain config3 zoned full host ...]      (default: all six groups)
 # Every group = one bench.py command profiled by SEPARATE rocprofv3 runs: --kernel-trace --stats for the durations, then one
 # --pmc run per counter set with --kernel-trace only (never combined with sys / runtime / hip / hsa trace domains):
 #   FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | the SQ set (waves, cycles, instructions by type, waits)
@@ -10,12 +10,17 @@
 #   chain     bench.py --no-extras --fifo-protocols cold: every fit_fifo_solo_kernel launch replays the headline chain
 #                                                                                        -> profiles/pmc_chain.json
 #   config3   bench.py --config3-only (10 000 nodes x 10 000 apps, both packers)          -> profiles/pmc_config3.json
+#   zoned     the kernels of the zone-aware and minimal-fragmentation packers, ONE instantiation per profiled command
+#             (tools/profile_cmd.py): the one-launch independent batch (fit_zoned_fused_kernel: single-az-tightly-pack,
+#             single-az-minimal-fragmentation), the LDS chains (fit_fifo_zoned_lds_kernel: single-az / az-aware tightly-pack;
+#             fit_fifo_minfrag_lds_kernel: plain = the 8-wavefront instantiation, single-AZ = the 16-wavefront one); the
+#             four counter sets and the LDS set each                                  -> profiles/pmc_zoned.json
 #   full      the driver's command with extras (every chain kernel appears): durations only + the LDS counter set
 #   host      the whole Filter through the C++ mirror of the reference's interface (host_bench) -> profiles/<tag>_host_filter.txt
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 shift || true
-GROUPS_=${*:-headline chain config3 full host}
+GROUPS_=${*:-headline chain config3 zoned full host}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -40,6 +45,16 @@ for g in $GROUPS_; do
       ;;
     config3)
       run_group c3 300 python $ROOT/bench.py --config3-only
+      ;;
+    zoned)
+      LDSSET="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_WAVE_CYCLES"
+      for spec in "zb_saz batch single-az-tightly-pack" "zb_smf batch single-az-minimal-fragmentation" \
+                  "zc_saz chain single-az-tightly-pack" "zc_aza chain az-aware-tightly-pack" \
+                  "mc_mf chain minimal-fragmentation" "mc_smf chain single-az-minimal-fragmentation"; do
+        set -- $spec
+        run_group $1 120 python $ROOT/tools/profile_cmd.py $2 $3
+        timeout 120 rocprofv3 --kernel-trace --pmc $LDSSET -T -f csv -d "$OUT/$1_lds" -o pmc -- python $ROOT/tools/profile_cmd.py $2 $3 > "$OUT/$1_lds.log" 2>&1
+      done
       ;;
     full)
       FULL="python $ROOT/bench.py --steps 50 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline --worker-sets 0 ${BENCH_ARGS:-}"

@@ -89,7 +89,7 @@ def _avg_ns(path, name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
     src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -201,6 +201,62 @@ def main():
         md += ("## BASELINE config 3 alone (`bench.py --config3-only`: 10 000 nodes x 10 000 apps, both packers)\n\n" +
                (_stats_table(kst, ("fit_independent",)) + "\n" if os.path.exists(kst) else "") +
                "```json\n" + json.dumps(c3, indent=1) + "\n```\n\n")
+
+    # ---- the zone-aware / minimal-fragmentation kernels, one instantiation per profiled command (tools/profile_cmd.py)
+    ZONED = (("zb_saz", "fit_zoned_fused_kernel", "single-az-tightly-pack", "independent batch, one launch", 1024),
+             ("zb_smf", "fit_zoned_fused_kernel", "single-az-minimal-fragmentation", "independent batch, one launch", 1024),
+             ("zc_saz", "fit_fifo_zoned_lds_kernel", "single-az-tightly-pack", "cold FIFO chain", 4),
+             ("zc_aza", "fit_fifo_zoned_lds_kernel", "az-aware-tightly-pack", "cold FIFO chain", 4),
+             ("mc_mf", "fit_fifo_minfrag_lds_kernel", "minimal-fragmentation", "cold FIFO chain (8-wavefront instantiation)", 4),
+             ("mc_smf", "fit_fifo_minfrag_lds_kernel", "single-az-minimal-fragmentation", "cold FIFO chain (16-wavefront instantiation)", 4))
+    zj = {"tag": tag, "note": "per launch of ONE instantiation (tools/profile_cmd.py: 10 000 nodes x 1 000 applications, 3 zones, AZ-major order); "
+                              "hbm_bytes = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB; l2_request_bytes = (TCC_HIT_sum + TCC_MISS_sum) x 128; "
+                              "instructions = SQ_INSTS_VALU + SALU + LDS + SMEM of all wavefronts; fractions over rocprofv3's average dispatch "
+                              "duration of the same command: hbm / 8 TB/s, l2 / 34.5 TB/s, issue / (simds x 2.4 GHz) with simds = 1 024 for a "
+                              "grid-wide kernel and 4 (one compute unit) for a one-workgroup chain kernel",
+          "kernels": {}}
+    zmd = ""
+    for pre, kname, algo, what, simds in ZONED:
+        per = _group_means(src, pre)
+        for r in _rows(src, f"{pre}_lds"):
+            per.setdefault(r["Kernel_Name"], collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        k = next((x for x in per if x.startswith(kname)), None)
+        st = os.path.join(src, f"{pre}_stats", "stats_kernel_stats.csv")
+        if k is None:
+            continue
+        dump_group(pre, {k: per[k]})
+        mean = {c: sum(v) / len(v) for c, v in per[k].items()}
+        d = _derive(mean, 1.0)
+        a, n = _avg_ns(st, kname)
+        e = {"kernel": kname, "algo": algo, "what": what, "launches": len(next(iter(per[k].values()))), "avg_dispatch_ns": a, "dispatches_in_stats": n,
+             "hbm_bytes": d.get("hbm_bytes"), "l2_request_bytes": d.get("l2_request_bytes"), "instructions": d.get("instructions"),
+             "wait_fraction": d.get("wait_fraction"), "simds": simds,
+             "lds_bank_conflict_per_active_lds_cycle": (mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_ACTIVE_INST_LDS"]) if mean.get("SQ_ACTIVE_INST_LDS") else None,
+             "counters": mean}
+        if a:
+            t = a * 1e-9
+            fr = {}
+            if e["hbm_bytes"] is not None:
+                fr["hbm"] = e["hbm_bytes"] / t / 8e12
+            if e["l2_request_bytes"] is not None:
+                fr["l2"] = e["l2_request_bytes"] / t / 34.5e12
+            if e["instructions"] is not None:
+                fr["issue"] = e["instructions"] / t / (simds * 2.4e9)
+            e["fractions"] = fr
+            if fr:
+                e["bound"] = max(fr, key=fr.get)
+                e["frac"] = fr[e["bound"]]
+        zj["kernels"][pre] = e
+        if os.path.exists(st):
+            shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats_{pre}.csv"))
+        zmd += (f"| {kname} | {algo} | {what} | {e['launches']} | {(a or 0) / 1e3:.1f} | {e.get('hbm_bytes') or 0:.0f} | {e.get('l2_request_bytes') or 0:.0f} | "
+                f"{e.get('instructions') or 0:.0f} | {(e.get('wait_fraction') or 0):.2f} | {(e.get('lds_bank_conflict_per_active_lds_cycle') or 0):.2f} | "
+                + " / ".join(f"{k2} {v2:.4f}" for k2, v2 in (e.get('fractions') or {}).items()) + " |\n")
+    if zj["kernels"]:
+        json.dump(zj, open(os.path.join(dst, "pmc_zoned.json"), "w"), indent=1)
+        md += ("## the zone-aware and minimal-fragmentation kernels, one instantiation per profiled command (`tools/profile_cmd.py`)\n\n"
+               "| kernel | packer | what | launches | avg us | HBM B | L2 request B | instructions | wait | LDS conflict / active | fractions |\n"
+               "|---|---|---|---|---|---|---|---|---|---|---|\n" + zmd + "\n" + zj["note"] + "\n\n")
 
     # ---- the full run (every chain kernel) + its LDS counter set
     stats = os.path.join(src, "stats", "stats_kernel_stats.csv")
