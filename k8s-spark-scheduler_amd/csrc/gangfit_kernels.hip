@@ -1624,6 +1624,18 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
         }
         if (cap_dim(a, e, rcp, k) != want) ++bad;
         if (cap_dim(a, 0, 0.0, k) != (a < 0 ? 0 : k)) ++bad;
+        // (b2) the unclamped quotient of minimal-fragmentation (cap_dim_full): the same operands — quotients on both sides of
+        //      its 2^40 switch to the plain division (a uniform in [0, 2^62) over a small divisor) —, both reciprocals
+        if (cap_dim_full(a, e, rcp) != (a < 0 ? 0 : a / e)) ++bad;
+        {
+            const int64_t e2 = 1 + (int64_t)(r2 % 4093);  // small divisors: quotients around and above 2^40
+            const int64_t a2 = (int64_t)((splitmix64(s) >> 2) >> (r1 % 24));
+            const double rcp2 = (it & 1u) ? fast_rcp((double)e2) : 1.0 / (double)e2;
+            if (cap_dim_full(a2, e2, rcp2) != a2 / e2) ++bad;
+            const int64_t a3 = ((int64_t)1 << 40) * e2 + (int64_t)(splitmix64(s) % 5) - 2;  // right at the switch
+            if (cap_dim_full(a3, e2, rcp2) != a3 / e2) ++bad;
+        }
+        if (cap_dim_full(a, 0, 0.0) != (a < 0 ? 0 : kCapInf)) ++bad;
         // (c) the narrow domain's division by multiplication (narrow_magic): |a| < 2^30, 0 < e < 2^30, the same operand families
         {
             const int nbits = 1 + (int)((r0 >> 16) % 30);

@@ -289,3 +289,48 @@ def test_tightly_pack_counts_follow_from_capacities(seed):
             multi += true_count > 1
         driver_listed += driver in nodes
     assert checked > 100 and multi > 10 and driver_listed > 0
+
+
+# ---------------------------------------------------------------------------------------------- unclamped quotients (cap_dim_full)
+# minimal-fragmentation needs floor(a / e) unclamped (csrc/gangfit_minfrag.inc).  The device takes an f64 estimate a * (1 / e) and,
+# when it is below 2^40, settles it with one exact multiply-subtract; anything larger goes to the plain 64-bit division.  Modelled
+# here with IEEE doubles and a reciprocal that is off by up to 2^-44 relative (fast_rcp: the hardware estimate plus one Newton step).
+
+def _cap_dim_full_model(a, e, rcp):
+    if a < 0:
+        return 0
+    qf = float(a) * rcp
+    if qf < 2.0 ** 40:
+        q = int(qf)
+        rem = a - q * e
+        if rem < 0:
+            q -= 1
+        elif rem >= e:
+            q += 1
+        return q
+    return a // e
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_unclamped_quotient_by_reciprocal_is_exact(seed):
+    rng = np.random.default_rng(900 + seed)
+    checked = big = 0
+    for _ in range(20000):
+        ebits = int(rng.integers(1, 62))
+        e = max(1, int(rng.integers(0, 1 << ebits)))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            a = int(rng.integers(0, 1 << 62))
+        elif kind == 1:  # just around a multiple of e
+            a = min((1 << 62) - 1, int(rng.integers(0, 1 << 41)) * e + int(rng.integers(-1, 2)))
+        elif kind == 2:
+            a = int(rng.integers(0, e))
+        else:  # right at the 2^40 switch
+            a = min((1 << 62) - 1, (1 << 40) * e + int(rng.integers(-2, 3)))
+        a = max(a, 0)
+        for rel in (0.0, 2.0 ** -44, -(2.0 ** -44)):
+            rcp = (1.0 / float(e)) * (1.0 + rel)
+            assert _cap_dim_full_model(a, e, rcp) == a // e, (a, e, rel)
+        checked += 1
+        big += (a // e) >= (1 << 40)
+    assert checked == 20000 and big > 100
