@@ -270,6 +270,15 @@ int gf_orders_set(gf_ctx *ctx, const uint32_t *driver_order, uint32_t n_d, const
 int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app *apps, gf_result *results,
                  uint32_t *exec_nodes, uint64_t exec_nodes_cap, int32_t *chain_failed_at);
 
+/* Feasibility of n_apps independent applications, nothing else: has_capacity[a] = PackingResult.HasCapacity of application a
+ * against the installed snapshot (1 / 0).  What UnschedulablePodMarker reads — DoesPodExceedClusterCapacity returns
+ * `!packingResult.HasCapacity` and drops the placements (internal/extender/unschedulablepods.go:132-166) —, batched over the
+ * stale pending drivers of one scan (:93-129).  The same decision code as gf_fit_batch(GF_MODE_INDEPENDENT): the placements
+ * are made and stay in device memory; one byte per application crosses the host link instead of a 16-byte result and 4 K
+ * bytes of placements, and nothing is copied out but those bytes.  Blocking.  Every packer (the zone-aware ones and a
+ * multi-device context go through gf_fit_batch internally). */
+int gf_fit_feasible(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, uint8_t *has_capacity);
+
 /* Incremental FIFO chains.  The reference replays every earlier driver on every Filter (internal/extender/resource.go:309-328);
  * with an unchanged snapshot, driver j + 1's chain is driver j's chain plus one application.  gf_fit_batch(GF_MODE_FIFO_CHAIN)
  * therefore keeps the last queue, its results and a checkpoint of the working table every 32 applications (more for tables

@@ -334,6 +334,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->h_results.release();
     ctx->h_exec.release();
     ctx->h_failed.release();
+    ctx->h_feasible.release();
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->worker.allocated) {

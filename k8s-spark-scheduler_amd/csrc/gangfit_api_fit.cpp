@@ -793,6 +793,69 @@ int gf_fit_batch(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
     return GF_OK;
 }
 
+int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps, uint8_t* has_capacity) {
+    if (!ctx) return GF_ERR_INVALID;
+    if (n_apps > 0 && (!apps || !has_capacity)) return fail(ctx, GF_ERR_INVALID, "apps/has_capacity must not be NULL");
+    if (n_apps == 0) return GF_OK;
+    const bool plain = algo == GF_ALGO_TIGHTLY_PACK || algo == GF_ALGO_DISTRIBUTE_EVENLY || algo == GF_ALGO_MINIMAL_FRAGMENTATION;
+    if (!ctx->group.empty() || !plain) {
+        // a multi-device context, or a zone-aware packer: the full batch, of which only HasCapacity is handed on
+        uint64_t total_k = 0;
+        for (uint32_t a = 0; a < n_apps; ++a) total_k += apps[a].k > 0 ? (uint64_t)apps[a].k : 0;
+        std::vector<gf_result> res(n_apps);
+        std::vector<uint32_t> exec((size_t)total_k + 1);
+        const int rc = gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, n_apps, apps, res.data(), exec.data(), total_k, nullptr);
+        if (rc != GF_OK) return rc;
+        for (uint32_t a = 0; a < n_apps; ++a) has_capacity[a] = res[a].has_capacity ? 1 : 0;
+        return GF_OK;
+    }
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    GF_VIEW_ENTER(ctx)
+    if (n_apps >= 0x80000000u) return fail(ctx, GF_ERR_INVALID, "n_apps = %u", n_apps);
+    if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
+    GF_HIP(ctx, hipSetDevice(ctx->device));
+    GF_HIP(ctx, ctx->h_apps.reserve(n_apps));
+    uint64_t total_k = 0;
+    for (uint32_t a = 0; a < n_apps; ++a) {
+        const gf_app& in = apps[a];
+        if (in.k < 0 || in.k > GF_MAX_K) return fail(ctx, GF_ERR_INVALID, "apps[%u].k = %d outside [0, %d]", a, in.k, GF_MAX_K);
+        for (int j = 0; j < 3; ++j)
+            if (in.drv[j] < 0 || in.drv[j] >= GF_MAX_ABS_QUANTITY || in.exe[j] < 0 || in.exe[j] >= GF_MAX_ABS_QUANTITY)
+                return fail(ctx, GF_ERR_INVALID, "apps[%u] request outside [0, 2^62)", a);
+        gf_app& o = ctx->h_apps.ptr[a];
+        o = in;
+        o.exec_off = total_k;  // the placements are still made (same decision code): into device memory, where they stay
+        total_k += (uint64_t)in.k;
+    }
+    const uint64_t half = total_k + 1;
+    GF_HIP(ctx, ctx->d_exec.reserve(total_k + 1));
+    GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
+    GF_HIP(ctx, ctx->h_feasible.reserve(n_apps));
+    hipStream_t st = ctx->stream;
+    const gf_app* d_apps = ctx->h_apps.dev;
+    uint8_t* d_feas = ctx->h_feasible.dev;
+    const bool mapped = ctx->zero_copy && d_apps != nullptr && d_feas != nullptr &&
+                        (uint64_t)n_apps * sizeof(gf_app) <= (UINT64_C(4) << 20);
+    DeviceBuf<uint8_t> staged;  // (hosts without mapped pinned memory, or very large batches: two copies around the kernel)
+    if (!mapped) {
+        GF_HIP(ctx, ctx->d_apps.reserve(n_apps));
+        GF_HIP(ctx, staged.reserve(n_apps));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
+        d_apps = ctx->d_apps.ptr;
+        d_feas = staged.ptr;
+    }
+    hipError_t e = gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps, nullptr,
+                                                   ctx->d_exec.ptr, ctx->d_scratch.ptr, half,
+                                                   ctx->stats_on ? ctx->d_stats.ptr : nullptr, st, d_feas);
+    if (e == hipSuccess && !mapped)
+        e = hipMemcpyAsync(ctx->h_feasible.ptr, staged.ptr, n_apps, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = gf_wait_stream(st);
+    staged.release();
+    if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "gf_fit_feasible failed: %s", hipGetErrorString(e));
+    std::memcpy(has_capacity, ctx->h_feasible.ptr, n_apps);
+    return GF_OK;
+}
+
 int gf_fit_batch_dev(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const gf_app* d_apps,
                      gf_result* d_results, uint32_t* d_exec_nodes, uint64_t exec_nodes_len, int32_t* d_chain_failed_at,
                      void* stream) {

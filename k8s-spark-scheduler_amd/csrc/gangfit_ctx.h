@@ -398,6 +398,7 @@ struct gf_ctx {
     PinnedBuf<gf_result> h_results;
     PinnedBuf<uint32_t> h_exec;
     PinnedBuf<int32_t> h_failed;
+    PinnedBuf<uint8_t> h_feasible;  // gf_fit_feasible: one HasCapacity byte per application, written by the kernel
     bool stats_on = false;
 
     // ---- views (gf_ctx_view): contexts that fit on THIS context's installed snapshot with buffers and a stream of their own.

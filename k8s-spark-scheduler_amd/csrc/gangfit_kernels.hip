@@ -1060,9 +1060,14 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // their acknowledgement cost more than the kernel-end write-back and the completion signal they replace; removed.)
 template <int ALGO>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independent_kernel(
-    NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
+    NodeTable T, SparseTable G, uint32_t n_apps_flags, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
     uint32_t* __restrict__ exec_nodes, uint32_t* __restrict__ scratch, uint64_t scratch_half,
     ScanStats* __restrict__ stats) {
+    // bit 31 of n_apps_flags (kFeasibilityOnly; no argument of its own: the kernel is one SGPR pair away from another spill):
+    // `results` is an array of n_apps BYTES that receive HasCapacity and nothing else (gf_fit_feasible) — the placements still
+    // go to exec_nodes, which the caller then keeps in device memory
+    const uint32_t n_apps = n_apps_flags & 0x7FFFFFFFu;
+    const bool feas_only = (n_apps_flags >> 31) != 0u;
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
@@ -1082,13 +1087,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
                                                             scratch + scratch_half + app.exec_off, lane, xvis, dvis,
                                                             merged ? &g0 : nullptr, &G);
         if (lane == 0) {
-            gf_result r;
-            r.has_capacity = dec.feasible ? 1 : 0;
-            if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
-            r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
-            r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
-            r.evaluated = 1;
-            results[ai] = r;
+            if (feas_only) {
+                reinterpret_cast<uint8_t*>(results)[ai] = dec.feasible ? 1 : 0;
+            } else {
+                gf_result r;
+                r.has_capacity = dec.feasible ? 1 : 0;
+                if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
+                r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
+                r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
+                r.evaluated = 1;
+                results[ai] = r;
+            }
         }
     };
     decide(load_app(apps, a), a);
@@ -1709,12 +1718,15 @@ hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseT
 
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream) {
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, uint8_t* d_feasible) {
     if (n_apps == 0) return hipSuccess;
+    if (n_apps >= 0x80000000u) return hipErrorInvalidValue;
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+    const uint32_t n_apps_flags = n_apps | (d_feasible != nullptr ? 0x80000000u : 0u);
+    if (d_feasible != nullptr) d_results = reinterpret_cast<gf_result*>(d_feasible);
 #define GF_IND(ALGO)                                                                                                        \
-    hipLaunchKernelGGL((fit_independent_kernel<ALGO>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps, d_results,   \
+    hipLaunchKernelGGL((fit_independent_kernel<ALGO>), grid, block, 0, stream, table, gpu_view, n_apps_flags, d_apps, d_results, \
                        d_exec_nodes, d_scratch, scratch_half, d_stats)
     if (algo == GF_ALGO_TIGHTLY_PACK)
         GF_IND(GF_ALGO_TIGHTLY_PACK);

@@ -40,7 +40,7 @@ assert APP_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
 GF_RESIDENT_USAGE = 0xFFFFFFFF
 
 EXPORTED_SYMBOLS = [
-    "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch",
+    "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch", "gf_fit_feasible",
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats", "gf_chain_profile",
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
     "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
@@ -196,6 +196,8 @@ def load() -> C.CDLL:
     L.gf_worker_stop.argtypes = [p]
     L.gf_worker_stats.restype = i32
     L.gf_worker_stats.argtypes = [p, p]
+    L.gf_fit_feasible.restype = i32
+    L.gf_fit_feasible.argtypes = [p, i32, u32, p, p]
     L.gf_chain_profile.restype = i32
     L.gf_chain_profile.argtypes = [p, p]
     L.gf_call_phases.restype = i32

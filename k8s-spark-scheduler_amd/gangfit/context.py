@@ -256,6 +256,13 @@ class Context:
                                            C.byref(failed)))
         return BatchOut(res, apps_off["exec_off"].copy(), out[:total_k], int(failed.value))
 
+    def fit_feasible(self, algo: int, apps: np.ndarray) -> np.ndarray:
+        """gf_fit_feasible: HasCapacity of every application (bool array) — what UnschedulablePodMarker reads."""
+        apps = np.ascontiguousarray(apps, dtype=N.APP_DTYPE)
+        out = np.zeros(len(apps), dtype=np.uint8)
+        self._check(self._lib.gf_fit_feasible(self._h, algo, len(apps), N.ptr(apps), N.ptr(out)))
+        return out.astype(bool)
+
     def spark_binpack(self, algo: int, drv, exe, k: int):
         """One decision in the shape of binpack.SparkBinPackFunction. Returns (has_capacity, driver, exec_nodes)."""
         app = make_apps([drv], [exe], [k])

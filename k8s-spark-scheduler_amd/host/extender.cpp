@@ -271,17 +271,14 @@ std::vector<std::pair<std::string, bool>> SparkSchedulerExtender::scanForUnsched
         if (err) *err = e;
         return {};
     }
-    uint64_t total_k = 0;
-    for (const gf_app& a : apps) total_k += (uint64_t)a.k;
-    std::vector<gf_result> results(apps.size());
-    std::vector<uint32_t> exec(total_k + 1);
-    if (gf_fit_batch(binpacker_.ctx, GF_MODE_INDEPENDENT, binpacker_.Algo, (uint32_t)apps.size(), apps.data(), results.data(),
-                     exec.data(), total_k, nullptr) != GF_OK) {
+    // DoesPodExceedClusterCapacity reads HasCapacity and nothing else (unschedulablepods.go:165): the feasibility-only batch
+    std::vector<uint8_t> fits(apps.size());
+    if (gf_fit_feasible(binpacker_.ctx, binpacker_.Algo, (uint32_t)apps.size(), apps.data(), fits.data()) != GF_OK) {
         if (served) *served = false;
-        if (err) *err = std::string("gf_fit_batch: ") + gf_last_error(binpacker_.ctx);
+        if (err) *err = std::string("gf_fit_feasible: ") + gf_last_error(binpacker_.ctx);
         return {};
     }
-    for (size_t i = 0; i < stale.size(); ++i) out.emplace_back(stale[i]->Name, results[i].has_capacity == 0);
+    for (size_t i = 0; i < stale.size(); ++i) out.emplace_back(stale[i]->Name, fits[i] == 0);
     return out;
 }
 

@@ -1,0 +1,71 @@
+"""gf_fit_feasible: the feasibility-only independent batch (what UnschedulablePodMarker reads: `!packingResult.HasCapacity`,
+internal/extender/unschedulablepods.go:132-166).  Same decision code as gf_fit_batch(GF_MODE_INDEPENDENT); only one byte per
+application crosses the host link."""
+import numpy as np
+import pytest
+
+import gangfit
+from gangfit import workloads as wl
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+IND = gangfit.GF_MODE_INDEPENDENT
+
+
+def _congested(n_nodes, n_apps, seed):
+    w = wl.headline(n_nodes, n_apps, seed=seed, congested=True)  # about half of the gangs do not fit
+    return w, w.snapshot
+
+
+@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("n_nodes,n_apps", [(1, 1), (64, 5), (300, 96), (3000, 700)])
+def test_feasible_equals_the_oracle_and_the_full_batch(gf_ctx, algo, n_nodes, n_apps):
+    w, s = _congested(n_nodes, n_apps, 0xFEA5 + algo + n_nodes)
+    gf_ctx.set_snapshot(s.avail, s.sched)
+    gf_ctx.set_orders(s.driver_order, s.exec_order)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
+    fits = gf_ctx.fit_feasible(algo, apps)
+    full = gf_ctx.fit_batch(IND, algo, apps)
+    ref = ob.fit_independent(algo, s.avail, ob.make_apps(w.drv, w.exe, w.k, w.flags), s.driver_order, s.exec_order)
+    assert np.array_equal(fits, full.results["has_capacity"].astype(bool))
+    assert np.array_equal(fits, ref.results["has_capacity"].astype(bool))
+    if n_apps >= 96:
+        assert fits.any() and not fits.all()
+
+
+@pytest.mark.parametrize("algo", [3, 4, 5])
+def test_feasible_zone_aware_packers(gf_ctx, algo):
+    w, s = _congested(900, 150, 0xFEA6 + algo)
+    zone = (wl.splitmix64(0xA7, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+    order = wl.reference_node_order(s.avail, zone)
+    gf_ctx.set_snapshot(s.avail, s.sched)
+    gf_ctx.set_zones(zone)
+    gf_ctx.set_orders(order, order)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
+    fits = gf_ctx.fit_feasible(algo, apps)
+    full = gf_ctx.fit_batch(IND, algo, apps)
+    assert np.array_equal(fits, full.results["has_capacity"].astype(bool))
+    assert fits.any()
+
+
+def test_feasible_rejects_what_the_batch_rejects(gf_ctx):
+    w, s = _congested(64, 4, 3)
+    gf_ctx.set_snapshot(s.avail, s.sched)
+    gf_ctx.set_orders(s.driver_order, s.exec_order)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
+    apps["k"][2] = -1
+    with pytest.raises(gangfit.GangfitError) as e:
+        gf_ctx.fit_feasible(0, apps)
+    assert e.value.code == gangfit.GF_ERR_INVALID
+    assert len(gf_ctx.fit_feasible(0, apps[:0])) == 0
+
+
+def test_feasible_without_mapped_staging(gf_ctx):
+    """zero_copy = 0: records and answers travel by copies around the kernel; same answers."""
+    w, s = _congested(500, 120, 11)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
+    with gangfit.Context(0, options={"zero_copy": 0}) as c:
+        c.set_snapshot(s.avail, s.sched)
+        c.set_orders(s.driver_order, s.exec_order)
+        a = c.fit_feasible(0, apps)
+        assert np.array_equal(a, c.fit_batch(IND, 0, apps).results["has_capacity"].astype(bool))
