@@ -56,7 +56,7 @@ def test_feasible_rejects_what_the_batch_rejects(gf_ctx):
     apps["k"][2] = -1
     with pytest.raises(gangfit.GangfitError) as e:
         gf_ctx.fit_feasible(0, apps)
-    assert e.value.code == gangfit.GF_ERR_INVALID
+    assert e.value.code == gangfit._native.GF_ERR_INVALID
     assert len(gf_ctx.fit_feasible(0, apps[:0])) == 0
 
 
