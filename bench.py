@@ -326,6 +326,8 @@ def compact_line(full):
     bc = reg.get("blocking_call") or {}
     if bc.get("us_per_call") is not None:
         t["regimes"]["blocking_call"] = {"value": _r(bc.get("value")), "us_per_call": _r(bc.get("us_per_call"))}
+        if bc.get("feasibility_only_us_per_call") is not None:  # gf_fit_feasible: what UnschedulablePodMarker reads
+            t["regimes"]["blocking_call"]["feasibility_only_us_per_call"] = _r(bc.get("feasibility_only_us_per_call"))
     fc = rf.get("fifo_chain")
     if fc:
         c = _trim_roofline(fc)
@@ -844,6 +846,22 @@ def main():
                     phases = ctx.call_phases()
                 except Exception:
                     phases = None
+                # the same 1 000 applications through gf_fit_feasible: HasCapacity only (what DoesPodExceedClusterCapacity
+                # reads, unschedulablepods.go:132-166), one byte per application back, the answers watched as they arrive
+                hfeas = np.zeros(len(happs), dtype=np.uint8)
+                pf = N.ptr(hfeas)
+
+                def feasible_batch():
+                    if lib.gf_fit_feasible(h, TIGHT, len(happs), pa, pf) != 0:
+                        raise RuntimeError("gf_fit_feasible")
+
+                f_med = lat(feasible_batch)
+                try:
+                    f_phases = ctx.call_phases()
+                except Exception:
+                    f_phases = None
+                host_batch()
+                f_same = bool(np.array_equal(hfeas.astype(bool), hres["has_capacity"].astype(bool)))
                 # ... and ONE application per call (DoesPodExceedClusterCapacity for a single pod, gf_spark_binpack)
                 k1 = int(happs[0]["k"])
 
@@ -863,6 +881,8 @@ def main():
                 wk = {"ms_per_batch": w_med * 1e3, "decisions_per_s": len(happs) / w_med,
                       "gf_fit_batch_ms_per_batch_same_protocol": l_med * 1e3,
                       "gf_fit_batch_phases_us": phases,
+                      "gf_fit_feasible_us_per_batch": f_med * 1e6, "gf_fit_feasible_phases_us": f_phases,
+                      "gf_fit_feasible_equals_has_capacity": f_same,
                       "one_application_per_call_us": {"gf_worker_fit": w_one * 1e6, "gf_fit_batch": l_one * 1e6},
                       "results_equal": bool(np.array_equal(wres, hres) and np.array_equal(wexec, hexec)),
                       "protocol": "median of 300 blocking calls, one after the other, worker resident",
@@ -882,6 +902,13 @@ def main():
                             "us_per_call": (wkd.get("gf_fit_batch_ms_per_batch_same_protocol") or e2e_wall / e2e_steps * 1e3) * 1e3,
                             "value": len(happs) / ((wkd.get("gf_fit_batch_ms_per_batch_same_protocol") or e2e_wall / e2e_steps * 1e3) * 1e-3),
                             "phases_us": wkd.get("gf_fit_batch_phases_us"),
+                            "feasibility_only_us_per_call": wkd.get("gf_fit_feasible_us_per_batch"),
+                            "feasibility_only_phases_us": wkd.get("gf_fit_feasible_phases_us"),
+                            "feasibility_only_equals_has_capacity": wkd.get("gf_fit_feasible_equals_has_capacity"),
+                            "feasibility_only_is": "gf_fit_feasible: HasCapacity of the same 1 000 applications and nothing else (what "
+                                                   "UnschedulablePodMarker reads); the kernel's collecting workgroup writes one byte per "
+                                                   "application to pinned memory and the caller watches them arrive instead of waiting "
+                                                   "for the stream",
                             "phases_are": "host clock: stage = validate + copy 1 000 records into pinned memory; launch = the launch call; "
                                           "wait = the stream (dispatch, the kernel reading the records from and writing the answers to "
                                           "pinned host memory over the host link, its completion signal); copy_out = 64 KB to the "

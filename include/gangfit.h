@@ -165,6 +165,7 @@ const char *gf_last_error(gf_ctx *ctx);
  *   "fifo_generic"           1: FIFO chains run on the wide / generic global-memory kernels only
  *   "lds_budget"             bytes of LDS one workgroup may use (<= the device's): smaller table fronts, global tails
  *   "minfrag_matrix", "minfrag_hist", "sparse_gpu", "zero_copy"   0 disables the respective structure
+ *   "feasible_announce"      0: gf_fit_feasible waits for its stream instead of watching the answers arrive in pinned memory
  *   "snapshot_finalize_host" 1: gf_snapshot_build* builds the slot tables through gf_orders_set on the host
  *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
  *   "sort_fault"             1: fault injection — the priority sort's grid barrier cannot complete; gf_snapshot_build* then
@@ -275,7 +276,10 @@ int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
  * `!packingResult.HasCapacity` and drops the placements (internal/extender/unschedulablepods.go:132-166) —, batched over the
  * stale pending drivers of one scan (:93-129).  The same decision code as gf_fit_batch(GF_MODE_INDEPENDENT): the placements
  * are made and stay in device memory; one byte per application crosses the host link instead of a 16-byte result and 4 K
- * bytes of placements, and nothing is copied out but those bytes.  Blocking.  Every packer (the zone-aware ones and a
+ * bytes of placements, and nothing is copied out but those bytes.  With mapped staging (the default) the bytes announce
+ * themselves: each is preset to "not yet", one more workgroup of the kernel collects them in device memory and writes the whole array with system-scope
+ * stores, and the call returns when the last byte has arrived — without the kernel-end write-back and the stream's completion
+ * signal (a kernel that never answers is noticed after 2 ms through the stream).  No gf_scan_stats counters.  Blocking.  Every packer (the zone-aware ones and a
  * multi-device context go through gf_fit_batch internally). */
 int gf_fit_feasible(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, uint8_t *has_capacity);
 

@@ -211,6 +211,7 @@ int gf_ctx_view(gf_ctx* parent, gf_ctx** out) {
         v->fifo_minfrag_hist = parent->fifo_minfrag_hist;
         v->chain_cache_on = parent->chain_cache_on;
         v->zero_copy = parent->zero_copy;
+        v->feasible_announce = parent->feasible_announce;
         v->zoned_fused = parent->zoned_fused;
     }
     v->view_of = parent;
@@ -335,6 +336,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->h_exec.release();
     ctx->h_failed.release();
     ctx->h_feasible.release();
+    ctx->d_feasible_sync.release();
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->worker.allocated) {
@@ -426,6 +428,8 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
         ctx->sparse_gpu = value != 0;
     } else if (k == "zero_copy") {
         ctx->zero_copy = value != 0;
+    } else if (k == "feasible_announce") {
+        ctx->feasible_announce = value != 0;
     } else if (k == "zoned_fused") {
         ctx->zoned_fused = value != 0;
     } else if (k == "snapshot_finalize_host") {

@@ -813,6 +813,8 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
     GF_VIEW_ENTER(ctx)
     if (n_apps >= 0x80000000u) return fail(ctx, GF_ERR_INVALID, "n_apps = %u", n_apps);
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede a fit");
+    using clk = std::chrono::steady_clock;
+    const auto t_entry = clk::now();
     GF_HIP(ctx, hipSetDevice(ctx->device));
     GF_HIP(ctx, ctx->h_apps.reserve(n_apps));
     uint64_t total_k = 0;
@@ -830,8 +832,16 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
     const uint64_t half = total_k + 1;
     GF_HIP(ctx, ctx->d_exec.reserve(total_k + 1));
     GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
-    GF_HIP(ctx, ctx->h_feasible.reserve(n_apps));
+    GF_HIP(ctx, ctx->h_feasible.reserve((size_t)n_apps + 4));  // the kernel writes whole words
     hipStream_t st = ctx->stream;
+    {  // the collection words start at zero; the kernel's collecting workgroup leaves them at zero again
+        const uint32_t* before = ctx->d_feasible_sync.ptr;
+        GF_HIP(ctx, ctx->d_feasible_sync.reserve(((size_t)n_apps + 3) / 4 + 4));
+        if (ctx->d_feasible_sync.ptr != before || ctx->feasible_sync_dirty) {
+            GF_HIP(ctx, hipMemsetAsync(ctx->d_feasible_sync.ptr, 0, ctx->d_feasible_sync.cap * sizeof(uint32_t), st));
+            ctx->feasible_sync_dirty = false;
+        }
+    }
     const gf_app* d_apps = ctx->h_apps.dev;
     uint8_t* d_feas = ctx->h_feasible.dev;
     const bool mapped = ctx->zero_copy && d_apps != nullptr && d_feas != nullptr &&
@@ -839,20 +849,58 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
     DeviceBuf<uint8_t> staged;  // (hosts without mapped pinned memory, or very large batches: two copies around the kernel)
     if (!mapped) {
         GF_HIP(ctx, ctx->d_apps.reserve(n_apps));
-        GF_HIP(ctx, staged.reserve(n_apps));
+        GF_HIP(ctx, staged.reserve((size_t)n_apps + 4));
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_apps.ptr, ctx->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, st));
         d_apps = ctx->d_apps.ptr;
         d_feas = staged.ptr;
     }
+    // Mapped staging: the answers announce themselves.  Every byte of the pinned array is preset to "not yet"; the kernel's
+    // collecting workgroup writes the whole array with system-scope (written-through) stores, and the caller watches the bytes
+    // arrive instead of waiting for the kernel-end write-back and the stream's completion signal (6-8 us of a 12-15 us wait:
+    // profiles/r5h_feasible_call.txt).  A byte that has arrived is final, so no ordering between them is needed; when all have
+    // arrived every wavefront has read its record and made its decision — what the kernel still owes (placement stores to device
+    // memory, its end) is ordered before anything this context puts on its stream next.  gf_fit_batch cannot do the same:
+    // 13 000 placement words written through over the host link cost more than the signal they replace (round 4: 30.3 us
+    // against 23.3).
+    constexpr uint8_t kNotYet = 0xFF;
+    const bool announce = mapped && ctx->feasible_announce;
+    if (announce) std::memset(ctx->h_feasible.ptr, kNotYet, n_apps);
+    const auto t_staged = clk::now();
     hipError_t e = gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps, nullptr,
-                                                   ctx->d_exec.ptr, ctx->d_scratch.ptr, half,
-                                                   ctx->stats_on ? ctx->d_stats.ptr : nullptr, st, d_feas);
+                                                   ctx->d_exec.ptr, ctx->d_scratch.ptr, half, nullptr, st, d_feas,
+                                                   ctx->d_feasible_sync.ptr);
     if (e == hipSuccess && !mapped)
         e = hipMemcpyAsync(ctx->h_feasible.ptr, staged.ptr, n_apps, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = gf_wait_stream(st);
+    const auto t_launched = clk::now();
+    bool arrived = false;
+    if (e == hipSuccess && announce) {
+        const volatile uint8_t* f = ctx->h_feasible.ptr;
+        uint32_t next = 0;  // everything before it has arrived
+        for (uint32_t spin = 0;; ++spin) {
+            while (next < n_apps && f[next] != kNotYet) ++next;
+            if (next == n_apps) {
+                arrived = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            // a kernel that faulted never writes: after 2 ms the stream is asked (it reports the error, or completes)
+            if ((spin & 255u) == 255u && clk::now() - t_launched > std::chrono::milliseconds(2)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (e == hipSuccess && !arrived) e = gf_wait_stream(st);
+    if (e != hipSuccess) ctx->feasible_sync_dirty = true;  // the collection may have stopped anywhere
+    const auto t_done = clk::now();
     staged.release();
     if (e != hipSuccess) return fail(ctx, GF_ERR_HIP, "gf_fit_feasible failed: %s", hipGetErrorString(e));
     std::memcpy(has_capacity, ctx->h_feasible.ptr, n_apps);
+    const auto t_out = clk::now();
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    ctx->call_phase_us[0] = us(t_entry, t_staged);  // gf_call_phases: stage | launch | wait | copy-out | total
+    ctx->call_phase_us[1] = us(t_staged, t_launched);
+    ctx->call_phase_us[2] = us(t_launched, t_done);
+    ctx->call_phase_us[3] = us(t_done, t_out);
+    ctx->call_phase_us[4] = us(t_entry, t_out);
     return GF_OK;
 }
 

@@ -283,6 +283,7 @@ struct gf_ctx {
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
     bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
+    bool feasible_announce = true; // option "feasible_announce" = 0: gf_fit_feasible waits for the stream instead of watching its answers arrive
     bool zoned_fused = true;       // option "zoned_fused" = 0: independent batches of the zone-aware packers take the four-kernel path
     double call_phase_us[5] = {0, 0, 0, 0, 0};  // last gf_fit_batch on the zero-copy path: stage | launch | wait | copy out | total
     PinnedBuf<uint64_t> h_masks;
@@ -399,6 +400,8 @@ struct gf_ctx {
     PinnedBuf<uint32_t> h_exec;
     PinnedBuf<int32_t> h_failed;
     PinnedBuf<uint8_t> h_feasible;  // gf_fit_feasible: one HasCapacity byte per application, written by the kernel
+    bool feasible_sync_dirty = false;     // a call failed: the collection words are cleared again before the next launch
+    DeviceBuf<uint32_t> d_feasible_sync;  // ... the bytes as the wavefronts leave them in device memory (zero between launches)
     bool stats_on = false;
 
     // ---- views (gf_ctx_view): contexts that fit on THIS context's installed snapshot with buffers and a stream of their own.

@@ -118,10 +118,13 @@ struct ScanStats {
 };
 
 // Launchers (defined in gangfit_kernels.hip).  scratch: 2 * total_k uint32 (DistributeEvenly survivor lists).
-// d_feasible != nullptr: feasibility only — n_apps bytes receive HasCapacity, d_results is not written (gf_fit_feasible).
+// d_feasible != nullptr: feasibility only (gf_fit_feasible) — n_apps bytes (padded to a multiple of four; device-mapped pinned
+// memory or a device buffer) receive HasCapacity, d_results is not written, no counters.  d_feasible_sync: ceil(n_apps / 4)
+// words of device memory, zero between launches (the kernel's collecting workgroup clears them again).
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, uint8_t* d_feasible = nullptr);
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, uint8_t* d_feasible = nullptr,
+                                  uint32_t* d_feasible_sync = nullptr);
 
 // ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gangfit_api_worker.cpp)
 constexpr uint32_t kWorkerRing = 64;

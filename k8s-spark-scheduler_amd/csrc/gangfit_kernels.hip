@@ -1058,20 +1058,48 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // stores and announces its own completion there — arrival counters, a sequence word the caller polls — instead of the stream
 // wait: 30.3 us per blocking 1 000-application call against 23.3 us; 13 000 dword write-through stores over the host link and
 // their acknowledgement cost more than the kernel-end write-back and the completion signal they replace; removed.)
-template <int ALGO>
+// FEAS (gf_fit_feasible): feasibility only.  `results` is then an array of n_apps BYTES (device-mapped pinned host memory, or a
+// device buffer) that receives HasCapacity and nothing else, and `stats` carries the call's collection words instead of
+// counters: ceil(n_apps / 4) words of DEVICE memory, zero between launches, one byte per application.  A deciding wavefront
+// leaves 0x80 | HasCapacity in its byte with an atomic OR that returns nothing — it waits for nothing, not even for its own
+// placement stores — and ends.  One more workgroup (the grid's last) collects: it watches the words until every byte carries
+// its 0x80, writes the whole array to `results` with a handful of system-scope (written-through) stores and clears the words
+// for the next launch.  The caller watches the bytes arrive in pinned memory instead of waiting for the kernel-end write-back
+// and the stream's completion signal.  Measured on the way (profiles/r5g_feasible_call_byte_stores.txt, r5h_feasible_call_last_wavefront.txt):
+// one system-scope byte store per wavefront straight into pinned memory — 1 000 lone bytes over the host link cost 10 us more
+// than they save —; an arrival counter whose last wavefront copies out — the counter's return value arrives behind the
+// wavefront's own placement stores (memory operations return in order, a store is acknowledged after ~2 us): 37 us per call.
+// The placements are still made — same decision code — and stay in device memory.  A separate instantiation: the batch
+// kernel proper carries none of this.
+template <int ALGO, bool FEAS>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independent_kernel(
-    NodeTable T, SparseTable G, uint32_t n_apps_flags, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
+    NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
     uint32_t* __restrict__ exec_nodes, uint32_t* __restrict__ scratch, uint64_t scratch_half,
     ScanStats* __restrict__ stats) {
-    // bit 31 of n_apps_flags (kFeasibilityOnly; no argument of its own: the kernel is one SGPR pair away from another spill):
-    // `results` is an array of n_apps BYTES that receive HasCapacity and nothing else (gf_fit_feasible) — the placements still
-    // go to exec_nodes, which the caller then keeps in device memory
-    const uint32_t n_apps = n_apps_flags & 0x7FFFFFFFu;
-    const bool feas_only = (n_apps_flags >> 31) != 0u;
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     const uint32_t n_waves = n_apps;
+    if (FEAS && blockIdx.x == gridDim.x - 1u) {  // the collecting workgroup (launch_fit_independent appends it)
+        if (wave != 0) return;
+        uint32_t* words = reinterpret_cast<uint32_t*>(stats);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(results);
+        const uint32_t n_words = (n_apps + 3u) / 4u;
+        for (uint32_t base = 0; base < n_words; base += kWave) {  // in order: the early words are usually complete first
+            const uint32_t i = base + (uint32_t)lane;
+            const uint32_t left = i < n_words ? n_apps - 4u * i : 0u;  // applications this word speaks for (>= 4: all four bytes)
+            const uint32_t want = left >= 4u ? 0x80808080u : (left == 0u ? 0u : (0x80808080u >> (8u * (4u - left))));
+            uint32_t v = 0;
+            do {
+                if (i < n_words) v = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while (__ballot((v & want) != want) != 0ull);
+            if (i < n_words) {
+                __hip_atomic_store(dst + i, v & 0x01010101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
     if (a >= n_waves) return;
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
@@ -1086,22 +1114,23 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
         Decision dec = wave_decide<ALGO, GlobalView, false>(V, O, app, exec_nodes + app.exec_off, scratch + app.exec_off,
                                                             scratch + scratch_half + app.exec_off, lane, xvis, dvis,
                                                             merged ? &g0 : nullptr, &G);
-        if (lane == 0) {
-            if (feas_only) {
-                reinterpret_cast<uint8_t*>(results)[ai] = dec.feasible ? 1 : 0;
-            } else {
-                gf_result r;
-                r.has_capacity = dec.feasible ? 1 : 0;
-                if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
-                r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
-                r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
-                r.evaluated = 1;
-                results[ai] = r;
-            }
+        if (FEAS) {
+            // no return value, no fence: nothing this wavefront has in flight is waited for
+            if (lane == 0)
+                (void)__hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stats) + (ai >> 2), (0x80u | (dec.feasible ? 1u : 0u)) << (8u * (ai & 3u)),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0) {
+            gf_result r;
+            r.has_capacity = dec.feasible ? 1 : 0;
+            if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
+            r.driver_node = dec.feasible ? dec.ds_node : GF_NO_NODE;
+            r.exec_len = dec.feasible ? (uint32_t)app.k : 0u;
+            r.evaluated = 1;
+            results[ai] = r;
         }
     };
     decide(load_app(apps, a), a);
-    if (stats != nullptr && lane == 0) {
+    if (!FEAS && stats != nullptr && lane == 0) {
         atomicAdd(&stats->exec_slots_visited, xvis);
         atomicAdd(&stats->driver_slots_visited, dvis);
     }
@@ -1718,22 +1747,28 @@ hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseT
 
 hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, uint8_t* d_feasible) {
+                                  uint64_t scratch_half, ScanStats* d_stats, hipStream_t stream, uint8_t* d_feasible,
+                                  uint32_t* d_feasible_sync) {
     if (n_apps == 0) return hipSuccess;
-    if (n_apps >= 0x80000000u) return hipErrorInvalidValue;
+    if (d_feasible != nullptr && d_feasible_sync == nullptr) return hipErrorInvalidValue;
     const dim3 block(kWave * kWavesPerBlock);
     const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
-    const uint32_t n_apps_flags = n_apps | (d_feasible != nullptr ? 0x80000000u : 0u);
-    if (d_feasible != nullptr) d_results = reinterpret_cast<gf_result*>(d_feasible);
-#define GF_IND(ALGO)                                                                                                        \
-    hipLaunchKernelGGL((fit_independent_kernel<ALGO>), grid, block, 0, stream, table, gpu_view, n_apps_flags, d_apps, d_results, \
-                       d_exec_nodes, d_scratch, scratch_half, d_stats)
-    if (algo == GF_ALGO_TIGHTLY_PACK)
+    const dim3 grid_feas(grid.x + 1);  // + the collecting workgroup
+#define GF_IND(ALGO)                                                                                                               \
+    if (d_feasible != nullptr)                                                                                                     \
+        hipLaunchKernelGGL((fit_independent_kernel<ALGO, true>), grid_feas, block, 0, stream, table, gpu_view, n_apps, d_apps,      \
+                           reinterpret_cast<gf_result*>(d_feasible), d_exec_nodes, d_scratch, scratch_half,                        \
+                           reinterpret_cast<ScanStats*>(d_feasible_sync));                                                         \
+    else                                                                                                                           \
+        hipLaunchKernelGGL((fit_independent_kernel<ALGO, false>), grid, block, 0, stream, table, gpu_view, n_apps, d_apps,          \
+                           d_results, d_exec_nodes, d_scratch, scratch_half, d_stats)
+    if (algo == GF_ALGO_TIGHTLY_PACK) {
         GF_IND(GF_ALGO_TIGHTLY_PACK);
-    else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+    } else if (algo == GF_ALGO_MINIMAL_FRAGMENTATION) {
         GF_IND(GF_ALGO_MINIMAL_FRAGMENTATION);
-    else
+    } else {
         GF_IND(GF_ALGO_DISTRIBUTE_EVENLY);
+    }
 #undef GF_IND
     return hipGetLastError();
 }

@@ -60,6 +60,24 @@ def test_feasible_rejects_what_the_batch_rejects(gf_ctx):
     assert len(gf_ctx.fit_feasible(0, apps[:0])) == 0
 
 
+def test_feasible_waiting_for_the_stream(gf_ctx):
+    """feasible_announce = 0: the call waits for the stream instead of watching the bytes arrive; same answers, also when the
+    two kinds of call alternate on one context (the announcing call returns before its kernel has ended)."""
+    w, s = _congested(2000, 500, 17)
+    apps = gangfit.make_apps(w.drv, w.exe, w.k, w.flags)
+    with gangfit.Context(0) as c:
+        c.set_snapshot(s.avail, s.sched)
+        c.set_orders(s.driver_order, s.exec_order)
+        full = c.fit_batch(IND, 0, apps)
+        want = full.results["has_capacity"].astype(bool)
+        for rnd in range(6):
+            c.set_option("feasible_announce", rnd & 1)
+            assert np.array_equal(c.fit_feasible(0, apps), want)
+            assert np.array_equal(c.fit_feasible(1, apps[: 100 + rnd]), c.fit_batch(IND, 1, apps[: 100 + rnd]).results["has_capacity"].astype(bool))
+            again = c.fit_batch(IND, 0, apps)  # right behind an announcing call: placements of the full batch unchanged
+            assert np.array_equal(again.results, full.results) and np.array_equal(again.exec_nodes, full.exec_nodes)
+
+
 def test_feasible_without_mapped_staging(gf_ctx):
     """zero_copy = 0: records and answers travel by copies around the kernel; same answers."""
     w, s = _congested(500, 120, 11)

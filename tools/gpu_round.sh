@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU visit: the -m gpu parity suite, the torch-free host tests, the driver's bench command and the default one, then
 # the profiling recipe.  Everything lands under gpurun_out/<tag>/ (merged back by gpurun).
-#   tools/gpu_round.sh <tag> [go|tests|bench|two|zoned|c5|variants|prof ...]   (default: tests bench prof)
+#   tools/gpu_round.sh <tag> [go|tests|bench|two|zoned|c5|variants|phases|feasible|mf|prof ...]   (default: tests bench prof)
 #     go    is there a Go toolchain on the box (integration/go/run_pins.sh needs Go 1.19)?
 #     two   `python bench.py --gpus 2` on this one-GPU box: the N > 1 control flow starting its own ranks
 set -u
@@ -51,6 +51,17 @@ for w in $WHAT; do
         [ -f "$v" ] && GANGFIT_LIB=$PWD/$v timeout 300 python tools/probe_variants.py chain >> "$OUT/variants.txt" 2>&1
       done
       cat "$OUT/variants.txt"
+      ;;
+    phases)  # where the chain kernels' cycles go (instrumented variants), per application
+      { timeout 300 python tools/probe_solo_phases.py; timeout 300 python tools/probe_zoned.py 10000 3 azmajor; timeout 300 python tools/probe_minfrag.py azmajor; } > "$OUT/chain_phases.txt" 2>&1; echo "phases rc=$?"; cat "$OUT/chain_phases.txt"
+      ;;
+    feasible)  # the lone blocking call: gf_fit_batch against gf_fit_feasible
+      timeout 300 python tools/probe_feasible.py > "$OUT/feasible_call.txt" 2>&1; echo "feasible rc=$?"; cat "$OUT/feasible_call.txt"
+      ;;
+    mf)  # minimal-fragmentation chains: parity subset, phases, cold chain times of every packer
+      timeout 900 python -m pytest tests/test_gpu_minfrag.py tests/test_gpu_feasible.py tests/test_gpu_incremental.py tests/test_gpu_zones.py -m gpu -q -x --timeout 600 > "$OUT/pytest_mf.log" 2>&1; echo "pytest mf rc=$?"; tail -3 "$OUT/pytest_mf.log"
+      timeout 300 python tools/probe_minfrag.py azmajor > "$OUT/minfrag_phases.txt" 2>&1; cat "$OUT/minfrag_phases.txt"
+      timeout 300 python tools/probe_variants.py chain > "$OUT/chain_times.txt" 2>&1; cat "$OUT/chain_times.txt"
       ;;
     prof)
       bash tools/profile_round.sh "$TAG" ${PROF_GROUPS:-} > "$OUT/profile.log" 2>&1; tail -12 "$OUT/profile.log"
