@@ -394,8 +394,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)  # ~15 ms per window: the closing barrier of an N-GPU run stays below 1 %
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--windows", type=int, default=9, help="timed windows of exactly --steps steps; the median is reported")
-    ap.add_argument("--worker-sets", type=int, default=3,
-                    help="groups of wavefronts of the resident worker = independent batches in flight on the device; 0 = launch path only")
+    ap.add_argument("--worker-sets", type=int, default=-1,
+                    help="groups of wavefronts of the resident worker = independent batches in flight on the device; -1 = the library's "
+                         "choice (three applications per wavefront, as many sets as fit: 11 sets of 21 workgroups for 1 000 "
+                         "applications), 0 = launch path only")
     ap.add_argument("--nodes", type=int, default=10000)
     ap.add_argument("--apps", type=int, default=1000)
     ap.add_argument("--filter-calls", type=int, default=1000, help="FIFO Filter calls (different heads) behind p50/p99")
@@ -588,12 +590,13 @@ def main():
     worker_info = None
     used_worker = False
     wkern = []
-    if args.worker_sets > 0:
+    worker_sets_used = None
+    if args.worker_sets != 0:
         NOUT = 8
         w_res = [torch.zeros_like(d_res) for _ in range(NOUT)]
         w_exec = [torch.zeros_like(d_exec) for _ in range(NOUT)]
         try:
-            ctx.set_option("worker_sets", args.worker_sets)
+            ctx.set_option("worker_sets", max(0, args.worker_sets))  # 0 = the library chooses at every launch
             arr = ctx.worker_batches([(len(apps), d_apps.data_ptr(), w_res[i % NOUT].data_ptr(), w_exec[i % NOUT].data_ptr(), total_k)
                                       for i in range(args.steps)])
 
@@ -625,7 +628,12 @@ def main():
             step(TIGHT)  # the launch path's answer into d_res / d_exec
             torch.cuda.synchronize()
             same = all(bool(torch.equal(w_res[i], d_res)) and bool(torch.equal(w_exec[i], d_exec)) for i in range(min(NOUT, args.steps)))
-            worker_info = {"sets": args.worker_sets, "window_ms": [x * 1e3 for x in wwalls], "answers_equal_launch_path": same,
+            try:
+                worker_sets_used, worker_blocks_used = ctx.worker_geometry()
+            except Exception:
+                worker_sets_used, worker_blocks_used = (args.worker_sets if args.worker_sets > 0 else None), None
+            worker_info = {"sets": worker_sets_used, "workgroups_per_set": worker_blocks_used,
+                           "window_ms": [x * 1e3 for x in wwalls], "answers_equal_launch_path": same,
                            "kernel_ms_per_ticket": _median(wkern) if wkern else None, "stats": ctx.worker_stats()}
             if dist is not None:
                 okf = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
@@ -714,7 +722,7 @@ def main():
     roofline["regimes"] = {
         "streamed_tickets": ({"value": world * len(apps) * args.steps / _median(worker_info["window_ms"]) * 1e3,
                               "ms_per_step": _median(worker_info["window_ms"]) / args.steps, "kernel": "fit_worker_kernel<tightly-pack>",
-                              "kernel_ms": worker_rf["kernel_ms"], "batches_in_flight": args.worker_sets,
+                              "kernel_ms": worker_rf["kernel_ms"], "batches_in_flight": worker_sets_used,
                               "what": "K tickets per window through the resident worker, its launch and departure inside the window"}
                              if worker_rf else None),
         "launch_per_batch": {"value": world * len(apps) * args.steps / seq_wall, "ms_per_step": seq_wall / args.steps * 1e3,
@@ -750,7 +758,7 @@ def main():
         "config": {"workload": f"independent batch, tightly-pack, {args.nodes} nodes x {args.apps} pending apps per GPU, "
                                "3-D (cpu milli, mem bytes, gpu) int64, SURVEY.md 8d/C2 distributions, seed 0x5EED0010",
                    "nodes": args.nodes, "apps_per_gpu": args.apps, "algo": "tightly-pack", "mode": "independent",
-                   "batches_in_flight": args.worker_sets if used_worker else 1,
+                   "batches_in_flight": worker_sets_used if used_worker else 1,
                    "regime": "streamed_tickets (resident worker)" if used_worker else "launch_per_batch (one graph of K launches)",
                    "sharding": "pending apps across ranks, node table replicated, no collective",
                    # what the process group was: "nccl" = RCCL over xGMI with one rank per GPU (rccl_ranks = its world size);

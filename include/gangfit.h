@@ -475,9 +475,11 @@ int gf_launch_floor(gf_ctx *ctx, void *stream, uint32_t iters, float *us_per_lau
  *     was posted and makes it leave;
  *   - plain packers only (tightly-pack, distribute-evenly, minimal-fragmentation); plain contexts only (no views, one
  *     device); results are bit-identical to gf_fit_batch(GF_MODE_INDEPENDENT) — same wave-level code.
- *   options: "worker_sets" (groups of wavefronts = batches in flight on the device, default 3), "worker_blocks_per_set"
- *   (workgroups of sixteen wavefronts per group, default 64: each fills a CU, 3 x 64 + 1 of them leave the rest of the device
- *   to FIFO chains), "worker_idle_us".
+ *   options: "worker_sets" (groups of wavefronts = batches in flight on the device, at most 16), "worker_blocks_per_set"
+ *   (workgroups of sixteen wavefronts per group; each fills a CU), "worker_idle_us".  Both default to 0 = chosen at every
+ *   launch of the worker from the first ticket it will serve: three applications per wavefront, one after the other, and as
+ *   many sets as fit while sixteen CUs stay free for FIFO chains (1 000 applications: 11 sets of 21 workgroups);
+ *   gf_worker_geometry reports what the last launch ran with.
  *
  * gf_worker_fit: one blocking batch with host arrays, like gf_fit_batch(GF_MODE_INDEPENDENT): the records are written into
  * a pinned slice the device reads in place, results and placements are written by the device into pinned memory (zero copy
@@ -504,6 +506,8 @@ int gf_worker_wait(gf_ctx *ctx, uint64_t first_ticket, uint32_t n_tickets);
 int gf_worker_stop(gf_ctx *ctx);
 /* out[0] tickets posted, [1] tickets known complete (a prefix), [2] launches of the worker so far, [3] 1 = resident now */
 int gf_worker_stats(gf_ctx *ctx, uint64_t out[4]);
+/* out[0] sets, out[1] workgroups per set of the worker's last launch (0 0 before the first) */
+int gf_worker_geometry(gf_ctx *ctx, uint32_t out[2]);
 /* Measurement helper: where the last blocking gf_fit_batch(GF_MODE_INDEPENDENT) of a plain packer on the zero-copy path spent
  * its time on the host's clock, in microseconds: [0] validation + staging of the records into pinned memory, [1] the launch
  * call, [2] the wait for the stream (dispatch, the kernel — which reads the records from and writes the answers to pinned host

@@ -443,10 +443,10 @@ int gf_set_option(gf_ctx* ctx, const char* key, int64_t value) {
     } else if (k == "worker_sets" || k == "worker_blocks_per_set" || k == "worker_idle_us") {
         worker_quiesce(ctx);
         if (k == "worker_sets") {
-            if (value < 1 || value > 16) return fail(ctx, GF_ERR_INVALID, "worker_sets outside [1, 16]");
+            if (value < 0 || value > 16) return fail(ctx, GF_ERR_INVALID, "worker_sets outside [0, 16]");
             ctx->worker.sets = (uint32_t)value;
         } else if (k == "worker_blocks_per_set") {
-            if (value < 1 || value > 1024) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set outside [1, 1024]");
+            if (value < 0 || value > 1024) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set outside [0, 1024]");
             ctx->worker.blocks_per_set = (uint32_t)value;
         } else {
             if (value < 10 || value > 1000000) return fail(ctx, GF_ERR_INVALID, "worker_idle_us outside [10, 10^6]");

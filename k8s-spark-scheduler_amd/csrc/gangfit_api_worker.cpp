@@ -113,18 +113,42 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     // every workgroup must be resident at once (a group that waits for a CU would leave its tickets unserved while the others
     // spin), and sixteen CUs stay free for FIFO chains (a chain needs a whole CU: sixteen wavefronts, the LDS): a workgroup of
     // the worker fills a CU's registers, so it has a CU to itself and the count of workgroups is the count of CUs taken
-    uint32_t sets = w.sets;
+    uint32_t sets = w.sets, bps = w.blocks_per_set;
     {
         const uint32_t cus = (uint32_t)ctx->info.compute_units;
         int per_cu = 0;
         GF_HIP(ctx, gangfit::worker_blocks_per_cu(algo, &per_cu));
         if (per_cu < 1) return fail(ctx, GF_ERR_HIP, "the worker kernel does not fit a CU");
         const uint32_t room = cus > 32 ? cus - 16u : cus;  // (per_cu is 1 for the tightly-pack instance; never count on more)
-        while (sets > 1 && 1u + sets * w.blocks_per_set > room) --sets;
-        if (1u + sets * w.blocks_per_set > room) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set does not fit the device");
+        // Unless the options say otherwise: THREE applications of a ticket per wavefront, one after the other, and as many sets as
+        // then fit.  A ticket is a chain of dependent misses per application, not arithmetic — a set that gives every wavefront one
+        // application (63 workgroups for 1 000) finishes a ticket in ~5.8 us but only three such sets fit the device; with three
+        // applications per wavefront a ticket takes ~13 us and eleven are in flight on the same CUs: 1.40 against 2.06 us per
+        // ticket in a long stream, 61 against 74 us for a window of twenty (profiles/r5j_worker_sets.txt; two per wavefront
+        // 1.56 us, four 1.41 us but 68 us for the window of twenty).  Sized by the first ticket this launch will serve.
+        // (gf_worker_fit — one blocking ticket at a time — asks for one application per wavefront: nothing else is in flight.)
+        if (bps == 0) {
+            uint32_t n_first = w.hint_apps;
+            if (first_ticket < w.posted)
+                n_first = (uint32_t)(host_load(&w.h->ring[first_ticket % kRing].word[5]) & 0xFFFFFFFFull);
+            const uint32_t per_wave = w.hint_per_wave ? w.hint_per_wave : 1u;
+            constexpr uint32_t kWavesPerGroup = 16;
+            bps = (n_first + per_wave * kWavesPerGroup - 1) / (per_wave * kWavesPerGroup);
+            if (bps < 1) bps = 1;
+            if (1u + bps > room) bps = room - 1u;
+        }
+        if (sets == 0) {
+            sets = (room - 1u) / bps;
+            if (sets > 16u) sets = 16u;
+            if (sets < 1u) sets = 1u;
+        }
+        while (sets > 1 && 1u + sets * bps > room) --sets;
+        if (1u + sets * bps > room) return fail(ctx, GF_ERR_INVALID, "worker_blocks_per_set does not fit the device");
     }
     a.sets = sets;
-    a.blocks_per_set = w.blocks_per_set;
+    a.blocks_per_set = bps;
+    w.cur_sets = sets;
+    w.cur_blocks_per_set = bps;
     a.stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
     w.launch_first = first_ticket;
     if (w.ev0) (void)hipEventRecord(w.ev0, w.stream);
@@ -263,6 +287,7 @@ int gf_worker_submit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_batches, const gf
         if (batches[i].exec_nodes_len > max_k) max_k = batches[i].exec_nodes_len;
     }
     bool need_launch = false;
+    ctx->worker.hint_per_wave = 3;  // a stream of tickets: throughput (worker_launch)
     if (const int rc = worker_prepare(ctx, algo, max_k, &need_launch); rc != GF_OK) return rc;
     gf_ctx::Worker& w = ctx->worker;
     const uint64_t first = w.posted;
@@ -314,6 +339,8 @@ int gf_worker_fit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* apps
     if (total_k > exec_nodes_cap || (total_k > 0 && !exec_nodes))
         return fail(ctx, GF_ERR_CAPACITY, "exec_nodes holds %llu entries, %llu needed", (unsigned long long)exec_nodes_cap,
                     (unsigned long long)total_k);
+    ctx->worker.hint_apps = n_apps;  // one blocking ticket: latency — an application per wavefront (worker_launch)
+    ctx->worker.hint_per_wave = 1;
     if (const int rc = worker_prepare(ctx, algo, total_k); rc != GF_OK) return rc;
     gf_ctx::Worker& w = ctx->worker;
     // one pinned slice per ring slot: records in, results and placements out — the device reads and writes them in place
@@ -379,6 +406,14 @@ int gf_worker_stats(gf_ctx* ctx, uint64_t out[4]) {
     out[1] = w.completed_upto;
     out[2] = w.launches;
     out[3] = (w.allocated && w.running && host_load(&w.h->state) != 2) ? 1 : 0;
+    return GF_OK;
+}
+
+int gf_worker_geometry(gf_ctx* ctx, uint32_t out[2]) {
+    if (!ctx || !out) return GF_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    out[0] = ctx->worker.cur_sets;
+    out[1] = ctx->worker.cur_blocks_per_set;
     return GF_OK;
 }
 

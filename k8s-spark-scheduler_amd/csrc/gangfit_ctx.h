@@ -233,8 +233,10 @@ struct gf_ctx {
         uint64_t scratch_stride = 0;
         uint64_t posted = 0;          // tickets posted so far (the host's copy of the doorbell)
         uint64_t completed_upto = 0;  // every ticket below this one is known complete
-        uint32_t sets = 3;
-        uint32_t blocks_per_set = 64;  // x 16 wavefronts
+        uint32_t sets = 0;            // option "worker_sets": 0 = chosen per launch (worker_launch)
+        uint32_t blocks_per_set = 0;  // option "worker_blocks_per_set" (x 16 wavefronts): 0 = chosen per launch
+        uint32_t cur_sets = 0, cur_blocks_per_set = 0;  // what the last launch ran with (gf_worker_geometry)
+        uint32_t hint_apps = 1000, hint_per_wave = 3;   // what the caller that launches expects: ticket size, applications per wavefront
         uint32_t idle_us = 200;
         uint64_t launches = 0;
         // HIP events on the worker's stream around its launch: how long the last finished launch stayed on the device and how

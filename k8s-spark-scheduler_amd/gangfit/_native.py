@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
     "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
     "gf_usage_reset", "gf_usage_apply", "gf_set_option", "gf_chain_cache_stats", "gf_generation", "gf_shard_count", "gf_ctx_view",
-    "gf_worker_fit", "gf_worker_submit_dev", "gf_worker_wait", "gf_worker_stop", "gf_worker_stats", "gf_worker_kernel_time", "gf_call_phases",
+    "gf_worker_fit", "gf_worker_submit_dev", "gf_worker_wait", "gf_worker_stop", "gf_worker_stats", "gf_worker_geometry", "gf_worker_kernel_time", "gf_call_phases",
 ]
 
 
@@ -196,6 +196,8 @@ def load() -> C.CDLL:
     L.gf_worker_stop.argtypes = [p]
     L.gf_worker_stats.restype = i32
     L.gf_worker_stats.argtypes = [p, p]
+    L.gf_worker_geometry.restype = i32
+    L.gf_worker_geometry.argtypes = [p, p]
     L.gf_fit_feasible.restype = i32
     L.gf_fit_feasible.argtypes = [p, i32, u32, p, p]
     L.gf_chain_profile.restype = i32

@@ -386,6 +386,12 @@ class Context:
         self._check(self._lib.gf_worker_stats(self._h, out))
         return {"posted": int(out[0]), "complete": int(out[1]), "launches": int(out[2]), "resident": bool(out[3])}
 
+    def worker_geometry(self):
+        """(sets, workgroups per set) of the worker's last launch."""
+        out = (C.c_uint32 * 2)()
+        self._check(self._lib.gf_worker_geometry(self._h, out))
+        return int(out[0]), int(out[1])
+
     def call_phases(self):
         """Host-clock phases (us) of the last blocking independent gf_fit_batch on the zero-copy path."""
         out = (C.c_double * 5)()
