@@ -798,8 +798,12 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
     if (n_apps > 0 && (!apps || !has_capacity)) return fail(ctx, GF_ERR_INVALID, "apps/has_capacity must not be NULL");
     if (n_apps == 0) return GF_OK;
     const bool plain = algo == GF_ALGO_TIGHTLY_PACK || algo == GF_ALGO_DISTRIBUTE_EVENLY || algo == GF_ALGO_MINIMAL_FRAGMENTATION;
-    if (!ctx->group.empty() || !plain) {
-        // a multi-device context, or a zone-aware packer: the full batch, of which only HasCapacity is handed on
+    // the zone-aware packers as ONE launch (fit_zoned_fused_kernel: a workgroup per application decides every candidate view
+    // and chooses): served here too; their four-kernel route is not
+    const bool fused_zoned = is_zone_algo(algo) && ctx->zoned_fused && ctx->have_sched && ctx->n_zones + 1 <= 64;
+    if (!ctx->group.empty() || !(plain || fused_zoned)) {
+        // a multi-device context, or a route without a feasibility-only kernel: the full batch, of which only HasCapacity is
+        // handed on
         uint64_t total_k = 0;
         for (uint32_t a = 0; a < n_apps; ++a) total_k += apps[a].k > 0 ? (uint64_t)apps[a].k : 0;
         std::vector<gf_result> res(n_apps);
@@ -866,9 +870,21 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
     const bool announce = mapped && ctx->feasible_announce;
     if (announce) std::memset(ctx->h_feasible.ptr, kNotYet, n_apps);
     const auto t_staged = clk::now();
-    hipError_t e = gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps, nullptr,
-                                                   ctx->d_exec.ptr, ctx->d_scratch.ptr, half, nullptr, st, d_feas,
-                                                   ctx->d_feasible_sync.ptr);
+    hipError_t e;
+    if (fused_zoned) {
+        const uint32_t nz = ctx->n_zones;
+        const int inner = algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ? GF_ALGO_MINIMAL_FRAGMENTATION : GF_ALGO_TIGHTLY_PACK;
+        e = ctx->d_zexec.reserve(((uint64_t)nz + 1) * half);
+        gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)ctx->zd_row0 * ctx->zstride, nz, ctx->zstride};
+        if (e == hipSuccess)
+            e = gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), zt,
+                                                ctx->d_sched.ptr, ctx->d_zexec.ptr, half, n_apps, d_apps, nullptr, nullptr,
+                                                ctx->d_scratch.ptr, half, st, d_feas, ctx->d_feasible_sync.ptr);
+    } else {
+        e = gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps, nullptr,
+                                            ctx->d_exec.ptr, ctx->d_scratch.ptr, half, nullptr, st, d_feas,
+                                            ctx->d_feasible_sync.ptr);
+    }
     if (e == hipSuccess && !mapped)
         e = hipMemcpyAsync(ctx->h_feasible.ptr, staged.ptr, n_apps, hipMemcpyDeviceToHost, st);
     const auto t_launched = clk::now();

@@ -1058,19 +1058,44 @@ __device__ __forceinline__ void wave_commit_from_list(const View& V, const App& 
 // stores and announces its own completion there — arrival counters, a sequence word the caller polls — instead of the stream
 // wait: 30.3 us per blocking 1 000-application call against 23.3 us; 13 000 dword write-through stores over the host link and
 // their acknowledgement cost more than the kernel-end write-back and the completion signal they replace; removed.)
+// gf_fit_feasible, device side (fit_independent_kernel<.., true>, fit_zoned_fused_kernel<.., true>): how HasCapacity of every
+// application reaches the caller without the kernel having to end first.  `words`: ceil(n_apps / 4) words of DEVICE memory, zero
+// between launches, one byte per application.
+// feasible_announce: a deciding wavefront leaves 0x80 | HasCapacity in its byte with an atomic OR that returns nothing — it waits
+// for nothing, not even for its own placement stores — and ends.
+__device__ __forceinline__ void feasible_announce(uint32_t* words, uint32_t ai, bool feasible) {
+    (void)__hip_atomic_fetch_or(words + (ai >> 2), (0x80u | (feasible ? 1u : 0u)) << (8u * (ai & 3u)), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT);
+}
+// feasible_collect: one wavefront of one more workgroup (the grid's last) watches the words until every byte carries its 0x80,
+// writes the whole array to `dst` (device-mapped pinned memory, or a device buffer) with a handful of system-scope
+// (written-through) stores and clears the words for the next launch.
+__device__ __forceinline__ void feasible_collect(uint32_t* words, uint32_t* dst, uint32_t n_apps, int lane) {
+    const uint32_t n_words = (n_apps + 3u) / 4u;
+    for (uint32_t base = 0; base < n_words; base += kWave) {  // in order: the early words are usually complete first
+        const uint32_t i = base + (uint32_t)lane;
+        const uint32_t left = i < n_words ? n_apps - 4u * i : 0u;  // applications this word speaks for (>= 4: all four bytes)
+        const uint32_t want = left >= 4u ? 0x80808080u : (left == 0u ? 0u : (0x80808080u >> (8u * (4u - left))));
+        uint32_t v = 0;
+        do {
+            if (i < n_words) v = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (__ballot((v & want) != want) != 0ull);
+        if (i < n_words) {
+            __hip_atomic_store(dst + i, v & 0x01010101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // FEAS (gf_fit_feasible): feasibility only.  `results` is then an array of n_apps BYTES (device-mapped pinned host memory, or a
 // device buffer) that receives HasCapacity and nothing else, and `stats` carries the call's collection words instead of
-// counters: ceil(n_apps / 4) words of DEVICE memory, zero between launches, one byte per application.  A deciding wavefront
-// leaves 0x80 | HasCapacity in its byte with an atomic OR that returns nothing — it waits for nothing, not even for its own
-// placement stores — and ends.  One more workgroup (the grid's last) collects: it watches the words until every byte carries
-// its 0x80, writes the whole array to `results` with a handful of system-scope (written-through) stores and clears the words
-// for the next launch.  The caller watches the bytes arrive in pinned memory instead of waiting for the kernel-end write-back
-// and the stream's completion signal.  Measured on the way (profiles/r5g_feasible_call_byte_stores.txt, r5h_feasible_call_last_wavefront.txt):
-// one system-scope byte store per wavefront straight into pinned memory — 1 000 lone bytes over the host link cost 10 us more
-// than they save —; an arrival counter whose last wavefront copies out — the counter's return value arrives behind the
-// wavefront's own placement stores (memory operations return in order, a store is acknowledged after ~2 us): 37 us per call.
-// The placements are still made — same decision code — and stay in device memory.  A separate instantiation: the batch
-// kernel proper carries none of this.
+// counters (feasible_announce / feasible_collect above): the caller watches the bytes arrive in pinned memory instead of
+// waiting for the kernel-end write-back and the stream's completion signal.  Measured on the way
+// (profiles/r5g_feasible_call_byte_stores.txt, r5h_feasible_call_last_wavefront.txt): one system-scope byte store per wavefront
+// straight into pinned memory — 1 000 lone bytes over the host link cost 10 us more than they save —; an arrival counter whose
+// last wavefront copies out — the counter's return value arrives behind the wavefront's own placement stores (memory
+// operations return in order, a store is acknowledged after ~2 us): 37 us per call.  The placements are still made — same
+// decision code — and stay in device memory.  A separate instantiation: the batch kernel proper carries none of this.
 template <int ALGO, bool FEAS>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independent_kernel(
     NodeTable T, SparseTable G, uint32_t n_apps, const gf_app* __restrict__ apps, gf_result* __restrict__ results,
@@ -1081,23 +1106,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
     const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
     const uint32_t n_waves = n_apps;
     if (FEAS && blockIdx.x == gridDim.x - 1u) {  // the collecting workgroup (launch_fit_independent appends it)
-        if (wave != 0) return;
-        uint32_t* words = reinterpret_cast<uint32_t*>(stats);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(results);
-        const uint32_t n_words = (n_apps + 3u) / 4u;
-        for (uint32_t base = 0; base < n_words; base += kWave) {  // in order: the early words are usually complete first
-            const uint32_t i = base + (uint32_t)lane;
-            const uint32_t left = i < n_words ? n_apps - 4u * i : 0u;  // applications this word speaks for (>= 4: all four bytes)
-            const uint32_t want = left >= 4u ? 0x80808080u : (left == 0u ? 0u : (0x80808080u >> (8u * (4u - left))));
-            uint32_t v = 0;
-            do {
-                if (i < n_words) v = __hip_atomic_load(words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while (__ballot((v & want) != want) != 0ull);
-            if (i < n_words) {
-                __hip_atomic_store(dst + i, v & 0x01010101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        if (wave == 0) feasible_collect(reinterpret_cast<uint32_t*>(stats), reinterpret_cast<uint32_t*>(results), n_apps, lane);
         return;
     }
     if (a >= n_waves) return;
@@ -1115,10 +1124,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
                                                             scratch + scratch_half + app.exec_off, lane, xvis, dvis,
                                                             merged ? &g0 : nullptr, &G);
         if (FEAS) {
-            // no return value, no fence: nothing this wavefront has in flight is waited for
-            if (lane == 0)
-                (void)__hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(stats) + (ai >> 2), (0x80u | (dec.feasible ? 1u : 0u)) << (8u * (ai & 3u)),
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) feasible_announce(reinterpret_cast<uint32_t*>(stats), ai, dec.feasible);
         } else if (lane == 0) {
             gf_result r;
             r.has_capacity = dec.feasible ? 1 : 0;
@@ -2000,21 +2006,30 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
 hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const ZoneTable& zones,
                                   const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, hipStream_t stream) {
+                                  uint64_t scratch_half, hipStream_t stream, uint8_t* d_feasible, uint32_t* d_feasible_sync) {
     if (n_apps == 0) return hipSuccess;
+    if (d_feasible != nullptr && d_feasible_sync == nullptr) return hipErrorInvalidValue;
     if (inner_algo != GF_ALGO_TIGHTLY_PACK && inner_algo != GF_ALGO_MINIMAL_FRAGMENTATION) return hipErrorInvalidValue;
     if (az_aware && inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
     if (zones.n_zones + (az_aware ? 1u : 0u) > 64u) return hipErrorInvalidValue;
-    const dim3 grid(n_apps), block(kWave * kFusedWaves);
-#define GF_FUSED(ALGO, AZ)                                                                                             \
-    hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ>), grid, block, 0, stream, table, zones, d_sched, n_apps, d_apps, \
-                       d_results, d_exec_nodes, d_zexec, zexec_stride, d_scratch, scratch_half)
-    if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION)
+    const dim3 grid(n_apps), grid_feas(n_apps + 1) /* + the collecting workgroup */, block(kWave * kFusedWaves);
+    // feasibility only (gf_fit_feasible): d_results is not written, d_exec_nodes receives nothing; d_feasible / d_feasible_sync
+    // as for launch_fit_independent
+#define GF_FUSED(ALGO, AZ)                                                                                                      \
+    if (d_feasible != nullptr)                                                                                                  \
+        hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, true>), grid_feas, block, 0, stream, table, zones, d_sched, n_apps, \
+                           d_apps, reinterpret_cast<gf_result*>(d_feasible), d_feasible_sync, d_zexec, zexec_stride, d_scratch, \
+                           scratch_half);                                                                                       \
+    else                                                                                                                        \
+        hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, false>), grid, block, 0, stream, table, zones, d_sched, n_apps,     \
+                           d_apps, d_results, d_exec_nodes, d_zexec, zexec_stride, d_scratch, scratch_half)
+    if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION) {
         GF_FUSED(GF_ALGO_MINIMAL_FRAGMENTATION, false);
-    else if (az_aware)
+    } else if (az_aware) {
         GF_FUSED(GF_ALGO_TIGHTLY_PACK, true);
-    else
+    } else {
         GF_FUSED(GF_ALGO_TIGHTLY_PACK, false);
+    }
 #undef GF_FUSED
     return hipGetLastError();
 }
