@@ -655,6 +655,33 @@ func (c *Context) FitIndependentOnWorker(algo int, apps []App) ([]Result, error)
 	return results, err
 }
 
+// FitFeasibleOnInstalledSnapshot answers DoesPodExceedClusterCapacity for a batch of stale pending drivers
+// (internal/extender/unschedulablepods.go:93-166): HasCapacity of every application against the installed snapshot and
+// nothing else (include/gangfit.h, gf_fit_feasible) — the same decisions as FitBatchOnInstalledSnapshot(fifo = false), one byte
+// per application back over the host link, and the call returns when the bytes have arrived instead of waiting for the
+// kernel's completion signal (one pod: ~11 us against ~18 us; 1 000 pods: ~17 us against ~24 us on an MI355X).  Every packer.
+// Unverified here (no Go toolchain); tests/test_gpu_feasible.py drives the C entry point.
+func (c *Context) FitFeasibleOnInstalledSnapshot(algo int, apps []App) ([]bool, error) {
+	capps, _, err := flattenApps(apps)
+	if err != nil {
+		return nil, err
+	}
+	if len(apps) == 0 {
+		return nil, nil
+	}
+	fits := make([]C.uint8_t, len(apps))
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	if rc := C.gf_fit_feasible(c.ctx, C.gf_algo(algo), C.uint32_t(len(apps)), &capps[0], &fits[0]); rc != C.GF_OK {
+		return nil, c.err(rc)
+	}
+	out := make([]bool, len(apps))
+	for i := range fits {
+		out[i] = fits[i] != 0
+	}
+	return out, nil
+}
+
 // WorkerStop makes the resident worker leave the device now (it leaves by itself when idle).
 func (c *Context) WorkerStop() error {
 	c.mu.Lock()
