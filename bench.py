@@ -235,7 +235,7 @@ def cpu_chain_baseline(algo, avail, sched, zone, driver_order, exec_order, drv, 
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 3
 
-def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
+def run_config3(ctx, torch, dev, stream, timed_graph, steps=100):
     """10 000 nodes x 10 000 pending apps, both plain packers, device resident: decisions/s, kernel time, and the roofline as the
     three measured fractions (HBM bytes, L2 request bytes, issued instructions of profiles/pmc_config3.json over this run's
     kernel time).  The visited bytes of the in-kernel counters and the SURVEY.md 8d full-scan formula are listed as
@@ -280,7 +280,11 @@ def run_config3(ctx, torch, dev, stream, timed_graph, steps=20):
                                            "HBM peak); algorithmic = SURVEY.md 8d, which charges the full scan the lazy kernel skips"},
               "note": "10 000 wavefronts over 1 024 SIMDs: about ten per SIMD; bound by the depth of the dependent-miss chain and the "
                       "issue slots (DESIGN.md 9), not by bytes"}
-        c3[name] = {"decisions_per_s": len(apps3) * steps / wall_3, "kernel_ms": kern_3, "submission": how3, "roofline": rf}
+        c3[name] = {"decisions_per_s": len(apps3) * steps / wall_3, "kernel_ms": kern_3, "submission": how3, "roofline": rf,
+                    "decisions_per_s_by_kernel_time": len(apps3) / (kern_3 * 1e-3), "launches_per_window": steps,
+                    "window_is": "one recorded graph of `launches_per_window` launches between synchronises, host clock (rounds 1-4 used 20: "
+                                 "the graph's start and the closing synchronise were a tenth of such a window); the kernel is linear in "
+                                 "the batch size from ~2 000 applications on, 5.1 us + 0.6 us per 1 000 (profiles/r5n_config3_sizes.txt)"}
     return c3
 
 
@@ -1293,6 +1297,32 @@ def main():
                         int(algo), s.avail, s.sched, zone3 if zoned else None, order, order, base.drv, base.exe,
                         base.k, base.flags, reps=2)
                     extras[name]["speedup_vs_cpu_p50"] = extras[name]["fifo_filter_cpu_baseline"]["p50_ms"] / extras[name]["fifo_filter_p50_ms"]
+                try:  # the lone feasibility call of the same packer (gf_fit_feasible: what UnschedulablePodMarker reads)
+                    f50, _ = host_ms(lambda: ctx.fit_feasible(algo, happs), n=20)
+                    extras[name]["feasibility_only_us_per_call_host_entry"] = f50 * 1e3
+                except Exception as e:
+                    extras[name]["feasibility_only_us_per_call_host_entry"] = f"{type(e).__name__}: {e}"
+                # counter-backed rooflines of this packer's two kernels: the committed profile of ONE instantiation per
+                # command (tools/profile_round.sh zoned -> profiles/pmc_zoned.json), three fractions over rocprofv3's average
+                # dispatch duration of that command; this run's Filter p50 beside the chain's
+                zp = (load_profile("pmc_zoned.json") or {})
+                zk = zp.get("kernels") or {}
+                keys = {"single_az_tightly_pack": ("zc_saz", "zb_saz"), "az_aware_tightly_pack": ("zc_aza", None),
+                        "minimal_fragmentation": ("mc_mf", None), "single_az_minimal_fragmentation": ("mc_smf", "zb_smf")}[name]
+                rf = {}
+                for role, key in (("fifo_chain", keys[0]), ("independent_batch", keys[1])):
+                    k = zk.get(key) if key else None
+                    if not k:
+                        continue
+                    rf[role] = {"kernel": k.get("kernel"), "kernel_ms": (k.get("avg_dispatch_ns") or 0) * 1e-6, "bound": k.get("bound"),
+                                "frac": k.get("frac"), "fractions": k.get("fractions"), "traffic": k.get("hbm_bytes"),
+                                "wait_fraction": k.get("wait_fraction"),
+                                "lds_bank_conflict_per_active_lds_cycle": k.get("lds_bank_conflict_per_active_lds_cycle"),
+                                "simds": k.get("simds"), "counters_from": f"profiles/pmc_zoned.json ({zp.get('tag')}), entry {key}"}
+                    if role == "fifo_chain":
+                        rf[role]["this_run_filter_p50_ms"] = extras[name]["fifo_filter_p50_ms"]
+                if rf:
+                    extras[name]["roofline"] = rf
                 if zoned:
                     ctx.set_orders(s.driver_order, s.exec_order)
                     flat, _ = fifo_latency(ctx, algo, happs, 4, warm=1)
