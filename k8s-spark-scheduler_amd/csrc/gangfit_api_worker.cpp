@@ -150,6 +150,10 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     w.cur_sets = sets;
     w.cur_blocks_per_set = bps;
     a.stats = ctx->stats_on ? ctx->d_stats.ptr : nullptr;
+    // the tickets already posted for this launch (at most one per set) ride in its arguments
+    a.n_inline = 0;
+    for (uint64_t t = first_ticket; t < w.posted && a.n_inline < gangfit::kWorkerInline && a.n_inline < sets; ++t, ++a.n_inline)
+        for (int k = 0; k < 6; ++k) a.inline_words[a.n_inline][k] = host_load(&w.h->ring[t % kRing].word[k]);
     w.launch_first = first_ticket;
     if (w.ev0) (void)hipEventRecord(w.ev0, w.stream);
     GF_HIP(ctx, gangfit::launch_fit_worker(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), a, w.stream));

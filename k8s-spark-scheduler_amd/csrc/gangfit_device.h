@@ -128,6 +128,7 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
 
 // ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gangfit_api_worker.cpp)
 constexpr uint32_t kWorkerRing = 64;
+constexpr uint32_t kWorkerInline = 16;  // tickets a launch of the worker carries in its arguments (at most one per set)
 constexpr int kWorkerWaves = 16;             // wavefronts per workgroup of the worker kernel (one workgroup fills a CU)
 constexpr uint32_t kWorkerCountStride = 64;  // words between two tickets' counters: one 256-byte line (one memory channel) each  // tickets in flight at most (host side waits for ticket t - kWorkerRing before it posts t)
 
@@ -169,6 +170,14 @@ struct WorkerArgs {
     uint32_t sets;
     uint32_t blocks_per_set;
     ScanStats* stats;  // nullable: slots visited, summed over every decision of the launch (gf_scan_stats)
+    // The first tickets of the launch travel with it: tickets first_ticket .. first_ticket + n_inline - 1 as their six tagged
+    // words, exactly as in the ring.  A set finds its first ticket in the kernel's argument segment — which every wavefront
+    // reads at its start anyway — instead of waiting for the leader's look at the doorbell and its relay over the host link
+    // (two round trips, ~4 us of a 60 us window of twenty tickets).  The leader relays them all the same (the ring is what
+    // later rounds and the completion accounting index).
+    uint32_t n_inline;
+    uint32_t pad_inline;
+    unsigned long long inline_words[kWorkerInline][6];
 };
 
 hipError_t worker_blocks_per_cu(gf_algo algo, int* out);
