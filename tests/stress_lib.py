@@ -81,6 +81,10 @@ def one_seed(ctxs, seed):
                 bad = same(wk, ref, False)
                 if bad:
                     bad = "resident worker: " + bad
+            if bad is None:  # the feasibility-only call (gf_fit_feasible: what UnschedulablePodMarker reads), every packer
+                fits = ctx.fit_feasible(algo, apps)
+                if not np.array_equal(fits, np.asarray(ref.results["has_capacity"]).astype(bool)):
+                    bad = "gf_fit_feasible differs from HasCapacity"
             if bad is None and algo in (3, 4, 5, 0, 1):
                 avg = ctx.avg_packing_efficiency(algo, apps, gpu)
                 if ref.avg_eff is not None and not np.array_equal(avg.view(np.uint64), np.asarray(ref.avg_eff).view(np.uint64)):
