@@ -441,6 +441,7 @@ class Context:
         names = ("", "unindexed", "bound", "no_driver", "short")
         return {"rare_count": {names[i]: int(out[i]) for i in range(1, 5)},
                 "rare_cycles": {names[i]: int(out[5 + i]) for i in range(1, 5)},
+                "prologue_cycles": int(out[5]), "chain_end_cycles": int(out[0]),  # solo chain: from the kernel's start
                 "hw_id": int(out[10]), "xcc_id": int(out[11])}
 
     def hbm_probe(self, nbytes: int = 2 << 30, iters: int = 10):
