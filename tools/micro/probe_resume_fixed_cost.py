@@ -31,7 +31,8 @@ for name, w in (("10 000 nodes (headline)", wl.headline(10000, 1000)), ("30 000 
         ph = ctx.last_fifo_phases
         st = ctx.chain_cache_stats()
         cp = ctx.chain_profile()
-        print(f"      prologue {cp['prologue_cycles']} cycles, chain {cp['chain_end_cycles'] - cp['prologue_cycles']}, epilogue {cyc - cp['chain_end_cycles']}")
+        print(f"      prologue {cp['prologue_cycles']} cycles, chain {cp['chain_end_cycles'] - cp['prologue_cycles']}, epilogue {cyc - cp['chain_end_cycles']}"
+              f"   (GF_SOLO_PROLOGUE_MARKS build: tables in LDS at {cp['rare_cycles']['unindexed']}, shape ids at {cp['rare_cycles']['bound']}, dominators at {cp['rare_cycles']['no_driver']}, index at {cp['rare_cycles']['short']})")
         print(f"{name:26s} {an}: cold {np.median(cold):.3f} ms, same queue again {np.median(warm):.3f} ms (p99 {np.percentile(warm, 99):.3f}); "
               f"instrumented resumed kernel {ticks / 100.0:.1f} us = {cyc} cycles, of which the chain loop's phases {sum(ph[:5])} ; cache {st}", flush=True)
     ctx.close()
