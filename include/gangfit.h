@@ -288,6 +288,11 @@ int gf_fit_feasible(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *ap
  * therefore keeps the last queue, its results and a checkpoint of the working table every 32 applications (more for tables
  * whose 128 checkpoints would exceed 2 GiB), and a call whose queue starts with the same records resumes from the last
  * checkpoint inside the common prefix (the filtered driver of either queue excluded: nothing is committed behind it).
+ * The plain packers' chain on a table that fits LDS also keeps its TIP — the table before the application the chain ended at
+ * (the driver being filtered, behind which nothing is committed, or the application it aborted at) —, and a queue that agrees
+ * with the cached one up to there (the Filter of the next driver in creation order, the same Filter again) resumes from it:
+ * one or two applications evaluated instead of everything since the last checkpoint, unless the chain crosses a checkpoint
+ * boundary (it then starts from the checkpoint, so that the boundary's dump is made).
  * Every call that installs a snapshot, zones or orders (gf_snapshot_set, gf_zones_set, gf_orders_set, gf_snapshot_build*)
  * and gf_set_option drop the cache.  Results, placements, chain_failed_at and gf_residual_get are those of the full replay,
  * bit for bit: a checkpoint IS the table the replay holds at that application.  Served: every packer's LDS chain (plain,

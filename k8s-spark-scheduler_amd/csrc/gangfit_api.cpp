@@ -275,6 +275,7 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->h_gidx.release();
     ctx->d_napps.release();
     ctx->chain.d_ckpt.release();
+    ctx->chain.d_tip.release();
     ctx->d_flag32.release();
     ctx->d_sortwork.release();
     ctx->d_wide_needed.release();

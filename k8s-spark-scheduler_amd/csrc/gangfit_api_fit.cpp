@@ -181,15 +181,20 @@ struct ChainRun {
     bool record = false;         // dump checkpoints into ctx->chain.d_ckpt
     bool narrow_proven = false;  // every request has a scaled form (checked on the host): the wide twin is not launched
     uint32_t common = 0;         // leading applications identical to the cached queue's (>= a_begin): the cache keeps them
+    bool from_tip = false;       // the launch starts from the cached chain's tip (a_begin = its tip_at, any value) instead of a checkpoint
+    bool write_tip = false;      // the launch leaves its own tip in ctx->chain.d_tip
 };
 
 // The checkpoint arguments of a chain kernel and the table it starts from.
 gangfit::ChainCkpt chain_ckpt_args(gf_ctx* ctx, const ChainRun* run, const int32_t** restore) {
-    gangfit::ChainCkpt ck{nullptr, run ? run->a_begin : 0u, ctx->chain.shift, ctx->chain.slot_words, nullptr};
+    gangfit::ChainCkpt ck{nullptr, run ? run->a_begin : 0u, ctx->chain.shift, ctx->chain.slot_words, nullptr, nullptr};
     *restore = nullptr;
     if (run != nullptr && (run->record || run->a_begin > 0)) {
         ck.base = ctx->chain.d_ckpt.ptr;
-        if (run->a_begin > 0) {
+        if (run->write_tip) ck.tip = ctx->chain.d_tip.ptr;
+        if (run->a_begin > 0 && run->from_tip) {
+            *restore = ctx->chain.d_tip.ptr;
+        } else if (run->a_begin > 0) {
             *restore = ck.base + (size_t)((run->a_begin >> ck.shift) - 1u) * ctx->chain.slot_words;
             if (ctx->chain.dirty_format)
                 ck.resume_mask = reinterpret_cast<const unsigned long long*>(*restore + 3 * (size_t)ctx->n_slots + (ctx->n_slots & 1u));
@@ -480,6 +485,30 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
         if (c > C.n_ckpt) c = C.n_ckpt;
         a_begin = c << shift;
     }
+    // The cached chain's TIP (solo kernel, whole table in LDS): the table before the application that chain ended at.  A queue
+    // that agrees with the cached one up to there — the Filter of the next driver in creation order, the same Filter again —
+    // resumes from it and evaluates one or two applications instead of everything since the last checkpoint.  Not when this
+    // chain would cross a checkpoint boundary: it then starts from the checkpoint, so that the boundary's dump is made (the
+    // kernel dumps where a refill of its staging buffer falls, every 32 applications from ITS first one).
+    const bool tip_possible = solo && table_in_lds;
+    bool from_tip = false;
+    if (same && tip_possible && C.tip_valid && C.d_tip.ptr != nullptr && C.tip_at > a_begin && C.tip_at <= common &&
+        ((n_apps - 1) >> shift) == (C.tip_at >> shift)) {
+        a_begin = C.tip_at;
+        from_tip = true;
+    }
+    if (tip_possible && slot_words > C.d_tip.cap) {
+        if (C.d_tip.ptr) (void)gf_wait_stream(ctx->stream);
+        if (C.d_tip.reserve(slot_words) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        C.tip_valid = false;
+        if (from_tip) {  // (cannot happen: a valid tip lives in a buffer of this size)
+            from_tip = false;
+            a_begin = 0;
+        }
+    }
     // the checkpoint buffer keeps what it holds when it grows
     if (n_ck * slot_words > C.d_ckpt.cap) {
         size_t want = C.d_ckpt.cap ? C.d_ckpt.cap : 32 * slot_words;
@@ -509,6 +538,8 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
     run->a_begin = a_begin;
     run->common = same ? common : 0;
     run->record = true;
+    run->from_tip = from_tip;
+    run->write_tip = tip_possible;
     run->narrow_proven = true;
     ctx->planned_units.valid = true;
     for (int j = 0; j < 3; ++j) {
@@ -539,6 +570,8 @@ void chain_commit(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, uint64_t total_k, 
     // the chain reached application `last` (the one it aborted at, else the filtered driver): dumps exist up to there
     const uint32_t last = failed_at >= 0 ? (uint32_t)failed_at : n_apps - 1;
     C.n_ckpt = last >> C.shift;
+    C.tip_valid = run.write_tip;  // the epilogue left the table before application `last`
+    C.tip_at = last;
     C.valid = true;
     ctx->chain_stat[0] += 1;
     ctx->chain_stat[1] += run.a_begin > 0 ? 1 : 0;

@@ -45,8 +45,17 @@ def test_growing_queue_resumes_and_matches_full_replay(algo):
             _check(ctx, algo, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])
         chains, resumed, evaluated, skipped = ctx.chain_cache_stats()
         assert chains == 140
-        assert resumed == 140 - 33  # chains of 34 and more applications find checkpoint 1 (the table before application 32)
-        assert skipped == sum(((n - 2) // 32) * 32 for n in range(2, 141))
+        # The chain of n applications follows the chain of n - 1, which left its TIP: the table before its last application,
+        # n - 2.  It resumes there (two applications evaluated) unless it crosses a checkpoint boundary — (n - 1) % 32 == 0 —: it
+        # then starts from the last checkpoint, so that the boundary's dump is made (n = 33: no checkpoint yet, a full replay).
+
+        def first_evaluated(n):
+            if n >= 3 and (n - 1) % 32 != 0:
+                return n - 2
+            return ((n - 2) // 32) * 32 if n >= 2 else 0
+
+        assert resumed == sum(first_evaluated(n) > 0 for n in range(1, 141)) == 137
+        assert skipped == sum(first_evaluated(n) for n in range(1, 141))
         assert evaluated + skipped == sum(range(1, 141))
 
 
@@ -89,9 +98,59 @@ def test_divergence_in_the_middle_and_shrinking_queue():
             _check(ctx, TIGHT, avail, D, X, drv, exe, k, flags)
         st = ctx.chain_cache_stats()
         assert st[0] == 9 and st[1] == 7  # pos 31 and 0 leave no checkpoint in the common prefix
-        assert st[3] == 128 + 64 + 64 + 32 + 32 + 192 + 192
+        # (pos 199 is the driver being filtered: the queues agree up to it and the previous chain's tip — the table before
+        #  application 199 — serves; at pos 198 the tip is behind the common prefix and checkpoint 6 does)
+        assert st[3] == 128 + 64 + 64 + 32 + 32 + 199 + 192
         for n in (120, 64, 65, 33, 200):  # a driver was scheduled / deleted: shorter queues, then the long one again
             _check(ctx, TIGHT, avail, D, X, drv[:n], exe[:n], k[:n], flags[:n])
+
+
+@pytest.mark.parametrize("algo", [TIGHT, EVEN])
+def test_the_tip_serves_the_next_filter_and_the_same_filter_again(algo):
+    """The Filter of driver j + 1 after the Filter of driver j evaluates two applications (the tip: the table before the last
+    application of the previous chain), the same Filter again one; a chain that aborts leaves its tip at the application it
+    aborted at; a queue that diverges before the tip falls back to the checkpoints.  Every answer against the full replay."""
+    rng = np.random.default_rng(77 + algo)
+    avail, D, X, drv, exe, k = _random_problem(rng, 1500, 120, tight_cluster=False, layout="merged")
+    exe = np.maximum(exe, 1)
+    k = np.minimum(k, 25).astype(np.int32)
+    flags = np.ones(120, dtype=np.uint32)
+    with gangfit.Context(0) as ctx:
+        ctx.set_snapshot(avail)
+        ctx.set_orders(D, X)
+
+        def run(n, d=drv, e=exe, kk=k, f=flags):
+            ctx.chain_cache_stats(reset=True)
+            ref = _check(ctx, algo, avail, D, X, d[:n], e[:n], kk[:n], f[:n])
+            _, resumed, evaluated, skipped = ctx.chain_cache_stats()
+            return ref, evaluated, skipped
+
+        assert run(70)[1:] == (70, 0)
+        assert run(71)[1:] == (2, 69)     # from the tip of the chain of 70: applications 69 and 70
+        assert run(71)[1:] == (1, 70)     # the same Filter again: the filtered driver only
+        assert run(72)[1:] == (2, 70)
+        assert run(60)[1:] == (60 - 32, 32)  # a shorter queue: the tip (71) lies behind it, checkpoint 1 serves
+        assert run(61)[1:] == (2, 59)
+        d2 = drv.copy()
+        d2[40] = (d2[40] + 1) % 9
+        assert run(62, d=d2)[1:] == (62 - 32, 32)  # diverges at 40, before the tip (60): checkpoint 1
+        # crossing a checkpoint boundary: the chain of 97 applications ends at application 96 = 3 * 32 — it starts from the last
+        # checkpoint so that the dump of checkpoint 3 is made, and the next one uses the tip again
+        assert run(96, d=d2)[1:] == (96 - 32, 32)  # (checkpoint 2 did not exist yet: the chain of 62 ended before application 64)
+        assert run(97, d=d2)[1:] == (97 - 64, 64)
+        assert run(98, d=d2)[1:] == (2, 96)
+        # an aborting chain: its tip is the table before the application it aborted at
+        f2 = flags.copy()
+        e2 = exe.copy()
+        f2[105] = 0
+        e2[105] = (10 ** 6, 10 ** 6, 0)
+        ref, evaluated, skipped = run(110, d=d2, e=e2, f=f2)
+        assert ref.failed_at == 105 and skipped == 97 and evaluated == 105 - 97 + 1  # (from the tip of the chain of 98)
+        ref, evaluated, skipped = run(111, d=d2, e=e2, f=f2)
+        assert ref.failed_at == 105 and (evaluated, skipped) == (1, 105)  # resumes AT the aborting application, aborts again
+        f2[105] = 1  # skippable after all: the record changed at 105, the tip (the table before it) still serves
+        ref, evaluated, skipped = run(111, d=d2, e=e2, f=f2)
+        assert ref.failed_at == -1 and skipped == 105
 
 
 def test_aborting_chain_resumes_and_aborts_again():
