@@ -288,7 +288,7 @@ int gf_fit_feasible(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *ap
  * therefore keeps the last queue, its results and a checkpoint of the working table every 32 applications (more for tables
  * whose 128 checkpoints would exceed 2 GiB), and a call whose queue starts with the same records resumes from the last
  * checkpoint inside the common prefix (the filtered driver of either queue excluded: nothing is committed behind it).
- * The plain packers' chain on a table that fits LDS also keeps its TIP — the table before the application the chain ended at
+ * A chain on a table that fits LDS also keeps its TIP — the table before the application the chain ended at
  * (the driver being filtered, behind which nothing is committed, or the application it aborted at) —, and a queue that agrees
  * with the cached one up to there (the Filter of the next driver in creation order, the same Filter again) resumes from it:
  * one or two applications evaluated instead of everything since the last checkpoint, unless the chain crosses a checkpoint

@@ -485,12 +485,12 @@ bool chain_plan(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const 
         if (c > C.n_ckpt) c = C.n_ckpt;
         a_begin = c << shift;
     }
-    // The cached chain's TIP (solo kernel, whole table in LDS): the table before the application that chain ended at.  A queue
+    // The cached chain's TIP (whole table in LDS): the table before the application that chain ended at.  A queue
     // that agrees with the cached one up to there — the Filter of the next driver in creation order, the same Filter again —
     // resumes from it and evaluates one or two applications instead of everything since the last checkpoint.  Not when this
     // chain would cross a checkpoint boundary: it then starts from the checkpoint, so that the boundary's dump is made (the
     // kernel dumps where a refill of its staging buffer falls, every 32 applications from ITS first one).
-    const bool tip_possible = solo && table_in_lds;
+    const bool tip_possible = table_in_lds;  // (every LDS chain kernel leaves a tip when its whole table sits in LDS)
     bool from_tip = false;
     if (same && tip_possible && C.tip_valid && C.d_tip.ptr != nullptr && C.tip_at > a_begin && C.tip_at <= common &&
         ((n_apps - 1) >> shift) == (C.tip_at >> shift)) {

@@ -439,7 +439,7 @@ struct gf_ctx {
         std::vector<uint32_t> exec;
         DeviceBuf<int32_t> d_ckpt;    // [n][slot_words]
         DeviceBuf<int32_t> d_tip;     // [slot_words] the table before application tip_at of the cached chain (ChainCkpt::tip)
-        bool tip_valid = false;       // ... written by the cached chain (solo kernel, whole table in LDS)
+        bool tip_valid = false;       // ... written by the cached chain (LDS chain kernel, whole table in LDS)
         uint32_t tip_at = 0;
         size_t slot_words = 0;        // chain_ckpt_stride of the snapshot the buffer was laid out for
         bool dirty_format = false;    // the checkpoints are DELTAS (the chunks touched since the previous checkpoint + a cumulative

@@ -207,7 +207,7 @@ struct ChainCkpt {
     size_t stride;                          // int32 words between two checkpoints (>= 3 * n_slots; chain_ckpt_stride)
     const unsigned long long* resume_mask;  // solo kernel with a global table tail: the cumulative dirty-chunk mask of the
                                             // checkpoint this launch resumes from (nullptr: from the snapshot)
-    // The TIP (solo kernel, whole table in LDS; nullptr: none): when the chain ends — at the application it aborts at, else at
+    // The TIP (LDS chain kernels with the whole table in LDS; nullptr: none): when the chain ends — at the application it aborts at, else at
     // the driver being filtered, behind which nothing is committed — the table it holds is the table BEFORE that application.
     // The epilogue leaves it here (3 * n_slots int32, the layout of a checkpoint), and the next Filter of a queue that agrees with
     // this one up to there resumes from it: the Filter of driver j + 1 evaluates drivers j and j + 1 instead of everything since

@@ -296,22 +296,31 @@ def test_zone_aware_and_minfrag_chains_resume(algo, options):
         # (which of the two applies follows from the kernel's LDS geometry: the counters tell)
         lengths = (40, 41, 64, 65, 66, 97, 130, 150, 150, 149, 96)
 
-        def expect(shift):
+        def expect(shift, tip):
             skipped = resumed = 0
             for prev, n in zip(lengths, lengths[1:]):
-                n_ckpt = (prev - 1) >> shift                            # what the previous chain left behind
-                a0 = min((min(prev, n) - 1) >> shift, n_ckpt) << shift  # the common prefix ends before either queue's last application
+                n_ckpt = (prev - 1) >> shift  # what the previous chain left behind
+                common = min(prev, n) - 1     # the common prefix ends before either queue's last application
+                a0 = min(common >> shift, n_ckpt) << shift
+                tip_at = prev - 1             # ... and its tip (whole table in LDS): the table before its last application
+                if tip and a0 < tip_at <= common and ((n - 1) >> shift) == (tip_at >> shift):
+                    a0 = tip_at
                 skipped += a0
                 resumed += a0 > 0
             return resumed, skipped
 
         st = ctx.chain_cache_stats(reset=True)
         assert st[0] == 11
-        assert expect(5) == (10, 32 + 32 + 32 + 64 + 64 + 96 + 128 + 128 + 128 + 64)
-        shift = 5 if (st[1], st[3]) == expect(5) else 7
-        assert (st[1], st[3]) == expect(shift)
-        if not options:
-            assert shift == 5
+        assert expect(5, False) == (10, 32 + 32 + 32 + 64 + 64 + 96 + 128 + 128 + 128 + 64)
+        assert expect(5, True) == (10, 39 + 40 + 32 + 64 + 64 + 96 + 129 + 149 + 128 + 64)
+        if not options:  # the whole table in LDS: checkpoints every 32 applications and the tip
+            shift = 5
+            assert (st[1], st[3]) == expect(5, True)
+        else:            # a smaller LDS budget: whether the table still fits (tip), and which interval applies where it does not,
+            #              follows from the kernel's LDS geometry — the counters tell
+            got = (st[1], st[3])
+            shift, tip = next(((sh, tp) for sh, tp in ((5, True), (5, False), (7, False)) if got == expect(sh, tp)), (None, None))
+            assert shift is not None, got
         drv2 = drv.copy()
         drv2[70, 1] += 1
         _zcheck(ctx, algo, avail, sched, zone, D, X, drv2, exe, k, flags)
@@ -342,4 +351,4 @@ def test_headline_single_az_creation_order_heads():
         for n in (960, 961, 975, 1000, 1000):
             _zcheck(ctx, SAZ, s.avail, s.sched, zone3, order, order, w.drv[:n], w.exe[:n], w.k[:n], flags[:n])
         st = ctx.chain_cache_stats()
-        assert st[1] == 4 and st[3] == 928 + 960 + 960 + 992
+        assert st[1] == 4 and st[3] == 928 + 960 + 960 + 999  # (the same Filter again resumes from the chain's tip, application 999)
