@@ -56,7 +56,7 @@ L2_PEAK_GBPS = 34500.0  # aggregate L2 bandwidth of the eight XCDs (MI355X_MICRO
 N_SIMDS = 1024          # 256 CUs x 4
 CLOCK_GHZ = 2.4
 ISSUE_PEAK_GINST = N_SIMDS * CLOCK_GHZ  # one instruction per SIMD and cycle
-PROFILE_TAG = "r5ai"     # profiles/<tag>_* hold the rocprofv3 passes of this command (tools/profile_round.sh)
+PROFILE_TAG = "r5an"     # profiles/<tag>_* hold the rocprofv3 passes of this command (tools/profile_round.sh)
 
 
 def load_profile(name):
