@@ -215,3 +215,50 @@ def test_a_fifo_chain_starts_next_to_a_resident_worker():
         ctx.worker_stop()
     finally:
         ctx.close()
+
+
+def test_geometry_follows_the_first_ticket_of_a_launch():
+    """The worker's geometry is chosen per launch (gf_worker_geometry): a stream of tickets gets three applications per
+    wavefront and as many sets as fit next to sixteen free CUs; one blocking ticket one application per wavefront; the options
+    override; the answers are the launch path's whatever the geometry."""
+    import torch
+
+    ctx = gangfit.Context(0)
+    try:
+        w = wl.headline(4000, 1000, seed=0x6E0)
+        _install(ctx, w)
+        assert ctx.worker_geometry() == (0, 0)  # no launch yet
+        cus = ctx.device_info()["compute_units"]
+        room = cus - 16 if cus > 32 else cus
+        apps, total_k = gangfit.with_offsets(gangfit.make_apps(w.drv, w.exe, w.k))
+        want = ctx.fit_batch(IND, TIGHT, apps)
+        dev = torch.device("cuda:0")
+        d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
+        outs = [(torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev), torch.zeros(total_k + 1, dtype=torch.int32, device=dev))
+                for _ in range(4)]
+        torch.cuda.synchronize()
+
+        def stream(n_apps, n_tickets=12):
+            first = ctx.worker_submit_dev(TIGHT, [(n_apps, d_apps.data_ptr(), outs[i % 4][0].data_ptr(), outs[i % 4][1].data_ptr(), total_k)
+                                                  for i in range(n_tickets)])
+            ctx.worker_wait(first, n_tickets)
+            g = ctx.worker_geometry()
+            ctx.worker_stop()
+            torch.cuda.synchronize()
+            return g
+
+        sets, bps = stream(1000)
+        assert bps == (1000 + 47) // 48 == 21 and sets == min(16, (room - 1) // 21)  # 11 x 21 on 256 CUs
+        res = outs[0][0].cpu().numpy().view(gangfit._native.RESULT_DTYPE)
+        assert np.array_equal(res, want.results) and np.array_equal(outs[0][1].cpu().numpy()[:total_k].view(np.uint32), want.exec_nodes)
+        sets, bps = stream(100)
+        assert bps == 3 and sets == 16
+        assert _same(ctx.worker_fit(TIGHT, apps), want)  # one blocking ticket: an application per wavefront
+        sets, bps = ctx.worker_geometry()
+        assert bps == (1000 + 15) // 16 == 63 and sets == (room - 1) // 63
+        ctx.set_option("worker_sets", 2)
+        ctx.set_option("worker_blocks_per_set", 40)
+        assert stream(1000) == (2, 40)
+        assert np.array_equal(outs[0][0].cpu().numpy().view(gangfit._native.RESULT_DTYPE), want.results)
+    finally:
+        ctx.close()
