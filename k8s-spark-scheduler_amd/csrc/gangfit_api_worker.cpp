@@ -55,14 +55,20 @@ void worker_advance(gf_ctx::Worker& w);
 int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket);
 
 // The launch has left the device (its stream is idle): duration between the two events around it, tickets it relayed.
-void worker_finished(gf_ctx::Worker& w) {
+// (the duration itself is read from the events when somebody asks — gf_worker_kernel_time — or before they are recorded again:
+//  hipEventElapsedTime is a microsecond or two of a caller's window that nobody else needs)
+void worker_elapsed(gf_ctx::Worker& w) {
+    if (!w.elapsed_pending) return;
+    w.elapsed_pending = false;
     float ms = 0.0f;
-    if (w.ev0 && w.ev1 && hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess) {
-        const uint64_t consumed = host_load(&w.h->consumed);
-        w.last_ms = ms;
-        w.last_tickets = consumed > w.launch_first ? consumed - w.launch_first : 0;
-    }
+    if (w.ev0 && w.ev1 && hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess) w.last_ms = ms;
     (void)hipGetLastError();
+}
+void worker_finished(gf_ctx::Worker& w) {
+    worker_elapsed(w);  // (a launch that finished earlier and was never asked about)
+    const uint64_t consumed = host_load(&w.h->consumed);
+    w.last_tickets = consumed > w.launch_first ? consumed - w.launch_first : 0;
+    w.elapsed_pending = w.ev0 != nullptr && w.ev1 != nullptr;
 }
 
 // Makes the launch on the device (if any) leave once it has relayed and served every ticket posted so far, and waits for that.
@@ -155,6 +161,7 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     for (uint64_t t = first_ticket; t < w.posted && a.n_inline < gangfit::kWorkerInline && a.n_inline < sets; ++t, ++a.n_inline)
         for (int k = 0; k < 6; ++k) a.inline_words[a.n_inline][k] = host_load(&w.h->ring[t % kRing].word[k]);
     w.launch_first = first_ticket;
+    worker_elapsed(w);  // the previous launch's duration, before its events are recorded again
     if (w.ev0) (void)hipEventRecord(w.ev0, w.stream);
     GF_HIP(ctx, gangfit::launch_fit_worker(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), a, w.stream));
     if (w.ev1) (void)hipEventRecord(w.ev1, w.stream);
@@ -427,6 +434,7 @@ int gf_worker_kernel_time(gf_ctx* ctx, float* ms, uint64_t* tickets) {
     const gf_ctx::Worker& w = ctx->worker;
     if (!w.allocated || w.launches == 0 || (w.running && w.launches == 1))
         return fail(ctx, GF_ERR_STATE, "no launch of the worker has finished yet (gf_worker_stop first)");
+    if (!w.running) worker_elapsed(ctx->worker);
     *ms = w.last_ms;
     *tickets = w.last_tickets;
     return GF_OK;

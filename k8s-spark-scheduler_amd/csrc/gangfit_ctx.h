@@ -244,6 +244,7 @@ struct gf_ctx {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         uint64_t launch_first = 0;     // first ticket of the launch on the device (or of the last one)
         float last_ms = 0.0f;          // duration of the last finished launch
+        bool elapsed_pending = false;  // ... still to be read from the events (worker_elapsed)
         uint64_t last_tickets = 0;     // tickets it relayed
         // staging of gf_worker_fit: one pinned (coherent, device-mapped) slice per ring slot
         void* stage = nullptr;
