@@ -766,6 +766,9 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
     b.d_keys_c = d_keys_c;
     b.d_perm_c = d_perm_c;
     b.sort_fault = ctx->sort_fault;
+    b.d_zfirst = d_zfirst;  // the finalize step's accumulators start clean with everything else (one clearing launch)
+    b.d_zhasx = d_zhasx;
+    b.zhasx_to_scalars_words = 2 * Z + 16;  // d_zhasx | d_zeval | d_scalars
     GF_HIP(ctx, ctx->d_sortwork.reserve(gangfit::snapshot_sort_work_words()));
     b.d_sort_work = ctx->d_sortwork.ptr;
     GF_HIP(ctx, gangfit::launch_snapshot_build(b, st));
@@ -813,21 +816,18 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         f.d_zmasks = ctx->d_zmasks.ptr;
         f.d_nsnap = ctx->d_nsnap.ptr;
         f.d_ncmax = ctx->d_ncmax.ptr;
-        GF_HIP(ctx, gangfit::launch_snapshot_finalize(f, st));
+        GF_HIP(ctx, gangfit::launch_snapshot_finalize(f, ctx->d_sortwork.ptr + gangfit::snapshot_sort_error_word(), st));
         GF_HIP(ctx, ctx->h_bcols.reserve(6 * N + 8));
-        GF_HIP(ctx, ctx->h_border.reserve(N + 8));
-        long long* h_units = reinterpret_cast<long long*>(ctx->h_bcols.ptr);  // 3 units, then the 3 largest scaled magnitudes
+        GF_HIP(ctx, ctx->h_border.reserve(N + 16));
+        // everything the host needs back is one range of sixteen words (SnapshotFinalize::d_scalars): one copy
         uint32_t* h_scalars = ctx->h_border.ptr;
-        GF_HIP(ctx, hipMemcpyAsync(h_units, d_units, 6 * sizeof(long long), hipMemcpyDeviceToHost, st));
-        GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        GF_HIP(ctx, hipMemcpyAsync(h_scalars + 4, ctx->d_sortwork.ptr + gangfit::snapshot_sort_error_word(), sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, st));
+        GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         GF_HIP(ctx, gf_wait_stream(st));
-        if (h_scalars[4] != 0) return fail(ctx, GF_ERR_HIP, "the priority sort's grid barrier gave up (device oversubscribed?)");
+        if (h_scalars[3] != 0) return fail(ctx, GF_ERR_HIP, "the priority sort's grid barrier gave up (device oversubscribed?)");
         const uint32_t nz = h_scalars[0];
-        for (int j = 0; j < 3; ++j) {
-            ctx->unit[j] = (int64_t)h_units[j];
-            ctx->nmax[j] = (int64_t)h_units[3 + j];
+        for (int j = 0; j < 3; ++j) {  // 3 units, then the 3 largest scaled magnitudes, as pairs of words
+            ctx->unit[j] = (int64_t)((uint64_t)h_scalars[4 + 2 * j] | ((uint64_t)h_scalars[5 + 2 * j] << 32));
+            ctx->nmax[j] = (int64_t)((uint64_t)h_scalars[10 + 2 * j] | ((uint64_t)h_scalars[11 + 2 * j] << 32));
         }
         ctx->narrow_ok = h_scalars[1] == 0;
         ctx->have_sched = h_scalars[2] == 0;  // a negative schedulable value (overhead above allocatable) disables the efficiencies

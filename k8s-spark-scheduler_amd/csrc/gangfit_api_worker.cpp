@@ -122,8 +122,10 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     uint32_t sets = w.sets, bps = w.blocks_per_set;
     {
         const uint32_t cus = (uint32_t)ctx->info.compute_units;
-        int per_cu = 0;
-        GF_HIP(ctx, gangfit::worker_blocks_per_cu(algo, &per_cu));
+        // (the occupancy query is a runtime call of a microsecond or two, and a launch may sit inside a caller's timed window:
+        //  asked once per packer)
+        int& per_cu = w.per_cu[(unsigned)algo & 7u];
+        if (per_cu == 0) GF_HIP(ctx, gangfit::worker_blocks_per_cu(algo, &per_cu));
         if (per_cu < 1) return fail(ctx, GF_ERR_HIP, "the worker kernel does not fit a CU");
         const uint32_t room = cus > 32 ? cus - 16u : cus;  // (per_cu is 1 for the tightly-pack instance; never count on more)
         // Unless the options say otherwise: THREE applications of a ticket per wavefront, one after the other, and as many sets as

@@ -239,6 +239,7 @@ struct gf_ctx {
         uint32_t hint_apps = 1000, hint_per_wave = 3;   // what the caller that launches expects: ticket size, applications per wavefront
         uint32_t idle_us = 200;
         uint64_t launches = 0;
+        int per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // resident workgroups of the worker kernel per CU, by packer (asked of the runtime once)
         // HIP events on the worker's stream around its launch: how long the last finished launch stayed on the device and how
         // many tickets it served (gf_worker_kernel_time: the per-ticket kernel time of bench.py's roofline)
         hipEvent_t ev0 = nullptr, ev1 = nullptr;

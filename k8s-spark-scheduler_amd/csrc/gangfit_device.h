@@ -423,6 +423,10 @@ struct SnapshotBuild {
     uint32_t* d_sort_work;       // snapshot_sort_work_words() uint32 (8-byte aligned): count tables, barrier, scalars
     int sort_fault = 0;          // fault injection (tests): 1 = one workgroup of the sort never arrives at the grid barrier and
                                  // the others give up after 2^12 instead of 2^24 probes -> the error word is set
+    // what launch_snapshot_finalize accumulates into, cleared by the build's one clearing launch (nullptr: no finalize follows):
+    uint32_t* d_zfirst = nullptr;  // n_zones words, set to all ones
+    uint32_t* d_zhasx = nullptr;   // the range d_zhasx | d_zeval | d_scalars[0 .. 16), set to zero ...
+    size_t zhasx_to_scalars_words = 0;  // ... this many words
 };
 // usage[node] += sign * entry for n_entries reservation entries (columns cpu | memory | gpu of d_req); entries on nodes
 // >= n_nodes are ignored.
@@ -451,12 +455,13 @@ struct SnapshotFinalize {
     uint32_t* d_zfirst;         // n_zones
     uint32_t* d_zhasx;          // n_zones
     uint32_t* d_zeval;          // n_zones: zone -> index in the evaluation list, GF_NO_NODE = not evaluated
-    uint32_t* d_scalars;        // [0] = zones in the evaluation list, [1] = no narrow form
+    uint32_t* d_scalars;        // 16 words: [0] = zones in the evaluation list, [1] = no narrow form, [2] = negative schedulable
+                                // value, [3] = the sort's error word, [4 .. 16) = d_units as pairs of words (one read-back)
     uint64_t* d_zmasks;         // 2 * n_zones * n_chunks: executor rows, then (from row n_zones) driver rows
     int32_t* d_nsnap;           // 3 * n_slots
     int32_t* d_ncmax;           // 3 * n_chunks
 };
-hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t stream);
+hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, const uint32_t* d_sort_error, hipStream_t stream);
 struct CopyOut {  // three ranges of 32-bit words, any of them empty
     const uint32_t* src[3];
     uint32_t* dst[3];

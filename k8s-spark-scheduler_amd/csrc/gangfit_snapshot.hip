@@ -61,6 +61,10 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 // Also feeds the priority sort that follows (priority_sort_kernel): the permutation in name order (perm[name_rank[n]] = n) and
 // the ranges of the two sort columns — sort_scal: max ~cpu | max cpu | max ~mem | max mem | OR (cpu - cpu[0]) | OR (mem - mem[0])
 // over the biased free values (all zero at launch).
+// Grid-stride over the nodes with at most kMetaBlocks workgroups, and ONE set of the six range atomics per workgroup: they are
+// device-scope read-modify-writes of one cache line and queue behind each other — one set per wavefront (rounds 2-5a: 1 563
+// wavefronts x 6 at 100 000 nodes) made this kernel 112 us of a 0.40 ms build, 15 us at 10 000 nodes.
+constexpr uint32_t kMetaBlocks = 96;
 __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const int64_t* __restrict__ alloc,
                                                        const int64_t* __restrict__ overhead,
                                                        const int64_t* __restrict__ usage, const uint32_t* __restrict__ zone,
@@ -70,14 +74,18 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
                                                        const uint32_t* __restrict__ name_rank, uint32_t* __restrict__ name_order,
                                                        unsigned long long* __restrict__ sort_scal) {
     __shared__ unsigned long long zacc[3 * kZoneLdsMax];  // memory | cpu | population per zone
+    __shared__ unsigned long long red[6][4];              // the six range words per wavefront of the workgroup
     const bool in_lds = n_zones <= kZoneLdsMax;
     if (in_lds) {
         for (uint32_t i = threadIdx.x; i < 3 * n_zones; i += blockDim.x) zacc[i] = 0ull;
         __syncthreads();
     }
-    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long ncmn = 0ull, cmx = 0ull, nmmn = 0ull, mmx = 0ull, cor = 0ull, mor = 0ull;
-    if (n < n_nodes) {
+    // node 0's free cpu / memory: the reference point of the common trailing zeros (every difference to the minimum
+    // shares the trailing zeros of the differences to ANY one element)
+    const int64_t o0 = overhead != nullptr ? overhead[0] : 0, o1 = overhead != nullptr ? overhead[n_nodes] : 0;
+    const unsigned long long c0 = biased(alloc[0] - (usage[0] + o0)), m0 = biased(alloc[n_nodes] - (usage[n_nodes] + o1));
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += gridDim.x * blockDim.x) {
         int64_t a[3];
         for (int j = 0; j < 3; ++j) {
             const size_t k = (size_t)j * n_nodes + n;
@@ -86,20 +94,14 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
             avail[k] = a[j];
             sched[k] = alloc[k] - o;
         }
-        {
-            // node 0's free cpu / memory: the reference point of the common trailing zeros (every difference to the minimum
-            // shares the trailing zeros of the differences to ANY one element)
-            const int64_t o0 = overhead != nullptr ? overhead[0] : 0, o1 = overhead != nullptr ? overhead[n_nodes] : 0;
-            const unsigned long long c0 = biased(alloc[0] - (usage[0] + o0)), m0 = biased(alloc[n_nodes] - (usage[n_nodes] + o1));
-            const unsigned long long c = biased(a[0]), m = biased(a[1]);
-            ncmn = ~c;
-            cmx = c;
-            nmmn = ~m;
-            mmx = m;
-            cor = c - c0;
-            mor = m - m0;
-            name_order[name_rank[n]] = n;  // name_rank is a permutation (validated by the host layer)
-        }
+        const unsigned long long c = biased(a[0]), m = biased(a[1]);
+        ncmn = ~c > ncmn ? ~c : ncmn;
+        cmx = c > cmx ? c : cmx;
+        nmmn = ~m > nmmn ? ~m : nmmn;
+        mmx = m > mmx ? m : mmx;
+        cor |= c - c0;
+        mor |= m - m0;
+        name_order[name_rank[n]] = n;  // name_rank is a permutation (validated by the host layer)
         const uint32_t z = zone[n];
         if (z < n_zones) {
             if (in_lds) {  // a few hundred thousand same-address global atomics would serialise
@@ -119,16 +121,28 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
     mmx = wave_max_u64(mmx);
     cor = wave_or_u64(cor);
     mor = wave_or_u64(mor);
-    if ((threadIdx.x & 63u) == 0 && (n < n_nodes)) {  // lane 0 of a wavefront that holds nodes
-        atomicMax(&sort_scal[0], ncmn);
-        atomicMax(&sort_scal[1], cmx);
-        atomicMax(&sort_scal[2], nmmn);
-        atomicMax(&sort_scal[3], mmx);
-        if (cor) atomicOr(&sort_scal[4], cor);
-        if (mor) atomicOr(&sort_scal[5], mor);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) {
+        red[0][wave] = ncmn;
+        red[1][wave] = cmx;
+        red[2][wave] = nmmn;
+        red[3][wave] = mmx;
+        red[4][wave] = cor;
+        red[5][wave] = mor;
+    }
+    __syncthreads();
+    // (a workgroup of the grid always holds nodes: the grid never has more workgroups than 256-node blocks; lanes without a
+    //  node contribute zeros, the identity of max over biased values' complements and of OR)
+    if (threadIdx.x < 6) {
+        const uint32_t k = threadIdx.x, nw = blockDim.x >> 6;
+        unsigned long long v = 0ull;
+        for (uint32_t w = 0; w < nw; ++w) v = k < 4 ? (red[k][w] > v ? red[k][w] : v) : (v | red[k][w]);
+        if (k < 4)
+            atomicMax(&sort_scal[k], v);
+        else if (v)
+            atomicOr(&sort_scal[k], v);
     }
     if (in_lds) {
-        __syncthreads();
         for (uint32_t z = threadIdx.x; z < n_zones; z += blockDim.x)
             if (zacc[2 * n_zones + z] != 0ull) {
                 atomicAdd(&zone_sum[2 * (size_t)z], zacc[z]);
@@ -136,6 +150,32 @@ __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const i
                 atomicAdd(&zone_sum[2 * (size_t)n_zones + z], zacc[2 * n_zones + z]);
             }
     }
+}
+
+// Everything a build accumulates into starts at zero (the zone evaluation's first-slot table at all ones): ONE launch instead
+// of five runtime fills of a few hundred bytes each — every one of them a kernel of its own on the stream.
+struct SnapshotClear {
+    uint32_t* zero[4];   // word ranges set to 0
+    size_t zero_words[4];
+    uint32_t* ones;      // word range set to 0xFFFFFFFF
+    size_t ones_words;
+};
+__global__ __launch_bounds__(256) void snapshot_clear_kernel(SnapshotClear c) {
+    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, stride = (size_t)gridDim.x * 256u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t* p = c.zero[r];
+        const size_t n = c.zero_words[r];
+        if (n == 0) continue;
+        if (((uintptr_t)p & 15u) == 0) {  // the large ranges (count tables, the usage sums) are 16-byte aligned
+            uint4* p4 = reinterpret_cast<uint4*>(p);
+            for (size_t i = t; i < n / 4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
+            for (size_t i = (n & ~(size_t)3) + t; i < n; i += stride) p[i] = 0u;
+        } else {
+            for (size_t i = t; i < n; i += stride) p[i] = 0u;
+        }
+    }
+    for (size_t i = t; i < c.ones_words; i += stride) c.ones[i] = 0xFFFFFFFFu;
 }
 
 // resourcesLessThan over the zones (nodesorting.go:73-80, 102-104): memory, then cpu, ascending; ties keep the
@@ -425,7 +465,14 @@ __device__ __forceinline__ uint64_t gcd_u64(uint64_t a, uint64_t b) {
 }
 
 // One thread per slot, 64-slot chunks = wavefronts.  Tables, candidate masks, chunk maxima, per-chunk gcds, zone facts.
-__global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f) {
+constexpr uint32_t kFinalizeBlock = 1024;  // sixteen chunks per workgroup: its zone facts leave as one atomic per zone
+__global__ __launch_bounds__(kFinalizeBlock) void finalize_slots_kernel(SnapshotFinalize f) {
+    __shared__ uint32_t zf[kZoneLdsMax], zx[kZoneLdsMax];  // first driver slot / "has an executor candidate" per zone
+    if (f.n_zones <= kZoneLdsMax)
+        for (uint32_t zi = threadIdx.x; zi < f.n_zones; zi += blockDim.x) {
+            zf[zi] = 0xFFFFFFFFu;
+            zx[zi] = 0u;
+        }
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t c = s >> 6;
     const int lane = (int)(threadIdx.x & 63u);
@@ -478,16 +525,29 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
         const int tz = any ? __builtin_ctzll(any) : 0;
         v >>= tz;
         if (__ballot(v >> 32) == 0) {
-            uint32_t w = (uint32_t)v;
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t o = (uint32_t)__shfl_xor((int)w, d, 64);
-                while (o) {
-                    const uint32_t t = w % o;
-                    w = o;
-                    o = t;
+            // A candidate (some non-zero value of the chunk) and ROUNDS: every lane takes its value modulo the candidate — one
+            // division per lane and round —; when every remainder is zero the candidate, itself a member, is the gcd, else it
+            // is replaced by its gcd with one non-zero remainder (at most half of it: a real cluster's chunk of equal or
+            // commensurable nodes ends after one or two rounds).  The butterfly this replaces ran Euclid's loop in every lane
+            // at every one of its six levels.
+            const uint32_t w = (uint32_t)v;
+            const uint64_t nz = __ballot(w != 0u);
+            uint32_t cand = 0;
+            if (nz) {
+                cand = (uint32_t)__shfl((int)w, __ffsll((unsigned long long)nz) - 1, 64);
+                for (;;) {
+                    const uint32_t r = w % cand;
+                    const uint64_t left = __ballot(r != 0u);
+                    if (left == 0) break;
+                    uint32_t o = (uint32_t)__shfl((int)r, __ffsll((unsigned long long)left) - 1, 64);  // 0 < o < cand
+                    while (o) {  // wave-uniform Euclid
+                        const uint32_t t = cand % o;
+                        cand = o;
+                        o = t;
+                    }
                 }
             }
-            g[j] = (uint64_t)w << tz;
+            g[j] = (uint64_t)cand << tz;
         } else {
             for (int d = 1; d < 64; d <<= 1) v = gcd_u64(v, (uint64_t)__shfl_xor((long long)v, d, 64));
             g[j] = v << tz;
@@ -503,7 +563,10 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
         }
     }
     // zones by first appearance in the driver order, and whether they own an executor candidate (single_az.go:36-41)
-    // (one atomic per wavefront and zone: a hundred thousand same-address atomics would serialise)
+    // (one atomic per wavefront and zone, combined per workgroup in LDS when the zones fit: the global ones are device-scope
+    //  read-modify-writes of a handful of words and queue behind each other — 1 563 wavefronts x 3 zones x 2 at 100 000 nodes)
+    const bool z_lds = f.n_zones <= kZoneLdsMax;
+    if (z_lds) __syncthreads();  // zf / zx initialised (top of the kernel)
     uint64_t todo = __ballot((dbit || xbit) && z < f.n_zones);
     while (todo) {
         const int leader = __ffsll((unsigned long long)todo) - 1;
@@ -511,42 +574,96 @@ __global__ __launch_bounds__(256) void finalize_slots_kernel(SnapshotFinalize f)
         const uint64_t same = __ballot(z == zl && z < f.n_zones && real);
         const uint64_t dsame = __ballot(z == zl && dbit), xsame = __ballot(z == zl && xbit);
         if (lane == leader) {
-            if (dsame) atomicMin(&f.d_zfirst[zl], (s - (uint32_t)lane) + (uint32_t)(__ffsll((unsigned long long)dsame) - 1));
-            if (xsame) atomicOr(&f.d_zhasx[zl], 1u);
+            const uint32_t first = (s - (uint32_t)lane) + (uint32_t)(__ffsll((unsigned long long)dsame) - 1);
+            if (z_lds) {
+                if (dsame) atomicMin(&zf[zl], first);
+                if (xsame) atomicOr(&zx[zl], 1u);
+            } else {
+                if (dsame) atomicMin(&f.d_zfirst[zl], first);
+                if (xsame) atomicOr(&f.d_zhasx[zl], 1u);
+            }
         }
         todo &= ~same;
     }
+    if (z_lds) {
+        __syncthreads();
+        for (uint32_t zi = threadIdx.x; zi < f.n_zones; zi += blockDim.x) {
+            if (zf[zi] != 0xFFFFFFFFu) atomicMin(&f.d_zfirst[zi], zf[zi]);
+            if (zx[zi]) atomicOr(&f.d_zhasx[zi], 1u);
+        }
+    }
 }
 
-// One workgroup: the per-dimension units (gcd over the chunk gcds) and the zone evaluation list.
-__global__ __launch_bounds__(256) void finalize_reduce_kernel(SnapshotFinalize f) {
-    __shared__ unsigned long long part[6][256];
-    for (int j = 0; j < 3; ++j) {
-        uint64_t g = 0, mg = 0;
-        for (uint32_t c = threadIdx.x; c < f.n_chunks; c += blockDim.x) {
-            g = gcd_u64(g, f.d_gcd_part[(size_t)j * f.n_chunks + c]);
-            const uint64_t v = f.d_gcd_part[(size_t)(3 + j) * f.n_chunks + c];
-            mg = v > mg ? v : mg;
+// gcd of two 64-bit values without the 64-bit software division where it can be avoided: equal operands (the rule — the chunks
+// of a real cluster share their gcd) and zeros return at once; otherwise the common power of two is set aside and Euclid runs
+// on the odd parts, in 32 bits when both fit (byte / milli quantities almost always do).
+__device__ __forceinline__ uint64_t gcd_fast(uint64_t a, uint64_t b) {
+    if (a == b || b == 0) return a;
+    if (a == 0) return b;
+    const int sh = __builtin_ctzll(a | b);
+    a >>= __builtin_ctzll(a);
+    b >>= __builtin_ctzll(b);
+    if (((a | b) >> 32) == 0) {
+        uint32_t x = (uint32_t)a, y = (uint32_t)b;
+        while (y) {
+            const uint32_t t = x % y;
+            x = y;
+            y = t;
         }
-        part[j][threadIdx.x] = g;
-        part[3 + j][threadIdx.x] = mg;
+        return (uint64_t)x << sh;
+    }
+    return gcd_u64(a, b) << sh;
+}
+
+// One workgroup: the per-dimension units (gcd over the chunk gcds) and the zone evaluation list.  Four groups of 256 threads
+// side by side — the three dimensions' gcd trees and the three magnitude maxima — instead of one after the other: the trees are
+// chains of dependent gcds, and this kernel sits between two grid-wide ones on the build's critical path.
+// Thread 0 also gathers what the host reads back into ONE range: d_scalars[3] = the priority sort's error word,
+// d_scalars[4 .. 15] = the three units and the three largest scaled magnitudes as pairs of 32-bit words (one copy, not three).
+constexpr uint32_t kReduceGroup = 256;
+__global__ __launch_bounds__(4 * kReduceGroup) void finalize_reduce_kernel(SnapshotFinalize f, const uint32_t* __restrict__ sort_error) {
+    __shared__ unsigned long long part[6][kReduceGroup];
+    const uint32_t grp = threadIdx.x / kReduceGroup, t = threadIdx.x % kReduceGroup;
+    if (grp < 3) {
+        uint64_t g = 0;
+        for (uint32_t c = t; c < f.n_chunks; c += kReduceGroup) g = gcd_fast(g, f.d_gcd_part[(size_t)grp * f.n_chunks + c]);
+        part[grp][t] = g;
+    } else {
+        uint64_t mg[3] = {0, 0, 0};
+        for (uint32_t c = t; c < f.n_chunks; c += kReduceGroup)
+            for (int j = 0; j < 3; ++j) {
+                const uint64_t v = f.d_gcd_part[(size_t)(3 + j) * f.n_chunks + c];
+                mg[j] = v > mg[j] ? v : mg[j];
+            }
+        for (int j = 0; j < 3; ++j) part[3 + j][t] = mg[j];
     }
     __syncthreads();
-    for (uint32_t w = blockDim.x / 2; w > 0; w >>= 1) {  // tree: a serial pass of one thread over 768 software gcds took 0.1 ms
-        if (threadIdx.x < w)
-            for (int j = 0; j < 3; ++j) {
-                part[j][threadIdx.x] = gcd_u64(part[j][threadIdx.x], part[j][threadIdx.x + w]);
-                const uint64_t o = part[3 + j][threadIdx.x + w];
-                if (o > part[3 + j][threadIdx.x]) part[3 + j][threadIdx.x] = o;
+    for (uint32_t w = kReduceGroup / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            if (grp < 3) {
+                part[grp][t] = gcd_fast(part[grp][t], part[grp][t + w]);
+            } else {
+                for (int j = 0; j < 3; ++j) {
+                    const uint64_t o = part[3 + j][t + w];
+                    if (o > part[3 + j][t]) part[3 + j][t] = o;
+                }
             }
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         for (int j = 0; j < 3; ++j) {
             const uint64_t g = part[j][0];
-            f.d_units[j] = g ? (long long)g : 1ll;
-            f.d_units[3 + j] = (long long)(part[3 + j][0] / (g ? g : 1ull));  // largest scaled magnitude
+            const long long unit = g ? (long long)g : 1ll;
+            const long long top = (long long)(part[3 + j][0] / (g ? g : 1ull));  // largest scaled magnitude
+            f.d_units[j] = unit;
+            f.d_units[3 + j] = top;
+            f.d_scalars[4 + 2 * j] = (uint32_t)(unsigned long long)unit;
+            f.d_scalars[5 + 2 * j] = (uint32_t)((unsigned long long)unit >> 32);
+            f.d_scalars[10 + 2 * j] = (uint32_t)(unsigned long long)top;
+            f.d_scalars[11 + 2 * j] = (uint32_t)((unsigned long long)top >> 32);
         }
+        f.d_scalars[3] = sort_error != nullptr ? *sort_error : 0u;
         // evaluation list: zones that have a driver candidate AND an executor candidate, ordered by their first driver slot
         uint32_t nz = 0;
         for (uint32_t z = 0; z < f.n_zones; ++z) f.d_zeval[z] = GF_NO_NODE;
@@ -608,14 +725,12 @@ __global__ __launch_bounds__(256) void finalize_narrow_zones_kernel(SnapshotFina
     }
 }
 
-hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(f.d_zfirst, 0xFF, (size_t)f.n_zones * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(f.d_zhasx, 0, (size_t)f.n_zones * sizeof(uint32_t), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(f.d_scalars, 0, 4 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+// (d_zfirst, d_zhasx and d_scalars[0 .. 16) were cleared by launch_snapshot_build's one clearing kernel: SnapshotBuild names them)
+hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, const uint32_t* d_sort_error, hipStream_t stream) {
     const dim3 block(256), grid((unsigned)(((size_t)f.n_chunks * 64 + 255) / 256));
-    hipLaunchKernelGGL(finalize_slots_kernel, grid, block, 0, stream, f);
-    hipLaunchKernelGGL(finalize_reduce_kernel, dim3(1), block, 0, stream, f);
+    const dim3 sgrid((unsigned)(((size_t)f.n_chunks * 64 + kFinalizeBlock - 1) / kFinalizeBlock));
+    hipLaunchKernelGGL(finalize_slots_kernel, sgrid, dim3(kFinalizeBlock), 0, stream, f);
+    hipLaunchKernelGGL(finalize_reduce_kernel, dim3(1), dim3(4 * kReduceGroup), 0, stream, f, d_sort_error);
     hipLaunchKernelGGL(finalize_narrow_zones_kernel, grid, block, 0, stream, f);
     return hipGetLastError();
 }
@@ -716,19 +831,38 @@ hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
     const uint32_t n = b.n_nodes;
     if (n == 0) return hipSuccess;
     hipError_t e;
-    if (!b.usage_resident && (e = hipMemsetAsync(b.d_usage, 0, 3 * (size_t)n * sizeof(int64_t), stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.d_zone_sum, 0, 3 * (size_t)(b.n_zones ? b.n_zones : 1) * sizeof(int64_t), stream)) != hipSuccess)
-        return e;
+    // the priority sort's work area (count tables, barrier and scalars start at zero; metadata_kernel leaves the column ranges),
+    // the zone sums, the usage sums unless they are resident, and the finalize step's zone facts and scalars: one clearing launch
+    const size_t work_bytes = (size_t)(kSortHistWords + kSortStateWords) * sizeof(uint32_t) + kSortScalars * sizeof(unsigned long long);
+    {
+        SnapshotClear c{};
+        c.zero[0] = b.d_sort_work;
+        c.zero_words[0] = work_bytes / sizeof(uint32_t);
+        c.zero[1] = reinterpret_cast<uint32_t*>(b.d_zone_sum);
+        c.zero_words[1] = 2 * 3 * (size_t)(b.n_zones ? b.n_zones : 1);
+        if (!b.usage_resident) {
+            c.zero[2] = reinterpret_cast<uint32_t*>(b.d_usage);
+            c.zero_words[2] = 2 * 3 * (size_t)n;
+        }
+        if (b.d_zhasx != nullptr) {  // d_zhasx | d_zeval | d_scalars are one range (gf_snapshot_build's carve)
+            c.zero[3] = b.d_zhasx;
+            c.zero_words[3] = b.zhasx_to_scalars_words;
+        }
+        c.ones = b.d_zfirst;
+        c.ones_words = b.d_zfirst != nullptr ? b.n_zones : 0;
+        const size_t most = c.zero_words[2] > c.zero_words[0] ? c.zero_words[2] : c.zero_words[0];
+        const unsigned blocks = (unsigned)((most / 4 + 255) / 256);
+        hipLaunchKernelGGL(snapshot_clear_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(256), 0, stream, c);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     const dim3 block(256);
     if (b.n_res > 0 && !b.usage_resident)
         hipLaunchKernelGGL(usage_scatter_kernel, dim3((b.n_res + 255) / 256), block, 0, stream, b.n_res, n, b.d_res_node,
                            b.d_res_req, b.d_res_req + b.n_res, b.d_res_req + 2 * (size_t)b.n_res,
                            reinterpret_cast<unsigned long long*>(b.d_usage), 1);
-    // the priority sort's work area: count tables, barrier and scalars start at zero; metadata_kernel leaves the column ranges
-    const size_t work_bytes = (size_t)(kSortHistWords + kSortStateWords) * sizeof(uint32_t) + kSortScalars * sizeof(unsigned long long);
-    if ((e = hipMemsetAsync(b.d_sort_work, 0, work_bytes, stream)) != hipSuccess) return e;
     unsigned long long* sort_scal = reinterpret_cast<unsigned long long*>(b.d_sort_work + kSortHistWords + kSortStateWords);
-    const dim3 grid((n + 255) / 256);
+    const unsigned meta_blocks = (n + 255) / 256;
+    const dim3 grid(meta_blocks > kMetaBlocks ? kMetaBlocks : meta_blocks);
     hipLaunchKernelGGL(metadata_kernel, grid, block, 0, stream, n, b.d_alloc, b.d_overhead, (const int64_t*)b.d_usage,
                        b.d_zone, b.n_zones, b.d_avail, b.d_sched, reinterpret_cast<unsigned long long*>(b.d_zone_sum),
                        b.d_name_rank, b.d_perm_a, sort_scal);
