@@ -816,12 +816,17 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         f.d_zmasks = ctx->d_zmasks.ptr;
         f.d_nsnap = ctx->d_nsnap.ptr;
         f.d_ncmax = ctx->d_ncmax.ptr;
-        GF_HIP(ctx, gangfit::launch_snapshot_finalize(f, ctx->d_sortwork.ptr + gangfit::snapshot_sort_error_word(), st));
         GF_HIP(ctx, ctx->h_bcols.reserve(6 * N + 8));
         GF_HIP(ctx, ctx->h_border.reserve(N + 16));
-        // everything the host needs back is one range of sixteen words (SnapshotFinalize::d_scalars): one copy
+        // everything the host needs back is one range of sixteen words (SnapshotFinalize::d_scalars): the kernels write it into
+        // pinned memory as they produce it (no copy on the stream), or ONE copy where that memory is not mapped to the device
         uint32_t* h_scalars = ctx->h_border.ptr;
-        GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        if (ctx->h_border.dev != nullptr) {
+            std::memset(h_scalars, 0, 16 * sizeof(uint32_t));
+            f.h_out = ctx->h_border.dev;
+        }
+        GF_HIP(ctx, gangfit::launch_snapshot_finalize(f, ctx->d_sortwork.ptr + gangfit::snapshot_sort_error_word(), st));
+        if (f.h_out == nullptr) GF_HIP(ctx, hipMemcpyAsync(h_scalars, d_scalars, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         GF_HIP(ctx, gf_wait_stream(st));
         if (h_scalars[3] != 0) return fail(ctx, GF_ERR_HIP, "the priority sort's grid barrier gave up (device oversubscribed?)");
         const uint32_t nz = h_scalars[0];

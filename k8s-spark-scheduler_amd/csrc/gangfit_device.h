@@ -457,6 +457,8 @@ struct SnapshotFinalize {
     uint32_t* d_zeval;          // n_zones: zone -> index in the evaluation list, GF_NO_NODE = not evaluated
     uint32_t* d_scalars;        // 16 words: [0] = zones in the evaluation list, [1] = no narrow form, [2] = negative schedulable
                                 // value, [3] = the sort's error word, [4 .. 16) = d_units as pairs of words (one read-back)
+    uint32_t* h_out = nullptr;  // nullable: the device's address of sixteen pinned host words, ZEROED BY THE HOST before the launch, that
+                                // receive d_scalars as the kernels produce it (no read-back copy on the stream)
     uint64_t* d_zmasks;         // 2 * n_zones * n_chunks: executor rows, then (from row n_zones) driver rows
     int32_t* d_nsnap;           // 3 * n_slots
     int32_t* d_ncmax;           // 3 * n_chunks

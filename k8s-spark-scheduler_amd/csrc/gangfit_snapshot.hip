@@ -64,7 +64,7 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
 // Grid-stride over the nodes with at most kMetaBlocks workgroups, and ONE set of the six range atomics per workgroup: they are
 // device-scope read-modify-writes of one cache line and queue behind each other — one set per wavefront (rounds 2-5a: 1 563
 // wavefronts x 6 at 100 000 nodes) made this kernel 112 us of a 0.40 ms build, 15 us at 10 000 nodes.
-constexpr uint32_t kMetaBlocks = 96;
+constexpr uint32_t kMetaBlocks = 192;
 __global__ __launch_bounds__(256) void metadata_kernel(uint32_t n_nodes, const int64_t* __restrict__ alloc,
                                                        const int64_t* __restrict__ overhead,
                                                        const int64_t* __restrict__ usage, const uint32_t* __restrict__ zone,
@@ -220,7 +220,10 @@ __global__ void zone_rank_kernel(uint32_t n_zones, const long long* __restrict__
 // workgroup needed (860 us measured) and of the two dozen launches of a sorting library.  What is left is the barrier: the
 // XCDs' L2s are not coherent with each other, so each one is a write-back, an invalidate and a round trip to memory.
 constexpr uint32_t kSortWG = 64;          // workgroups = wavefronts
-constexpr int kSortTile = 8;              // 64-element chunks a wavefront has in flight per step (independent loads)
+constexpr int kSortTile = 16;             // 64-element chunks a wavefront has in flight per step (independent loads)
+constexpr int kSortKeyTile = 8;           // ... in the key build (a node id, then three gathers per element)
+constexpr int kSortRowBatch = 32;         // rows of the count table requested together (behind a grid barrier every one of them
+                                          // is a round trip to memory: eight at a time made a pass of 64 rows eight round trips)
 constexpr uint32_t kSortHistWords = 3u * kSortWG * 256u;  // three rotating count tables [segment][digit]
 constexpr uint32_t kSortStateWords = 4u;  // barrier count | barrier generation | error | spare
 constexpr uint32_t kSortScalars = 16u;    // 64-bit words behind the state (the first six: metadata_kernel's ranges)
@@ -230,7 +233,8 @@ struct PrioritySort {
     const int64_t* cpu;        // free cpu by node
     const int64_t* mem;        // free memory by node
     const uint32_t* zone;      // zone id by node
-    const uint32_t* zrank;     // zone id -> rank
+    const uint32_t* zrank;     // zone id -> rank (zone_rank_kernel; only read when there are more than 64 zones)
+    const long long* zone_sum; // free memory | free cpu per zone (metadata_kernel): up to 64 zones are ranked by the kernel itself
     unsigned long long* keys[3];
     uint32_t* perm[3];         // [0] holds the name order at launch, [1] receives the result: position -> node
     uint32_t* work;            // kSortHistWords + kSortStateWords uint32 + kSortScalars uint64; zero at launch but the ranges
@@ -282,8 +286,26 @@ __device__ __forceinline__ unsigned long long digit_peers(uint32_t d, bool valid
 
 __global__ __launch_bounds__(64) void priority_sort_kernel(PrioritySort A) {
     __shared__ uint32_t off[256];  // this segment's next output position per digit
+    __shared__ uint32_t zrank_l[64];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x;
     const uint32_t n = A.n;
+    // resourcesLessThan over the zones (nodesorting.go:73-80, 102-104: memory, then cpu, ascending; ties keep the caller's zone-id
+    // order): lane = zone, rank = the zones that sort before mine.  (A launch of its own — zone_rank_kernel — only beyond 64 zones.)
+    const bool zr_local = A.n_zones <= 64u;
+    if (zr_local) {
+        long long zm = 0, zc = 0;
+        if (lane < A.n_zones) {
+            zm = A.zone_sum[2 * (size_t)lane];
+            zc = A.zone_sum[2 * (size_t)lane + 1];
+        }
+        uint32_t r = 0;
+        for (uint32_t y = 0; y < A.n_zones; ++y) {
+            const long long ym = __shfl(zm, (int)y, 64), yc = __shfl(zc, (int)y, 64);
+            r += (ym != zm ? ym < zm : (yc != zc ? yc < zc : y < lane)) ? 1u : 0u;
+        }
+        zrank_l[lane] = r;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
     uint32_t* const hist = A.work;
     uint32_t* const state = A.work + kSortHistWords;
     const unsigned long long* const scal = reinterpret_cast<const unsigned long long*>(A.work + kSortHistWords + kSortStateWords);
@@ -325,31 +347,50 @@ __global__ __launch_bounds__(64) void priority_sort_kernel(PrioritySort A) {
             const uint32_t* pin = A.perm[src];
             for (uint32_t d = lane; d < 256u; d += 64u) off[d] = 0u;
             __builtin_amdgcn_s_waitcnt(0xC07F);
-            for (uint32_t base = lo; base < hi; base += 64u) {
-                const uint32_t i = base + lane;
-                const bool valid = i < hi;
-                unsigned long long key = 0ull;
-                if (valid) {
-                    const uint32_t node = pin[i];
-                    uint32_t sft = 0;
-                    if (has_c) {
-                        key = (biased(A.cpu[node]) - cmin) >> tzc;
-                        sft = wc;
-                    }
-                    if (has_m) {
-                        if (sft < 64u) key |= ((biased(A.mem[node]) - mmin) >> tzm) << sft;
-                        sft += wm;
-                    }
-                    if (has_z) {
-                        const uint32_t z = A.zone[node];
-                        const unsigned long long zr = z < A.n_zones ? A.zrank[z] : A.n_zones;
-                        if (sft < 64u) key |= zr << sft;
-                    }
-                    kin[i] = key;
+            // kSortKeyTile chunks at a time: their node ids, then all their gathers, then the keys — a chunk at a time was a chain
+            // of three dependent round trips (id -> columns -> zone rank) per 64 elements
+            for (uint32_t base = lo; base < hi; base += 64u * kSortKeyTile) {
+                uint32_t node[kSortKeyTile], zid[kSortKeyTile];
+                int64_t vc[kSortKeyTile], vm[kSortKeyTile];
+#pragma unroll
+                for (int t = 0; t < kSortKeyTile; ++t) {
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    node[t] = i < hi ? pin[i] : 0u;
                 }
-                const uint32_t d = (uint32_t)key & 255u;
-                const unsigned long long peers = digit_peers(d, valid);
-                if (valid && (peers & lt_mask) == 0ull) off[d] += (uint32_t)__popcll(peers);  // the peers' leader
+#pragma unroll
+                for (int t = 0; t < kSortKeyTile; ++t) {
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    vc[t] = (has_c && i < hi) ? A.cpu[node[t]] : 0;
+                    vm[t] = (has_m && i < hi) ? A.mem[node[t]] : 0;
+                    zid[t] = (has_z && i < hi) ? A.zone[node[t]] : 0u;
+                }
+#pragma unroll
+                for (int t = 0; t < kSortKeyTile; ++t) {
+                    if (base + (uint32_t)t * 64u >= hi) break;  // wave-uniform
+                    const uint32_t i = base + (uint32_t)t * 64u + lane;
+                    const bool valid = i < hi;
+                    unsigned long long key = 0ull;
+                    if (valid) {
+                        uint32_t sft = 0;
+                        if (has_c) {
+                            key = (biased(vc[t]) - cmin) >> tzc;
+                            sft = wc;
+                        }
+                        if (has_m) {
+                            if (sft < 64u) key |= ((biased(vm[t]) - mmin) >> tzm) << sft;
+                            sft += wm;
+                        }
+                        if (has_z) {
+                            const uint32_t z = zid[t];
+                            const unsigned long long zr = z < A.n_zones ? (zr_local ? zrank_l[z] : A.zrank[z]) : A.n_zones;
+                            if (sft < 64u) key |= zr << sft;
+                        }
+                        kin[i] = key;
+                    }
+                    const uint32_t d = (uint32_t)key & 255u;
+                    const unsigned long long peers = digit_peers(d, valid);
+                    if (valid && (peers & lt_mask) == 0ull) off[d] += (uint32_t)__popcll(peers);  // the peers' leader
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             uint32_t* row = hist + ((size_t)(P % 3u) * kSortWG + wave) * 256u;
@@ -371,14 +412,14 @@ __global__ __launch_bounds__(64) void priority_sort_kernel(PrioritySort A) {
             // ---- this segment's output offsets: digit-major exclusive scan over (digit, segment); lane l owns digits 4l .. 4l+3
             {
                 uint32_t tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
-                for (uint32_t r0 = 0; r0 < n_seg; r0 += 8u) {
-                    uint4 rows[8];
+                for (uint32_t r0 = 0; r0 < n_seg; r0 += (uint32_t)kSortRowBatch) {
+                    uint4 rows[kSortRowBatch];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
+                    for (int t = 0; t < kSortRowBatch; ++t)
                         rows[t] = (r0 + (uint32_t)t < n_seg) ? reinterpret_cast<const uint4*>(cur + (size_t)(r0 + t) * 256u)[lane]
                                                              : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
+                    for (int t = 0; t < kSortRowBatch; ++t) {
                         const bool before = r0 + (uint32_t)t < wave;
                         tot[0] += rows[t].x;
                         tot[1] += rows[t].y;
@@ -493,7 +534,10 @@ __global__ __launch_bounds__(kFinalizeBlock) void finalize_slots_kernel(Snapshot
         flags = f.d_flags[node];
         z = f.d_zone[node];
         f.d_node_slot[node] = s;
-        if (sc[0] < 0 || sc[1] < 0 || sc[2] < 0) atomicOr(&f.d_scalars[2], 1u);
+        if (sc[0] < 0 || sc[1] < 0 || sc[2] < 0) {
+            atomicOr(&f.d_scalars[2], 1u);
+            if (f.h_out != nullptr) f.h_out[2] = 1u;  // (every writer stores the same value: no atomic over the host link)
+        }
     }
     if (in_range) {
         for (int j = 0; j < 3; ++j) {
@@ -664,6 +708,9 @@ __global__ __launch_bounds__(4 * kReduceGroup) void finalize_reduce_kernel(Snaps
             f.d_scalars[11 + 2 * j] = (uint32_t)((unsigned long long)top >> 32);
         }
         f.d_scalars[3] = sort_error != nullptr ? *sort_error : 0u;
+        if (f.h_out != nullptr) {  // the host's copy, written in place (pinned, device-mapped; complete when the build's last kernel is)
+            for (int k = 3; k < 16; ++k) f.h_out[k] = f.d_scalars[k];
+        }
         // evaluation list: zones that have a driver candidate AND an executor candidate, ordered by their first driver slot
         uint32_t nz = 0;
         for (uint32_t z = 0; z < f.n_zones; ++z) f.d_zeval[z] = GF_NO_NODE;
@@ -678,6 +725,7 @@ __global__ __launch_bounds__(4 * kReduceGroup) void finalize_reduce_kernel(Snaps
             f.d_zeval[best] = nz++;
         }
         f.d_scalars[0] = nz;  // [1] = "a scaled value does not fit 2^30" (next kernel), [2] = "negative schedulable value"
+        if (f.h_out != nullptr) f.h_out[0] = nz;
     }
 }
 
@@ -697,7 +745,10 @@ __global__ __launch_bounds__(256) void finalize_narrow_zones_kernel(SnapshotFina
             bad = bad || q >= (INT64_C(1) << 30) || q <= -(INT64_C(1) << 30);
             v[j] = (int32_t)q;
         }
-    if (__ballot(bad) && lane == 0) atomicOr(&f.d_scalars[1], 1u);
+    if (__ballot(bad) && lane == 0) {
+        atomicOr(&f.d_scalars[1], 1u);
+        if (f.h_out != nullptr) f.h_out[1] = 1u;
+    }
     for (int j = 0; j < 3; ++j) {
         if (s < ns) f.d_nsnap[(size_t)j * ns + s] = v[j];
         int32_t m = s < ns ? v[j] : INT32_MIN;
@@ -728,8 +779,11 @@ __global__ __launch_bounds__(256) void finalize_narrow_zones_kernel(SnapshotFina
 // (d_zfirst, d_zhasx and d_scalars[0 .. 16) were cleared by launch_snapshot_build's one clearing kernel: SnapshotBuild names them)
 hipError_t launch_snapshot_finalize(const SnapshotFinalize& f, const uint32_t* d_sort_error, hipStream_t stream) {
     const dim3 block(256), grid((unsigned)(((size_t)f.n_chunks * 64 + 255) / 256));
-    const dim3 sgrid((unsigned)(((size_t)f.n_chunks * 64 + kFinalizeBlock - 1) / kFinalizeBlock));
-    hipLaunchKernelGGL(finalize_slots_kernel, sgrid, dim3(kFinalizeBlock), 0, stream, f);
+    // sixteen chunks per workgroup on large tables (fewer zone atomics); on small ones four — sixteen wavefronts of gcd loops
+    // share a CU's four SIMDs, and a 10 000-node table has no more wavefronts than the device has CUs (20 us against 13)
+    const unsigned sblock = f.n_chunks > 512u ? kFinalizeBlock : 256u;
+    const dim3 sgrid((unsigned)(((size_t)f.n_chunks * 64 + sblock - 1) / sblock));
+    hipLaunchKernelGGL(finalize_slots_kernel, sgrid, dim3(sblock), 0, stream, f);
     hipLaunchKernelGGL(finalize_reduce_kernel, dim3(1), dim3(4 * kReduceGroup), 0, stream, f, d_sort_error);
     hipLaunchKernelGGL(finalize_narrow_zones_kernel, grid, block, 0, stream, f);
     return hipGetLastError();
@@ -866,11 +920,12 @@ hipError_t launch_snapshot_build(const SnapshotBuild& b, hipStream_t stream) {
     hipLaunchKernelGGL(metadata_kernel, grid, block, 0, stream, n, b.d_alloc, b.d_overhead, (const int64_t*)b.d_usage,
                        b.d_zone, b.n_zones, b.d_avail, b.d_sched, reinterpret_cast<unsigned long long*>(b.d_zone_sum),
                        b.d_name_rank, b.d_perm_a, sort_scal);
-    hipLaunchKernelGGL(zone_rank_kernel, dim3(1), dim3(64), 0, stream, b.n_zones, (const long long*)b.d_zone_sum,
-                       b.d_zone_order, b.d_zone_rank);
+    if (b.n_zones > 64u)  // (up to 64 zones are ranked by the sort kernel itself: one launch less on the build's critical path)
+        hipLaunchKernelGGL(zone_rank_kernel, dim3(1), dim3(64), 0, stream, b.n_zones, (const long long*)b.d_zone_sum,
+                           b.d_zone_order, b.d_zone_rank);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // (zone rank, free memory, free cpu, name): one cooperative launch, the result sits in d_perm_b
-    PrioritySort ps{n, b.n_zones, b.d_avail, b.d_avail + n, b.d_zone, b.d_zone_rank,
+    PrioritySort ps{n, b.n_zones, b.d_avail, b.d_avail + n, b.d_zone, b.d_zone_rank, (const long long*)b.d_zone_sum,
                     {reinterpret_cast<unsigned long long*>(b.d_keys_a), reinterpret_cast<unsigned long long*>(b.d_keys_b),
                      reinterpret_cast<unsigned long long*>(b.d_keys_c)},
                     {b.d_perm_a, b.d_perm_b, b.d_perm_c}, b.d_sort_work, b.sort_fault ? (1u << 12) : (1u << 24)};
