@@ -24,6 +24,13 @@ NodeTable make_table(gf_ctx* ctx, int64_t* base) {
     t.d_identity = ctx->d_identity ? 1u : 0u;
     t.xmask = ctx->d_masks.ptr;
     t.dmask = ctx->d_masks.ptr + ctx->n_chunks;
+    // the snapshot's scaled int32 twin travels with the SNAPSHOT only (a chain's working copy has its own, in the chain's units)
+    if (ctx->narrow_ok && base == ctx->d_snap.ptr && ctx->d_nsnap.ptr != nullptr) {
+        t.ncpu = ctx->d_nsnap.ptr;
+        t.nmem = t.ncpu + ctx->n_slots;
+        t.ngpu = t.nmem + ctx->n_slots;
+        for (int j = 0; j < 3; ++j) t.nunit[j] = ctx->unit[j] > 0 ? ctx->unit[j] : 1;
+    }
     return t;
 }
 

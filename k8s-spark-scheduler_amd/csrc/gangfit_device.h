@@ -38,6 +38,13 @@ struct NodeTable {
     uint32_t n_slots;
     uint32_t n_nodes;
     uint32_t d_identity;        // 1: driver position == slot (merged layout)
+    // The SNAPSHOT in the scaled int32 domain (value = scaled value * nunit[dimension], |scaled value| < 2^30), slot order; nullptr
+    // when the snapshot has no such form.  Read by the minimal-fragmentation independent batch (gangfit_minfrag.inc), whose every
+    // pass evaluates every candidate slot: a capacity there is a multiply-high instead of a 64-bit quotient.
+    const int32_t* ncpu = nullptr;
+    const int32_t* nmem = nullptr;
+    const int32_t* ngpu = nullptr;
+    int64_t nunit[3] = {1, 1, 1};
 };
 
 // Sparse-dimension view of the executor order for the independent batch (merged layout): the executor candidates that have

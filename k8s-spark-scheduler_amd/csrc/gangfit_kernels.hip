@@ -31,6 +31,7 @@ namespace gangfit {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kMfHistBins = 256;  // minimal-fragmentation: capacities below this are counted in a histogram (Orders::mf_hist)
 #ifndef GF_WAVES_PER_BLOCK
 #define GF_WAVES_PER_BLOCK 4
 #endif
@@ -346,6 +347,7 @@ __device__ __forceinline__ bool load_with_cand(const View& V, uint32_t j, uint32
 }
 
 // Index tables that never change during a launch.
+typedef __attribute__((address_space(3))) uint32_t lds_u32h;
 struct Orders {
     const uint32_t* slot_node;
     const uint32_t* dslot;
@@ -354,6 +356,28 @@ struct Orders {
     bool d_identity;  // merged layout: driver position == slot, candidates flagged by the dmask bits
     bool dpos_mask = false;  // general layout: the view's dmask is indexed by driver POSITION and must be consulted
                              // (zone views; the plain general layout accepts every position)
+    // minimal-fragmentation, histogram form (gangfit_minfrag.inc: wave_minfrag_hist): 3 * kMfHistBins words of LDS private to the
+    // calling wavefront, 16-byte aligned, and the snapshot's scaled int32 columns (NodeTable::ncpu ..); nullptr = the
+    // pass-per-question walk on the wide table
+    lds_u32h* mf_hist = nullptr;
+    bool mf_lent = false;  // (an LDS array may sit at LDS address 0, which compares equal to nullptr: the flag says whether mf_hist is lent)
+    const int32_t* ncpu = nullptr;
+    const int32_t* nmem = nullptr;
+    const int32_t* ngpu = nullptr;
+    int64_t nunit0 = 1, nunit1 = 1, nunit2 = 1;
+#ifdef GF_MF_PROBE  // experiment build: where a minimal-fragmentation decision's cycles go (summed over the launch's applications)
+    unsigned long long* mf_probe = nullptr;
+#endif
+    __device__ __forceinline__ void lend_minfrag(lds_u32h* lds, const NodeTable& T) {
+        mf_hist = lds;
+        mf_lent = true;
+        ncpu = T.ncpu;
+        nmem = T.nmem;
+        ngpu = T.ngpu;
+        nunit0 = T.nunit[0];
+        nunit1 = T.nunit[1];
+        nunit2 = T.nunit[2];
+    }
     __device__ __forceinline__ uint32_t driver_slot(uint32_t i) const { return d_identity ? i : dslot[i]; }
 };
 
@@ -822,6 +846,25 @@ __device__ __forceinline__ int64_t wave_even_general(const View& V, const Orders
     return S;
 }
 
+// floor(a / e) for 0 <= a < 2^30 as a multiplication (Granlund & Montgomery, "Division by invariant integers using
+// multiplication", N = 30): with l = ceil(log2 e) and m = ceil(2^(30 + l) / e) < 2^31, floor(a / e) == (m a) >> (30 + l), i.e.
+// mulhi(2 m, 2 a) >> l — shift, multiply-high, shift: three instructions per dimension where the float estimate with its
+// exact correction took fourteen.  The request's three multipliers are computed once per application (prepare_app).
+__device__ __forceinline__ uint32_t narrow_shift(int32_t e) {  // l = ceil(log2 e); 0 for e <= 1
+    return e <= 1 ? 0u : 32u - (uint32_t)__builtin_clz((uint32_t)e - 1u);
+}
+__device__ __forceinline__ void narrow_magic(int32_t e, uint32_t& mag, uint32_t& sh) {
+    if (e <= 0) {
+        mag = 0;
+        sh = 0;
+        return;
+    }
+    const uint32_t l = narrow_shift(e);
+    const uint64_t m = ((1ull << (30u + l)) + (uint64_t)(uint32_t)e - 1ull) / (uint64_t)(uint32_t)e;
+    mag = (uint32_t)(2ull * m);
+    sh = l;
+}
+
 #include "gangfit_minfrag.inc"
 
 struct Decision {
@@ -1113,6 +1156,16 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
+    if constexpr (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) {  // the capacity histogram of this wavefront's application
+        __shared__ __attribute__((aligned(16))) uint32_t mf_hist[kWavesPerBlock * 3 * kMfHistBins];
+        O.lend_minfrag((lds_u32h*)mf_hist + (size_t)wave * 3 * kMfHistBins, T);
+#ifdef GF_MF_PROBE
+        if (stats != nullptr) O.mf_probe = &stats->fifo_phase_cycles[0];
+#endif
+    }
+#ifdef GF_MF_PROBE
+    const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
     // every launch starts with cold L2s: the chunk index of group 0 and the app record are requested together
     //      (unconditionally — a branch here would make the compiler wait for the loads at the join; the general layout
     //      ignores the values, the buffers exist in both layouts)
@@ -1136,6 +1189,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
         }
     };
     decide(load_app(apps, a), a);
+#ifdef GF_MF_PROBE
+    if constexpr (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION)
+        if (!FEAS && stats != nullptr && lane == 0) atomicAdd(&stats->fifo_phase_cycles[0], __builtin_readcyclecounter() - t_kernel0);
+#endif
     if (!FEAS && stats != nullptr && lane == 0) {
         atomicAdd(&stats->exec_slots_visited, xvis);
         atomicAdd(&stats->driver_slots_visited, dvis);

@@ -149,6 +149,46 @@ def test_single_az_minimal_fragmentation_random(gf_ctx, n, layout):
             assert np.array_equal(gf_ctx.residual(), ref.avail_after)
 
 
+@pytest.mark.parametrize("cap_hi", [3, 12, 60, 255, 300])
+@pytest.mark.parametrize("n", [5, 64, 65, 700, 3000])
+def test_histogram_form_level_walks(gf_ctx, n, cap_hi):
+    """The independent batch in its histogram form (gangfit_minfrag.inc: wave_minfrag_hist — scaled int32 table, capacities below
+    256 counted per value, the level walk planned on the counts and emitted by ONE pass): clusters of small whole capacities, many
+    nodes per level, gangs from one executor up to most of the cluster — single-node endings, complete and partial drains, the
+    "first undrained node of the last level" ending, the subset rule; cap_hi 255 / 300 put capacities at and beyond the last bin
+    (300: the walk on the wide table takes over).  Merged layout (D = X = every node), with and without zones."""
+    rng = np.random.default_rng(31337 + 17 * n + cap_hi)
+    caps = rng.integers(0, cap_hi + 1, size=n)
+    caps[rng.random(n) < 0.05] = -1  # overcommitted nodes
+    avail = np.stack([caps, np.full(n, 1000), rng.integers(0, 2, size=n)], axis=1).astype(np.int64)
+    order = rng.permutation(n).astype(np.uint32)
+    a = 150
+    total = int(np.maximum(caps, 0).sum())
+    k = rng.integers(1, max(2, total), size=a)
+    k[: a // 3] = rng.integers(1, max(2, min(total, 3 * cap_hi)), size=a // 3)  # the gangs one or two nodes take
+    k = np.minimum(k, 100000).astype(np.int32)
+    drv = np.stack([rng.integers(0, 3, size=a), rng.integers(0, 50, size=a), np.zeros(a, dtype=np.int64)], axis=1).astype(np.int64)
+    exe = np.stack([rng.integers(1, 3, size=a), rng.integers(0, 9, size=a), np.zeros(a, dtype=np.int64)], axis=1).astype(np.int64)
+    gf_ctx.set_snapshot(avail)
+    gf_ctx.set_orders(order, order)
+    apps = _gpu_apps(drv, exe, k)
+    gpu = gf_ctx.fit_batch(IND, MF, apps)
+    ref = ob.fit_independent(ob.ALGO_MINIMAL_FRAGMENTATION, avail, ob.make_apps(drv, exe, k), order, order)
+    _assert_same(gpu, ref, apps)
+    if total > 0:
+        assert ref.results["has_capacity"].any()
+    # the same cluster in three zones through the registered packer (one wavefront and one histogram per candidate zone)
+    zone = rng.integers(0, 3, size=n).astype(np.uint32)
+    sched = np.maximum(avail, 1) + 5
+    _setup(gf_ctx, avail, sched, zone, order, order)
+    k3 = np.minimum(k, max(1, total // 4)).astype(np.int32)
+    apps3 = gangfit.make_apps(drv, exe, k3)
+    gpu = gf_ctx.fit_batch(IND, SAZMF, apps3)
+    ref = ob.fit_independent(ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION, avail, ob.make_apps(drv, exe, k3), order, order, sched=sched,
+                             zone=zone)
+    _assert_same(gpu, ref, apps3)
+
+
 def test_headline_size(gf_ctx):
     """10 000 nodes x 1 000 apps (3 zones for the single-AZ wrapper) against the literal oracle."""
     w = wl.headline(10000, 1000)
