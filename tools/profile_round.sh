@@ -52,6 +52,8 @@ for g in $GROUPS_; do
                   "zc_saz chain single-az-tightly-pack" "zc_aza chain az-aware-tightly-pack" \
                   "mc_mf chain minimal-fragmentation" "mc_smf chain single-az-minimal-fragmentation"; do
         set -- $spec
+        # ZONED_SPECS="zb_smf ...": only these instantiations (tools/summarize_profile.py keeps the others' entries of pmc_zoned.json)
+        if [ -n "${ZONED_SPECS:-}" ] && ! echo " $ZONED_SPECS " | grep -q " $1 "; then continue; fi
         run_group $1 120 python $ROOT/tools/profile_cmd.py $2 $3
         timeout 120 rocprofv3 --kernel-trace --pmc $LDSSET -T -f csv -d "$OUT/$1_lds" -o pmc -- python $ROOT/tools/profile_cmd.py $2 $3 > "$OUT/$1_lds.log" 2>&1
       done

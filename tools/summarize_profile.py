@@ -215,6 +215,18 @@ def main():
                               "duration of the same command: hbm / 8 TB/s, l2 / 34.5 TB/s, issue / (simds x 2.4 GHz) with simds = 1 024 for a "
                               "grid-wide kernel and 4 (one compute unit) for a one-workgroup chain kernel",
           "kernels": {}}
+    # a round that profiles only some instantiations (ZONED_SPECS of tools/profile_round.sh) keeps the others' entries, each under the
+    # tag of the visit that produced it
+    old_zoned = os.path.join(dst, "pmc_zoned.json")
+    if os.path.exists(old_zoned):
+        try:
+            oz = json.load(open(old_zoned))
+            for pre0, e0 in (oz.get("kernels") or {}).items():
+                e0.setdefault("tag", oz.get("tag"))
+                zj["kernels"][pre0] = e0
+        except Exception:
+            pass
+    fresh = 0
     zmd = ""
     for pre, kname, algo, what, simds in ZONED:
         per = _group_means(src, pre)
@@ -246,13 +258,15 @@ def main():
             if fr:
                 e["bound"] = max(fr, key=fr.get)
                 e["frac"] = fr[e["bound"]]
+        e["tag"] = tag
         zj["kernels"][pre] = e
+        fresh += 1
         if os.path.exists(st):
             shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats_{pre}.csv"))
         zmd += (f"| {kname} | {algo} | {what} | {e['launches']} | {(a or 0) / 1e3:.1f} | {e.get('hbm_bytes') or 0:.0f} | {e.get('l2_request_bytes') or 0:.0f} | "
                 f"{e.get('instructions') or 0:.0f} | {(e.get('wait_fraction') or 0):.2f} | {(e.get('lds_bank_conflict_per_active_lds_cycle') or 0):.2f} | "
                 + " / ".join(f"{k2} {v2:.4f}" for k2, v2 in (e.get('fractions') or {}).items()) + " |\n")
-    if zj["kernels"]:
+    if fresh:
         json.dump(zj, open(os.path.join(dst, "pmc_zoned.json"), "w"), indent=1)
         md += ("## the zone-aware and minimal-fragmentation kernels, one instantiation per profiled command (`tools/profile_cmd.py`)\n\n"
                "| kernel | packer | what | launches | avg us | HBM B | L2 request B | instructions | wait | LDS conflict / active | fractions |\n"
