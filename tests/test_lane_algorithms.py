@@ -6,6 +6,8 @@ these models document WHY the routines are exact, step by step, and run without 
   zoned_choose_best      chooseBestResult (single_az.go:75-97) as a row max-scan
   narrow_magic           floor(a / e) as a multiplication (gangfit_fifo_common.inc), the chain kernels' capacity arithmetic
   zoned_choose_bounded   chooseBestResult from (tree sum, error bound) pairs: never a different winner than the exact sums
+  minfrag_histogram      minimalFragmentation (minimal_fragmentation.go:59-137) decided on the histogram of the capacities + one
+                         emission pass (csrc/gangfit_minfrag.inc: wave_minfrag_hist), against the walk over the sorted list
 """
 import numpy as np
 import pytest
@@ -334,3 +336,161 @@ def test_unclamped_quotient_by_reciprocal_is_exact(seed):
         checked += 1
         big += (a // e) >= (1 << 40)
     assert checked == 20000 and big > 100
+
+
+# ------------------------------------------------------------------------------------------------ minimal-fragmentation, histogram form
+# The sequential definition: minimal_fragmentation.go:59-137 on a list of (position, capacity) pairs, written as the reference
+# writes it (stable sort by capacity, sort.Search, slices).  The device routine (wave_minfrag_hist) never sorts: ONE pass counts the
+# capacities and keeps the first position of each, the whole walk is planned on the counts, and ONE more pass emits the runs of
+# the drained levels (a node knows its rank among its level's nodes in priority order from a running count per level).
+
+def _search(n, pred):
+    lo, hi = 0, n
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if pred(mid):
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
+
+
+def _internal_minfrag_reference(count, caps):
+    """internalMinimalFragmentation (:93-137); caps = [(position, capacity)] sorted by capacity, stable."""
+    caps = list(caps)
+    out = []
+    while caps:
+        pos = _search(len(caps), lambda i: caps[i][1] >= count)
+        if pos != len(caps):
+            return out + [caps[pos][0]] * count, True
+        mx = caps[-1][1]
+        first = _search(len(caps), lambda i: caps[i][1] >= mx)
+        cur = first
+        while count >= mx and cur < len(caps):
+            out += [caps[cur][0]] * mx
+            count -= mx
+            cur += 1
+        if count == 0:
+            return out, True
+        caps = caps[:first] + caps[cur:]
+    return None, False
+
+
+def minfrag_reference(count, capacities):
+    """minimalFragmentation (:59-91) for capacities[position] (0 = the node is filtered out)."""
+    if count == 0:
+        return [], True
+    caps = sorted(((p, c) for p, c in enumerate(capacities) if c > 0), key=lambda pc: pc[1])  # sort.SliceStable
+    if not caps:
+        return None, False
+    mx = caps[-1][1]
+    if count < mx:
+        target = (count + mx) // 2
+        first = _search(len(caps), lambda i: caps[i][1] >= target)
+        nodes, ok = _internal_minfrag_reference(count, caps[:first])
+        if ok:
+            return nodes, ok
+    return _internal_minfrag_reference(count, caps)
+
+
+def minfrag_histogram(count, capacities, bins=256):
+    """The device routine, step by step (None = not applicable: a capacity beyond the last bin -> the walk serves the request)."""
+    K = count
+    if K == 0:
+        return [], True
+    # pass 1: counts and first positions (LDS atomics: order-free)
+    cnt = [0] * bins
+    first = [None] * bins
+    for p, c in enumerate(capacities):
+        if c >= bins:
+            return None
+        if c > 0:
+            cnt[c] += 1
+            if first[c] is None:
+                first[c] = p
+    S = sum(cnt[c] * min(c, K) for c in range(bins))
+    if S < K:
+        return None, False
+    max_cap = max(c for c in range(bins) if cnt[c])
+    top = bins
+    if K < max_cap:
+        target = (K + max_cap) // 2
+        if sum(cnt[c] * min(c, K) for c in range(target)) >= K:
+            top = target
+
+    def smallest_at_least(need, below):
+        return next((c for c in range(max(need, 1), below) if cnt[c]), None)
+
+    def largest_below(below):
+        return next((c for c in range(below - 1, 0, -1) if cnt[c]), 0)
+
+    R = K
+    cf = smallest_at_least(R, top)
+    if cf is not None:
+        return [first[cf]] * K, True
+    take, base = {}, {}        # per drained level: nodes taken completely, where its runs start in the output
+    last_pos, next_level, next_rank = None, None, 0
+    while True:
+        m = largest_below(top)
+        assert 0 < m < R
+        q = R // m
+        drained = min(cnt[m], q)
+        take[m], base[m] = drained, K - R
+        R -= drained * m
+        if R == 0:
+            break
+        if drained < cnt[m]:
+            cf = smallest_at_least(R, m)
+            if cf is not None:
+                last_pos = first[cf]
+            else:
+                next_level, next_rank = m, drained
+            break
+        top = m
+        cf = smallest_at_least(R, top)
+        if cf is not None:
+            last_pos = first[cf]
+            break
+    # pass 2: the runs, every node by its rank among its level's nodes in priority order
+    out = [None] * K
+    seen = {}
+    for p, c in enumerate(capacities):
+        if c in take or c == next_level:
+            rank = seen.get(c, 0)
+            seen[c] = rank + 1
+            if rank < take.get(c, 0):
+                for i in range(c):
+                    out[base[c] + rank * c + i] = p
+            if c == next_level and rank == next_rank:
+                last_pos = p
+    if R > 0:
+        for i in range(R):
+            out[K - R + i] = last_pos
+    assert all(v is not None for v in out)
+    return out, True
+
+
+def test_minfrag_histogram_doc_comment_examples():
+    caps = [1, 1, 3, 5, 5, 17]  # a .. f of minimal_fragmentation.go:43-58
+    a, b, c, d, e, f = range(6)
+    assert minfrag_histogram(11, caps) == ([d] * 5 + [e] * 5 + [a], True)
+    assert minfrag_histogram(6, caps) == ([d] * 5 + [a], True)
+    assert minfrag_histogram(15, caps) == ([d] * 5 + [e] * 5 + [c] * 3 + [a, b], True)
+    assert minfrag_histogram(17, caps) == ([f] * 17, True)
+    for k in range(0, 40):
+        assert minfrag_histogram(k, caps) == minfrag_reference(k, caps)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_minfrag_histogram_is_the_walk_over_the_sorted_list(seed):
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(1, 400))
+    hi = int(rng.choice([2, 5, 12, 40, 255]))
+    caps = [int(v) for v in rng.integers(0, hi + 1, size=n)]
+    total = sum(caps)
+    for _ in range(40):
+        k = int(rng.integers(0, max(2, total + 3)))
+        got = minfrag_histogram(k, caps)
+        assert got is not None
+        assert got == minfrag_reference(k, caps), (k, caps)
+    assert minfrag_histogram(3, caps + [256]) is None  # beyond the last bin: the walk takes over
