@@ -6,6 +6,8 @@ these models document WHY the routines are exact, step by step, and run without 
   zoned_choose_best      chooseBestResult (single_az.go:75-97) as a row max-scan
   narrow_magic           floor(a / e) as a multiplication (gangfit_fifo_common.inc), the chain kernels' capacity arithmetic
   zoned_choose_bounded   chooseBestResult from (tree sum, error bound) pairs: never a different winner than the exact sums
+  chunk_gcd_rounds       the gcd of a 64-slot chunk by candidate rounds (csrc/gangfit_snapshot.hip: finalize_slots_kernel) and the
+                         two-operand gcd with the common power of two set aside (gcd_fast), against math.gcd
   minfrag_histogram      minimalFragmentation (minimal_fragmentation.go:59-137) decided on the histogram of the capacities + one
                          emission pass (csrc/gangfit_minfrag.inc: wave_minfrag_hist), against the walk over the sorted list
 """
@@ -494,3 +496,56 @@ def test_minfrag_histogram_is_the_walk_over_the_sorted_list(seed):
         assert got is not None
         assert got == minfrag_reference(k, caps), (k, caps)
     assert minfrag_histogram(3, caps + [256]) is None  # beyond the last bin: the walk takes over
+
+
+# ------------------------------------------------------------------------------------------------ snapshot build: the units' gcds
+# finalize_slots_kernel: every lane takes its value modulo a candidate (some non-zero value of the chunk); all remainders zero =>
+# the candidate, itself a member, is the gcd; else the candidate becomes its gcd with one non-zero remainder (at most half of it).
+
+def chunk_gcd_rounds(values):
+    import math
+    v = [abs(int(x)) for x in values]
+    any_or = 0
+    for x in v:
+        any_or |= x
+    if any_or == 0:
+        return 0, 0
+    tz = (any_or & -any_or).bit_length() - 1            # the common power of two comes from the OR of the magnitudes
+    w = [x >> tz for x in v]
+    cand = next(x for x in w if x)
+    rounds = 0
+    while True:
+        rounds += 1
+        rem = [x % cand for x in w]
+        left = [r for r in rem if r]
+        if not left:
+            break
+        cand = math.gcd(cand, left[0])                   # wave-uniform Euclid on the first non-zero remainder
+    return cand << tz, rounds
+
+
+def gcd_fast(a, b):
+    import math
+    if a == b or b == 0:
+        return a
+    if a == 0:
+        return b
+    sh = ((a | b) & -(a | b)).bit_length() - 1
+    a >>= (a & -a).bit_length() - 1
+    b >>= (b & -b).bit_length() - 1
+    return math.gcd(a, b) << sh                           # (the device runs Euclid on the odd parts, in 32 bits when both fit)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_chunk_gcd_by_candidate_rounds(seed):
+    import math
+    rng = np.random.default_rng(9100 + seed)
+    unit = int(rng.choice([1, 100, 250, 1 << 20, 3 << 28, 1000]))
+    n = int(rng.integers(1, 65))
+    vals = [int(x) * unit * int(rng.choice([1, -1])) for x in rng.integers(0, 5000, size=n)]
+    got, rounds = chunk_gcd_rounds(vals)
+    assert got == math.gcd(*[abs(x) for x in vals]) if any(vals) else got == 0
+    assert rounds <= 33                                   # the candidate at least halves per round
+    for _ in range(50):
+        a, b = (int(x) * unit for x in rng.integers(0, 1 << 20, size=2))
+        assert gcd_fast(a, b) == math.gcd(a, b)
