@@ -8,6 +8,8 @@ these models document WHY the routines are exact, step by step, and run without 
   zoned_choose_bounded   chooseBestResult from (tree sum, error bound) pairs: never a different winner than the exact sums
   chunk_gcd_rounds       the gcd of a 64-slot chunk by candidate rounds (csrc/gangfit_snapshot.hip: finalize_slots_kernel) and the
                          two-operand gcd with the common power of two set aside (gcd_fast), against math.gcd
+  checkpoint_lookup      the source checkpoint of a delta-format overlay, lane = checkpoint (csrc/gangfit_fifo_common.inc:
+                         chain_prologue_kernel), against the walk back through the checkpoints
   minfrag_histogram      minimalFragmentation (minimal_fragmentation.go:59-137) decided on the histogram of the capacities + one
                          emission pass (csrc/gangfit_minfrag.inc: wave_minfrag_hist), against the walk over the sorted list
 """
@@ -549,3 +551,36 @@ def test_chunk_gcd_by_candidate_rounds(seed):
     for _ in range(50):
         a, b = (int(x) * unit for x in rng.integers(0, 1 << 20, size=2))
         assert gcd_fast(a, b) == math.gcd(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ resumed chains: the overlay's source
+# chain_prologue_kernel, delta format: a chunk named by the cumulative mask comes from the LATEST checkpoint at or before `count`
+# whose delta mask names it.  Sequential: walk j = count .. 1.  Device: lane l looks at checkpoint hi - l, 64 at a time from
+# hi = count downwards; the lowest lane with its bit set is the latest checkpoint.
+
+def checkpoint_walk(delta, count, chunk):
+    for j in range(count, 0, -1):
+        if delta[j - 1][chunk]:
+            return j
+    return 0
+
+
+def checkpoint_lanes(delta, count, chunk):
+    hi = count
+    while hi >= 1:
+        bits = [(hi - lane >= 1) and bool(delta[hi - lane - 1][chunk]) for lane in range(WAVE)]
+        if any(bits):
+            return hi - bits.index(True)
+        hi = hi - 64 if hi > 64 else 0
+    return 0
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_checkpoint_lookup_by_lanes(seed):
+    rng = np.random.default_rng(4400 + seed)
+    count = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 200]))
+    chunks = 40
+    delta = rng.random((count, chunks)) < float(rng.choice([0.02, 0.2, 0.7]))
+    for c in range(chunks):
+        for upto in {count, max(1, count // 2), 1}:
+            assert checkpoint_lanes(delta, upto, c) == checkpoint_walk(delta, upto, c)
