@@ -584,3 +584,30 @@ def test_checkpoint_lookup_by_lanes(seed):
     for c in range(chunks):
         for upto in {count, max(1, count // 2), 1}:
             assert checkpoint_lanes(delta, upto, c) == checkpoint_walk(delta, upto, c)
+
+
+# ------------------------------------------------------------------------------------------------ the C oracle against the same walk
+# oracle/gangfit_oracle.c is the checker of every GPU parity test; here ITS minimal-fragmentation is held to the Python
+# transcription of minimal_fragmentation.go:59-137 above (minfrag_reference) — an independent restatement written from the Go
+# source in a different language and shape (lists and slices instead of index arithmetic).
+
+@pytest.mark.parametrize("seed", range(25))
+def test_the_c_oracle_agrees_with_the_python_transcription_of_the_go_walk(seed):
+    from oracle import binding as ob
+    rng = np.random.default_rng(5200 + seed)
+    n = int(rng.integers(1, 120))
+    hi = int(rng.choice([2, 6, 20, 300]))
+    caps = [int(v) for v in rng.integers(0, hi + 1, size=n)]
+    # node i takes caps[i] executors of (1 cpu, 1 B); one more node, outside the executor order, hosts the driver
+    avail = [[c, 10 ** 6, 0] for c in caps] + [[1, 1, 0]]
+    order = [int(v) for v in rng.permutation(n)]
+    in_order = [caps[p] for p in order]
+    total = sum(caps)
+    for _ in range(25):
+        k = int(rng.integers(0, max(2, total + 3)))
+        ok, drv_node, ex = ob.spark_binpack(ob.ALGO_MINIMAL_FRAGMENTATION, avail, [1, 1, 0], [1, 1, 0], k, [n], order)
+        want, want_ok = minfrag_reference(k, in_order)
+        assert ok == want_ok, (k, caps)
+        if ok:
+            assert drv_node == n
+            assert [int(v) for v in ex] == [order[p] for p in want], (k, in_order)
