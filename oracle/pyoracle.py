@@ -8,6 +8,10 @@ loops — so that it can be read side by side with the reference.  It is indepen
 Citations are relative to /root/reference; LIB = vendor/github.com/palantir/k8s-spark-scheduler-lib/pkg.
 Quantities are canonical ints (cpu milli, memory bytes, gpu count) held in 3-tuples/lists.
 
+minimalFragmentation (LIB/binpack/minimal_fragmentation.go, LIB/capacity/capacity.go) is restated here with the reference's own
+shape too — a stably sorted list of (node, capacity) pairs, sort.Search, slices — so that the C oracle's index arithmetic and the
+device's histogram form are both held to something that reads like the Go source.
+
 Parity status: DistributeEvenly and FIFO replay are PARITY UNPINNED (no reference test selects them, no Go
 toolchain in this image); TightlyPack feasibility is pinned by the reference tests listed in
 tests/test_oracle_reference_kats.py.
@@ -88,6 +92,95 @@ def distribute_executors_evenly(exe, count, order, avail, reserved):
                 if len(nodes) == count:
                     return nodes, True
     return None, False
+
+
+MAX_INT = (1 << 63) - 1  # math.MaxInt on a 64-bit Go build
+
+
+def _go_int(v: int) -> int:
+    """Go int arithmetic wraps (two's complement, 64 bits)."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def capacity_against_single_dimension(available: int, reserved: int, required: int) -> int:
+    """getCapacityAgainstSingleDimension — LIB/capacity/capacity.go:36-56."""
+    available, reserved, required = int(available), int(reserved), int(required)  # (callers may hand over numpy scalars)
+    if reserved > available:
+        return 0
+    if required == 0:
+        return MAX_INT
+    return (available - reserved) // required  # inf.RoundFloor of a non-negative quotient
+
+
+def get_node_capacity(available: Sequence[int], reserved: Sequence[int], single_executor: Sequence[int]) -> int:
+    """GetNodeCapacity — LIB/capacity/capacity.go:59-75."""
+    return min(capacity_against_single_dimension(available[j], reserved[j], single_executor[j]) for j in range(3))
+
+
+def get_node_capacities(order, avail, reserved, single_executor):
+    """GetNodeCapacities + FilterOutNodesWithoutCapacity — LIB/capacity/capacity.go:78-113: [(name, capacity)], capacity > 0,
+    in nodePriorityOrder; names outside the metadata are left out."""
+    out = []
+    for n in order:
+        if n in avail:
+            c = get_node_capacity(avail[n], reserved.get(n, [0, 0, 0]), single_executor)
+            if c > 0:
+                out.append((n, c))
+    return out
+
+
+def _search(n: int, pred) -> int:
+    """sort.Search: the smallest index in [0, n) for which pred is true (n when there is none)."""
+    lo, hi = 0, n
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if pred(mid):
+            hi = mid
+        else:
+            lo = mid + 1
+    return lo
+
+
+def internal_minimal_fragmentation(count: int, caps):
+    """internalMinimalFragmentation — LIB/binpack/minimal_fragmentation.go:93-137; caps sorted by capacity (stable)."""
+    caps = list(caps)
+    nodes: List[str] = []
+    while len(caps) > 0:
+        position = _search(len(caps), lambda i: caps[i][1] >= count)
+        if position != len(caps):
+            return nodes + [caps[position][0]] * count, True
+        max_capacity = caps[-1][1]
+        first_max = _search(len(caps), lambda i: caps[i][1] >= max_capacity)
+        cur = first_max
+        while count >= max_capacity and cur < len(caps):
+            nodes += [caps[cur][0]] * max_capacity
+            count -= max_capacity
+            cur += 1
+        if count == 0:
+            return nodes, True
+        caps = caps[:first_max] + caps[cur:]
+    return None, False
+
+
+def minimal_fragmentation(exe, count, order, avail, reserved):
+    """minimalFragmentation — LIB/binpack/minimal_fragmentation.go:59-91 (never writes into `reserved`)."""
+    count = int(count)
+    if count == 0:
+        return [], True
+    caps = get_node_capacities(order, avail, reserved, exe)
+    if len(caps) == 0:
+        return None, False
+    caps.sort(key=lambda nc: nc[1])  # sort.SliceStable: Python's sort is stable
+    max_capacity = caps[-1][1]
+    if count < max_capacity:
+        total = _go_int(count + max_capacity)  # (executorCount + maxCapacity) wraps when maxCapacity is math.MaxInt
+        target = total // 2 if total >= 0 else -((-total) // 2)  # Go's integer division truncates towards zero
+        first = _search(len(caps), lambda i: caps[i][1] >= target)
+        nodes, ok = internal_minimal_fragmentation(count, caps[:first])
+        if ok:
+            return nodes, ok
+    return internal_minimal_fragmentation(count, caps)
 
 
 def spark_binpack(drv, exe, count, driver_order, exec_order, avail, packer: Packer) -> PackingResult:
@@ -192,6 +285,12 @@ def single_az(packer: Packer):
 
 
 single_az_tightly_pack = single_az(tightly_pack_executors)
+single_az_minimal_fragmentation = single_az(minimal_fragmentation)  # LIB/binpack/single_az_minimal_fragmentation.go:20
+
+
+def minimal_fragmentation_pack(drv, exe, count, driver_order, exec_order, avail) -> PackingResult:
+    """MinimalFragmentation — LIB/binpack/minimal_fragmentation.go:27-34."""
+    return spark_binpack(drv, exe, count, driver_order, exec_order, avail, minimal_fragmentation)
 
 
 def az_aware_tightly_pack(drv, exe, count, driver_order, exec_order, avail, sched, zone) -> PackingResult:

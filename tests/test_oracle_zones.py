@@ -17,8 +17,11 @@ def _py(algo, avail, sched, zone, drv, exe, k, D, X):
     av = {f"n{i}": list(r) for i, r in enumerate(avail)}
     sc = {f"n{i}": list(r) for i, r in enumerate(sched)}
     zn = {f"n{i}": int(z) for i, z in enumerate(zone)}
-    fn = po.single_az_tightly_pack if algo == SAZ else po.az_aware_tightly_pack
-    r = fn(drv, exe, k, names(D), names(X), av, sc, zn)
+    if algo == ob.ALGO_MINIMAL_FRAGMENTATION:
+        r = po.minimal_fragmentation_pack(drv, exe, k, names(D), names(X), av)
+    else:
+        fn = {SAZ: po.single_az_tightly_pack, AZA: po.az_aware_tightly_pack, SAZ_MF: po.single_az_minimal_fragmentation}[algo]
+        r = fn(drv, exe, k, names(D), names(X), av, sc, zn)
     return r.has_capacity, r.driver_node, r.executor_nodes
 
 
@@ -120,13 +123,15 @@ def _random_zoned(rng, n_nodes, n_zones):
     return avail, sched, zone, D, X, drv, exe, int(rng.integers(0, 9))
 
 
-@pytest.mark.parametrize("algo", [SAZ, AZA])
+@pytest.mark.parametrize("algo", [SAZ, AZA, SAZ_MF, ob.ALGO_MINIMAL_FRAGMENTATION])
 def test_three_restatements_agree_on_random_zoned_cases(algo):
     rng = np.random.default_rng(1234 + algo)
     feasible = 0
     for _ in range(400):
         n = int(rng.integers(1, 9))
         avail, sched, zone, D, X, drv, exe, k = _random_zoned(rng, n, int(rng.integers(1, 4)))
+        if algo in (SAZ_MF, ob.ALGO_MINIMAL_FRAGMENTATION) and rng.random() < 0.5:
+            k = int(rng.integers(0, 40))  # gangs that need several capacity levels
         apps = ob.make_apps([drv], [exe], [k])
         lit = ob.fit_independent(algo, avail, apps, D, X, False, sched=sched, zone=zone)
         clo = ob.fit_independent(algo, avail, apps, D, X, True, sched=sched, zone=zone)
@@ -139,7 +144,7 @@ def test_three_restatements_agree_on_random_zoned_cases(algo):
         if ok:
             feasible += 1
             assert pd == f"n{d}" and pex == [f"n{i}" for i in ex]
-    assert feasible > 50
+    assert feasible > 40
 
 
 def test_fifo_chain_with_single_az_packer_commits_the_chosen_zone():
