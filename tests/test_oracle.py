@@ -145,7 +145,7 @@ def test_fifo_quirk_k7():
     assert not res[1].has_capacity
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 def test_fifo_chain_c_vs_python(algo):
     rng = np.random.default_rng(7 + algo)
     for _ in range(60):
@@ -162,7 +162,8 @@ def test_fifo_chain_c_vs_python(algo):
         out = ob.fit_fifo_chain(algo, avail, apps, D, X)
         av = {f"n{i}": [int(v) for v in avail[i]] for i in range(n)}
         papps = [([int(v) for v in drv[i]], [int(v) for v in exe[i]], int(k[i]), bool(flags[i])) for i in range(a)]
-        res, failed = po.fit_earlier_drivers_then_pack(po.select_binpacker(ALGOS[algo]), papps, [f"n{i}" for i in D],
+        binpack = po.minimal_fragmentation_pack if algo == 2 else po.select_binpacker(ALGOS[algo])  # (2: not a registry name)
+        res, failed = po.fit_earlier_drivers_then_pack(binpack, papps, [f"n{i}" for i in D],
                                                        [f"n{i}" for i in X], av)
         assert failed == out.failed_at
         for i in range(a):
