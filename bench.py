@@ -1318,7 +1318,7 @@ def main():
                                 "frac": k.get("frac"), "fractions": k.get("fractions"), "traffic": k.get("hbm_bytes"),
                                 "wait_fraction": k.get("wait_fraction"),
                                 "lds_bank_conflict_per_active_lds_cycle": k.get("lds_bank_conflict_per_active_lds_cycle"),
-                                "simds": k.get("simds"), "counters_from": f"profiles/pmc_zoned.json ({zp.get('tag')}), entry {key}"}
+                                "simds": k.get("simds"), "counters_from": f"profiles/pmc_zoned.json ({k.get('tag') or zp.get('tag')}), entry {key}"}
                     if role == "fifo_chain":
                         rf[role]["this_run_filter_p50_ms"] = extras[name]["fifo_filter_p50_ms"]
                 if rf:
