@@ -110,3 +110,50 @@ def test_minimal_fragmentation_places_k_within_the_capacities(cl, rq):
             assert n not in seen
             seen.add(n)
             prev = n
+
+
+chain = st.lists(st.tuples(request, st.booleans()), min_size=1, max_size=6)
+
+
+@settings(max_examples=200, deadline=None)
+@given(cluster, chain, st.sampled_from([ob.ALGO_TIGHTLY_PACK, ob.ALGO_DISTRIBUTE_EVENLY, ob.ALGO_MINIMAL_FRAGMENTATION]))
+def test_fifo_replay_is_the_single_decision_applied_in_order_with_the_map_quirk(cl, apps, algo):
+    """fitEarlierDrivers + the final pack (resource.go:224-262, 309-328) rebuilt from ONE-decision calls: every earlier driver is
+    packed against what its predecessors left; a feasible one subtracts ONE executor request per DISTINCT executor node and the
+    driver request only where no executor landed (sparkResourceUsage builds a map: sparkpods.go:139-146); one that does not fit
+    is skipped when flagged and aborts the request otherwise; the last application is packed and nothing is subtracted."""
+    avail, dperm, xperm, nd, nx = cl
+    D, X = list(dperm[:nd]), list(xperm[:nx])
+    drv = [list(a[0][0]) for a in apps]
+    exe = [list(a[0][1]) for a in apps]
+    k = [a[0][2] for a in apps]
+    flags = [ob.APP_SKIPPABLE if a[1] else 0 for a in apps]
+    out = ob.fit_fifo_chain(algo, avail, ob.make_apps(drv, exe, k, flags), D, X)
+    table = [list(r) for r in avail]
+    failed = -1
+    for i in range(len(apps)):
+        ok, d, ex = ob.spark_binpack(algo, table, drv[i], exe[i], k[i], D, X)
+        got_ok, got_d, got_ex = out.placement(i)
+        assert out.results[i]["evaluated"] != 0
+        assert (ok, d if ok else ob.NO_NODE) == (got_ok, got_d)
+        if ok:
+            assert [int(v) for v in ex] == [int(v) for v in got_ex]
+        last = i == len(apps) - 1
+        if last:
+            break
+        if not ok:
+            if flags[i]:
+                continue
+            failed = i
+            break
+        hosts = set(int(v) for v in ex)
+        for n in hosts:
+            for j in range(3):
+                table[n][j] -= exe[i][j]
+        if d not in hosts:
+            for j in range(3):
+                table[d][j] -= drv[i][j]
+    assert out.failed_at == failed
+    if failed >= 0:
+        assert all(out.results[j]["evaluated"] == 0 for j in range(failed + 1, len(apps)))
+    assert out.avail_after.tolist() == table
