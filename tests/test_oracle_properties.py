@@ -157,3 +157,49 @@ def test_fifo_replay_is_the_single_decision_applied_in_order_with_the_map_quirk(
     if failed >= 0:
         assert all(out.results[j]["evaluated"] == 0 for j in range(failed + 1, len(apps)))
     assert out.avail_after.tolist() == table
+
+
+zoned_cluster = st.integers(1, 8).flatmap(lambda n: st.tuples(
+    st.lists(st.tuples(st.integers(0, 12), st.integers(0, 12), st.integers(0, 2)), min_size=n, max_size=n),          # used
+    st.lists(st.tuples(st.integers(1, 12), st.integers(1, 12), st.integers(0, 2)), min_size=n, max_size=n),          # schedulable
+    st.lists(st.integers(0, 2), min_size=n, max_size=n),                                                              # zone
+    st.permutations(list(range(n))), st.permutations(list(range(n))), st.integers(0, n), st.integers(0, n)))
+
+
+@settings(max_examples=250, deadline=None)
+@given(zoned_cluster, request,
+       st.sampled_from([(ob.ALGO_SINGLE_AZ_TIGHTLY_PACK, ob.ALGO_TIGHTLY_PACK, True),
+                        (ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION, ob.ALGO_MINIMAL_FRAGMENTATION, False),
+                        (ob.ALGO_AZ_AWARE_TIGHTLY_PACK, ob.ALGO_TIGHTLY_PACK, True)]))
+def test_zone_wrappers_are_the_inner_packer_per_zone_and_the_strictly_best_average(cl, rq, algos):
+    """getSingleAZSparkBinFunction + chooseBestResult (single_az.go:23-97) rebuilt from the INNER packer run on every zone's
+    sub-orders and the averages of ComputeAvgPackingEfficiency: zones in order of first appearance in the driver order, zones
+    without executor candidates skipped, the first feasible zone with the strictly highest average Max wins (from 0.0);
+    az-aware-tightly-pack falls back to the plain pack (az_aware_pack_tightly.go:33-37)."""
+    used, sched, zone, dperm, xperm, nd, nx = cl
+    wrapper, inner, reserves_execs = algos
+    avail = [[s - u for s, u in zip(srow, urow)] for srow, urow in zip(sched, used)]
+    D, X = list(dperm[:nd]), list(xperm[:nx])
+    drv, exe, k = rq
+    ok, d, ex = ob.spark_binpack(wrapper, avail, drv, exe, k, D, X, sched=sched, zone=zone)
+    zones = []
+    for n in D:
+        if zone[n] not in zones:
+            zones.append(zone[n])
+    best, best_max = None, 0.0
+    for z in zones:
+        Dz, Xz = [n for n in D if zone[n] == z], [n for n in X if zone[n] == z]
+        if not Xz:
+            continue
+        zok, zd, zex = ob.spark_binpack(inner, avail, drv, exe, k, Dz, Xz)
+        if not zok:
+            continue
+        avg = ob.avg_packing_efficiency_list(avail, sched, drv, exe, zd, [int(v) for v in zex], reserved_includes_executors=reserves_execs)
+        if best_max < avg[3]:
+            best, best_max = (zd, [int(v) for v in zex]), float(avg[3])
+    if best is None and wrapper == ob.ALGO_AZ_AWARE_TIGHTLY_PACK:
+        pok, pd, pex = ob.spark_binpack(inner, avail, drv, exe, k, D, X)
+        best = (pd, [int(v) for v in pex]) if pok else None
+    assert ok == (best is not None)
+    if ok:
+        assert (d, [int(v) for v in ex]) == best
