@@ -2,12 +2,21 @@
 generated clusters (hypothesis): independent of HOW the oracle computes its answers — only capacities by the closed form
 (capacity.go:36-75) and the definitions of the three packers are used.  CPU only; the GPU parity tests compare the kernels with this
 oracle, so what holds for it holds for them."""
+import os
+
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
 from oracle import binding as ob
 
 INF = 1 << 40
+# The same examples on every run (a parity suite must not be a lottery); GANGFIT_PROPERTY_EXAMPLES=<n> draws n fresh random ones
+# per property instead — how the properties were hunted with before they were committed (20 000 examples each).
+_HUNT = int(os.environ.get("GANGFIT_PROPERTY_EXAMPLES", "0"))
+
+
+def _settings(n):
+    return settings(max_examples=_HUNT or n, deadline=None, derandomize=not _HUNT)
 
 
 def _cap(avail_row, base, exe):
@@ -52,7 +61,7 @@ def _check_common(algo, avail, D, X, drv, exe, k):
     return d, ex
 
 
-@settings(max_examples=300, deadline=None)
+@_settings(300)
 @given(cluster, request)
 def test_tightly_pack_is_the_prefix_of_the_run_length_sequence(cl, rq):
     avail, dperm, xperm, nd, nx = cl
@@ -68,7 +77,7 @@ def test_tightly_pack_is_the_prefix_of_the_run_length_sequence(cl, rq):
     assert ex == want[:k]
 
 
-@settings(max_examples=300, deadline=None)
+@_settings(300)
 @given(cluster, request)
 def test_distribute_evenly_is_round_robin_over_the_nodes_with_room(cl, rq):
     avail, dperm, xperm, nd, nx = cl
@@ -88,7 +97,7 @@ def test_distribute_evenly_is_round_robin_over_the_nodes_with_room(cl, rq):
     assert ex == want[:k]
 
 
-@settings(max_examples=300, deadline=None)
+@_settings(300)
 @given(cluster, request)
 def test_minimal_fragmentation_places_k_within_the_capacities(cl, rq):
     avail, dperm, xperm, nd, nx = cl
@@ -115,7 +124,7 @@ def test_minimal_fragmentation_places_k_within_the_capacities(cl, rq):
 chain = st.lists(st.tuples(request, st.booleans()), min_size=1, max_size=6)
 
 
-@settings(max_examples=200, deadline=None)
+@_settings(200)
 @given(cluster, chain, st.sampled_from([ob.ALGO_TIGHTLY_PACK, ob.ALGO_DISTRIBUTE_EVENLY, ob.ALGO_MINIMAL_FRAGMENTATION]))
 def test_fifo_replay_is_the_single_decision_applied_in_order_with_the_map_quirk(cl, apps, algo):
     """fitEarlierDrivers + the final pack (resource.go:224-262, 309-328) rebuilt from ONE-decision calls: every earlier driver is
@@ -166,7 +175,7 @@ zoned_cluster = st.integers(1, 8).flatmap(lambda n: st.tuples(
     st.permutations(list(range(n))), st.permutations(list(range(n))), st.integers(0, n), st.integers(0, n)))
 
 
-@settings(max_examples=250, deadline=None)
+@_settings(250)
 @given(zoned_cluster, request,
        st.sampled_from([(ob.ALGO_SINGLE_AZ_TIGHTLY_PACK, ob.ALGO_TIGHTLY_PACK, True),
                         (ob.ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION, ob.ALGO_MINIMAL_FRAGMENTATION, False),
