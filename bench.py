@@ -310,6 +310,9 @@ def _trim_roofline(rf):
     if not rf:
         return None
     out = {k: _r(rf.get(k)) for k in ("kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic", "wait_fraction")}
+    for k in ("profile_steps", "profile_kernel_us", "profile_frac", "visited_bytes", "visited_over_formula"):
+        if rf.get(k) is not None:
+            out[k] = _r(rf.get(k), 4)
     fr = rf.get("fractions") or {}
     out["fractions"] = {k: _r(v.get("frac")) for k, v in fr.items()}
     return out
@@ -330,8 +333,14 @@ def compact_line(full):
     bc = reg.get("blocking_call") or {}
     if bc.get("us_per_call") is not None:
         t["regimes"]["blocking_call"] = {"value": _r(bc.get("value")), "us_per_call": _r(bc.get("us_per_call"))}
+        t["regimes"]["blocking_call"]["is"] = "SURVEY 8d end-to-end: host memory in and out, one call"
         if bc.get("feasibility_only_us_per_call") is not None:  # gf_fit_feasible: what UnschedulablePodMarker reads
             t["regimes"]["blocking_call"]["feasibility_only_us_per_call"] = _r(bc.get("feasibility_only_us_per_call"))
+    cg = (full.get("extras") or {}).get("congested") or {}
+    if cg.get("decisions_per_s"):  # the hard case of the same batch: usage ~U[0.95, 1], about half of the gangs do not fit
+        t["regimes"]["congested"] = {"value": _r(cg.get("decisions_per_s")), "kernel_ms": _r(cg.get("kernel_ms")),
+                                     "feasible_fraction": _r(cg.get("feasible_fraction"), 3), "regime": "launch_per_batch",
+                                     "cpu_1_core": _r((cg.get("cpu_baseline") or {}).get("value"))}
     fc = rf.get("fifo_chain")
     if fc:
         c = _trim_roofline(fc)
@@ -347,9 +356,15 @@ def compact_line(full):
         if f:
             c["fifo_chain"] = {k: _r(f.get(k)) for k in ("literal_p50_ms", "with_efficiency_maps_p50_ms", "reference_shaped_p50_ms",
                                                          "gpu_cold_p50_ms", "speedup_cold_p50", "cores", "kind")}
+        ac = (full.get("cpu_baseline_variants") or {}).get("literal_all_cores") or {}
+        if ac.get("value"):
+            c["all_cores"] = {"value": _r(ac.get("value")), "cores": ac.get("cores")}
         line["cpu_baseline"] = c
     line["full"] = full.get("full_results_file")
     text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT and "fifo_chain" in line["roofline"]:
+        line["roofline"]["fifo_chain"].pop("fractions", None)
+        text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_LIMIT:  # cannot happen with the fields above; a guard, so that the driver always gets a line it can parse
         for k in ("sample",):
             if "cpu_baseline" in line:
@@ -684,7 +699,17 @@ def main():
         step(TIGHT)
         singles.append(ctx.timer_end())
     isolated_launch_ms = _median(singles[10:])
-    prof = load_profile("pmc_headline.json") or {}
+    prof_all = load_profile("pmc_headline.json") or {}
+    # one entry per profiled command (tools/profile_round.sh: the driver's --steps 20 --warmup 5 and bench.py's defaults); the
+    # counters per step depend on K (launch ramp, idle polling), so this run reads the entry taken at ITS --steps — or, failing
+    # that, the nearest one, and says so
+    prof_runs = prof_all.get("runs") or {}
+    prof_key = f"steps{args.steps}"
+    if prof_runs and prof_key not in prof_runs:
+        prof_key = min(prof_runs, key=lambda k: abs(int(k[5:]) - args.steps))
+    prof = dict(prof_runs.get(prof_key) or prof_all)
+    prof.setdefault("tag", prof_all.get("tag"))
+    prof_steps = prof.get("steps")
 
     def kernel_roofline(kernel, regime, kernel_ms_step, how, per_step, visited):
         """per_step: the profile's counters of one step of this kernel ({hbm_bytes, l2_request_bytes, instructions, ...}) or None."""
@@ -695,10 +720,18 @@ def main():
                 "achieved": fr[bound]["achieved"] if bound else None, "peak": fr[bound]["peak"] if bound else None,
                 "unit": fr[bound]["unit"] if bound else None, "fractions": fr,
                 "traffic": ps.get("hbm_bytes"),
-                "counters_from": (f"profiles/pmc_headline.json ({prof.get('tag')}): separate rocprofv3 --pmc passes of this command "
-                                  "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; TCC_HIT + TCC_MISS x 128 B; SQ_INSTS_*), per step — a "
-                                  "committed profile, not this run; the kernel time IS this run's") if per_step else
+                "counters_from": (f"profiles/pmc_headline.json ({prof.get('tag')}, entry runs.{prof_key}: `{prof.get('command')}`): separate "
+                                  "rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; TCC_HIT + TCC_MISS x 128 B; "
+                                  "SQ_INSTS_*), per step — a committed profile, not this run; the kernel time IS this run's") if per_step else
                                  "no committed counter profile of this kernel: fractions unmeasured",
+                "profile_steps": prof_steps, "profile_steps_match": (prof_steps == args.steps) if per_step else None,
+                # the same counters over the PROFILE's own kernel time (rocprofv3's median dispatch / K): what a reader of
+                # profiles/pmc_headline.json reproduces without this run
+                "profile_kernel_us": (ps.get("rocprof_ns_per_ticket") or ps.get("rocprof_median_dispatch_ns") or
+                                      ps.get("rocprof_avg_dispatch_ns") or 0) * 1e-3 or None,
+                "profile_frac": ((ps.get("fractions_over_own_duration") or {}).get(bound) if bound else None),
+                "visited_bytes": visited,
+                "visited_over_formula": (visited / alg_bytes) if visited else None,
                 "wait_fraction": ps.get("wait_fraction"),
                 "information_only": {
                     "visited_bytes_per_step": visited, "visited_GBps": (visited / (kernel_ms_step * 1e-3) / 1e9) if visited else None,

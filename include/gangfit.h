@@ -166,6 +166,11 @@ const char *gf_last_error(gf_ctx *ctx);
  *   "lds_budget"             bytes of LDS one workgroup may use (<= the device's): smaller table fronts, global tails
  *   "minfrag_matrix", "minfrag_hist", "sparse_gpu", "zero_copy"   0 disables the respective structure
  *   "feasible_announce"      0: gf_fit_feasible waits for its stream instead of watching the answers arrive in pinned memory
+ *                            (GANGFIT_WAIT=block has the same effect: no spinning on the answers)
+ *   "zoned_fused"            0: the zone-aware packers' independent batches (gf_fit_batch, gf_fit_feasible) take the four-kernel
+ *                            route (fit_zoned_kernel, avg_efficiency_kernel, zone_select_kernel, translate) instead of the one
+ *                            launch of fit_zoned_fused_kernel (the default since round 5; views inherit the setting)
+ *   "worker_sets", "worker_blocks_per_set", "worker_idle_us"   geometry and idle time of the resident worker (0 = the library's choice)
  *   "snapshot_finalize_host" 1: gf_snapshot_build* builds the slot tables through gf_orders_set on the host
  *   "force_general_layout"   1: gf_orders_set never merges the two orders into one slot order
  *   "sort_fault"             1: fault injection — the priority sort's grid barrier cannot complete; gf_snapshot_build* then
@@ -279,8 +284,11 @@ int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
  * bytes of placements, and nothing is copied out but those bytes.  With mapped staging (the default) the bytes announce
  * themselves: each is preset to "not yet", one more workgroup of the kernel collects them in device memory and writes the whole array with system-scope
  * stores, and the call returns when the last byte has arrived — without the kernel-end write-back and the stream's completion
- * signal (a kernel that never answers is noticed after 2 ms through the stream).  No gf_scan_stats counters.  Blocking.  Every packer (the zone-aware ones and a
- * multi-device context go through gf_fit_batch internally). */
+ * signal (a kernel that never answers is noticed after 2 ms through the stream).  No gf_scan_stats counters.  Blocking.  Every packer: the plain ones
+ * through fit_independent_kernel's feasibility instantiation, the zone-aware ones through fit_zoned_fused_kernel's (one launch;
+ * option "zoned_fused" = 0, more than 63 zones or missing schedulable columns: gf_fit_batch internally, of which only
+ * HasCapacity is handed on — as for a multi-device context).  The kernel's placements go to buffers no other entry point uses,
+ * so a call that follows on another stream never meets the tail of this one. */
 int gf_fit_feasible(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, uint8_t *has_capacity);
 
 /* Incremental FIFO chains.  The reference replays every earlier driver on every Filter (internal/extender/resource.go:309-328);
@@ -364,6 +372,24 @@ int gf_packing_efficiencies(gf_ctx *ctx, gf_algo algo, const gf_app *app, const 
  *   node_out   n_req node indices, GF_NO_NODE = "not enough capacity to reschedule the executor" (failure-fit) */
 int gf_executor_fit(gf_ctx *ctx, int minimal_fragmentation, uint32_t n_req, const int64_t *exe, const int64_t *reserved,
                     const uint32_t *hosts_app, uint32_t *node_out);
+/* The same with the zone step of the executor Filter on the device: filterNodesToZone (internal/extender/resource.go:462-478,
+ * applied at :606-632 when a single-AZ packer runs with should-schedule-dynamically-allocated-executors-in-same-az and
+ * getCommonZoneForExecutorsApplication, :493-519, found ONE zone).  Replaces: the narrowing of availableNodes / nodeNames
+ * before NodeSchedulingMetadataForNodes and PotentialNodes in rescheduleExecutor.
+ *   node_zone  n_nodes zone ids of the label THIS path reads, topology.kubernetes.io/zone (not
+ *              necessarily the label gf_zones_set describes); no entry may be GF_ANY_ZONE
+ *   req_zone   n_req zone ids: request q only considers nodes n with node_zone[n] == req_zone[q]; GF_ANY_ZONE = every node
+ *              (the application's pods span several zones, :628-630)
+ *   both NULL  = gf_executor_fit.
+ * Exactness: the reference filters BEFORE it sorts.  Filtering the installed executor order gives the same sequence as
+ * sorting the filtered set whenever the order INSIDE a zone does not depend on the other zones: true for the reference's
+ * order (AZ priority, then free memory, free cpu, name: nodesorting.go:95-122) when node_zone partitions the nodes like the
+ * zones that order ranked (both labels carry the same value — every cluster the reference's tests build), and for any order
+ * when every node is in one zone.  A host whose two labels disagree filters on its side and calls gf_executor_fit
+ * (host/extender.cpp does: always exact). */
+#define GF_ANY_ZONE 0xFFFFFFFFu
+int gf_executor_fit_zoned(gf_ctx *ctx, int minimal_fragmentation, uint32_t n_req, const int64_t *exe, const int64_t *reserved,
+                          const uint32_t *hosts_app, const uint32_t *node_zone, const uint32_t *req_zone, uint32_t *node_out);
 
 /* findNodes of the failover reconciler (internal/extender/failover.go:412-436; call site :368): reserve space for k
  * executors of each of n_req stale applications by walking the executor order of gf_orders_set (the reconciler's

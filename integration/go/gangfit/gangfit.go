@@ -682,6 +682,54 @@ func (c *Context) FitFeasibleOnInstalledSnapshot(algo int, apps []App) ([]bool, 
 	return out, nil
 }
 
+// ExecutorFitOnInstalledSnapshot is the node choice of rescheduleExecutor (internal/extender/resource.go:594-673) for a batch
+// of executors against the installed snapshot and executor order: the first-fit loop (:658-662) or, minimalFragmentation = true,
+// rescheduleExecutorWithMinimalFragmentation (:675-703).  zones == nil: no zone step.  Otherwise nodeZone[n] is the id of node
+// n's topology.kubernetes.io/zone label (NOT the label the snapshot's zones come from, SURVEY.md quirk 7) and zones[q] the id
+// of the zone getCommonZoneForExecutorsApplication (:493-519) found for request q, or AnyZone when the application's running
+// pods span several zones (:628-630): filterNodesToZone (:462-478) then happens on the device (gf_executor_fit_zoned; exact
+// when both zone labels agree — include/gangfit.h — otherwise filter nodeNames in Go first and pass zones = nil).
+// Returns node names, "" = "not enough capacity to reschedule the executor".  Unverified here (no Go toolchain);
+// tests/test_executor_fit.py drives the C entry point.
+const AnyZone = ^uint32(0)
+
+func (c *Context) ExecutorFitOnInstalledSnapshot(minimalFragmentation bool, executors []*resources.Resources, nodeZone, zones []uint32) ([]string, error) {
+	if len(executors) == 0 {
+		return nil, nil
+	}
+	exe := make([]int64, 0, 3*len(executors))
+	for _, r := range executors {
+		v, err := canonical(r)
+		if err != nil {
+			return nil, err
+		}
+		exe = append(exe, v[0], v[1], v[2])
+	}
+	mf := C.int(0)
+	if minimalFragmentation {
+		mf = 1
+	}
+	out := make([]uint32, len(executors))
+	c.mu.Lock()
+	defer c.mu.Unlock()
+	var rc C.int
+	if zones == nil {
+		rc = C.gf_executor_fit(c.ctx, mf, C.uint32_t(len(executors)), p64(exe), nil, nil, p32(out))
+	} else {
+		rc = C.gf_executor_fit_zoned(c.ctx, mf, C.uint32_t(len(executors)), p64(exe), nil, nil, p32(nodeZone), p32(zones), p32(out))
+	}
+	if rc != C.GF_OK {
+		return nil, c.err(rc)
+	}
+	names := make([]string, len(out))
+	for i, n := range out {
+		if n != ^uint32(0) && int(n) < len(c.names) {
+			names[i] = c.names[n]
+		}
+	}
+	return names, nil
+}
+
 // WorkerStop makes the resident worker leave the device now (it leaves by itself when idle).
 func (c *Context) WorkerStop() error {
 	c.mu.Lock()

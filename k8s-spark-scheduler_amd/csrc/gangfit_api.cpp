@@ -312,6 +312,8 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_xreserved.release();
     ctx->d_xhosts.release();
     ctx->d_xout.release();
+    ctx->d_xnzone.release();
+    ctx->d_xqzone.release();
     ctx->g_part_loc.release();
     ctx->g_part_all.release();
     ctx->g_drv_loc.release();
@@ -328,6 +330,9 @@ void gf_destroy(gf_ctx* ctx) {
     ctx->d_results.release();
     ctx->d_exec.release();
     ctx->d_scratch.release();
+    ctx->d_feas_exec.release();
+    ctx->d_feas_scratch.release();
+    ctx->d_feas_zexec.release();
     ctx->d_failed.release();
     ctx->d_stats.release();
     ctx->h_table.release();

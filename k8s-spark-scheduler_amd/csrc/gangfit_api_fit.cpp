@@ -845,9 +845,20 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
         // a multi-device context, or a route without a feasibility-only kernel: the full batch, of which only HasCapacity is
         // handed on
         uint64_t total_k = 0;
-        for (uint32_t a = 0; a < n_apps; ++a) total_k += apps[a].k > 0 ? (uint64_t)apps[a].k : 0;
-        std::vector<gf_result> res(n_apps);
-        std::vector<uint32_t> exec((size_t)total_k + 1);
+        for (uint32_t a = 0; a < n_apps; ++a) {  // validated HERE: the sizes below come from it (gf_fit_batch checks the rest)
+            if (apps[a].k < 0 || apps[a].k > GF_MAX_K)
+                return fail(ctx, GF_ERR_INVALID, "apps[%u].k = %d outside [0, %d]", a, apps[a].k, GF_MAX_K);
+            total_k += (uint64_t)apps[a].k;
+        }
+        std::vector<gf_result> res;
+        std::vector<uint32_t> exec;
+        try {  // no exception crosses the C ABI
+            res.resize(n_apps);
+            exec.resize((size_t)total_k + 1);
+        } catch (const std::exception&) {
+            return fail(ctx, GF_ERR_CAPACITY, "gf_fit_feasible: no host memory for %u results + %llu placements", n_apps,
+                        (unsigned long long)total_k);
+        }
         const int rc = gf_fit_batch(ctx, GF_MODE_INDEPENDENT, algo, n_apps, apps, res.data(), exec.data(), total_k, nullptr);
         if (rc != GF_OK) return rc;
         for (uint32_t a = 0; a < n_apps; ++a) has_capacity[a] = res[a].has_capacity ? 1 : 0;
@@ -874,8 +885,8 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
         total_k += (uint64_t)in.k;
     }
     const uint64_t half = total_k + 1;
-    GF_HIP(ctx, ctx->d_exec.reserve(total_k + 1));
-    GF_HIP(ctx, ctx->d_scratch.reserve(2 * half));
+    GF_HIP(ctx, ctx->d_feas_exec.reserve(total_k + 1));  // private to this entry point: see gf_ctx::d_feas_exec
+    GF_HIP(ctx, ctx->d_feas_scratch.reserve(2 * half));
     GF_HIP(ctx, ctx->h_feasible.reserve((size_t)n_apps + 4));  // the kernel writes whole words
     hipStream_t st = ctx->stream;
     {  // the collection words start at zero; the kernel's collecting workgroup leaves them at zero again
@@ -903,26 +914,29 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
     // arrive instead of waiting for the kernel-end write-back and the stream's completion signal (6-8 us of a 12-15 us wait:
     // profiles/r5h_feasible_call.txt).  A byte that has arrived is final, so no ordering between them is needed; when all have
     // arrived every wavefront has read its record and made its decision — what the kernel still owes (placement stores to device
-    // memory, its end) is ordered before anything this context puts on its stream next.  gf_fit_batch cannot do the same:
+    // memory, its end) goes to buffers only this entry point uses (d_feas_*), and the next gf_fit_feasible is ordered behind it
+    // on the context's stream: an entry point that launches on a caller's stream, or copies on the null stream, shares nothing
+    // with the tail of this kernel.  gf_fit_batch cannot do the same:
     // 13 000 placement words written through over the host link cost more than the signal they replace (round 4: 30.3 us
     // against 23.3).
     constexpr uint8_t kNotYet = 0xFF;
-    const bool announce = mapped && ctx->feasible_announce;
+    // (GANGFIT_WAIT=block: the host cannot spare a core for the duration of a call — no spinning on the answers either)
+    const bool announce = mapped && ctx->feasible_announce && !wait_blocking();
     if (announce) std::memset(ctx->h_feasible.ptr, kNotYet, n_apps);
     const auto t_staged = clk::now();
     hipError_t e;
     if (fused_zoned) {
         const uint32_t nz = ctx->n_zones;
         const int inner = algo == GF_ALGO_SINGLE_AZ_MINIMAL_FRAGMENTATION ? GF_ALGO_MINIMAL_FRAGMENTATION : GF_ALGO_TIGHTLY_PACK;
-        e = ctx->d_zexec.reserve(((uint64_t)nz + 1) * half);
+        e = ctx->d_feas_zexec.reserve(((uint64_t)nz + 1) * half);
         gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)ctx->zd_row0 * ctx->zstride, nz, ctx->zstride};
         if (e == hipSuccess)
             e = gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), zt,
-                                                ctx->d_sched.ptr, ctx->d_zexec.ptr, half, n_apps, d_apps, nullptr, nullptr,
-                                                ctx->d_scratch.ptr, half, st, d_feas, ctx->d_feasible_sync.ptr);
+                                                ctx->d_sched.ptr, ctx->d_feas_zexec.ptr, half, n_apps, d_apps, nullptr, nullptr,
+                                                ctx->d_feas_scratch.ptr, half, st, d_feas, ctx->d_feasible_sync.ptr);
     } else {
         e = gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps, nullptr,
-                                            ctx->d_exec.ptr, ctx->d_scratch.ptr, half, nullptr, st, d_feas,
+                                            ctx->d_feas_exec.ptr, ctx->d_feas_scratch.ptr, half, nullptr, st, d_feas,
                                             ctx->d_feasible_sync.ptr);
     }
     if (e == hipSuccess && !mapped)
@@ -981,16 +995,26 @@ int gf_spark_binpack(gf_ctx* ctx, gf_algo algo, const gf_app* app, gf_result* re
 
 int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, const int64_t* exe, const int64_t* reserved,
                     const uint32_t* hosts_app, uint32_t* node_out) {
-    GF_DELEGATE(ctx, gf_executor_fit(ctx, minimal_fragmentation, n_req, exe, reserved, hosts_app, node_out));
+    return gf_executor_fit_zoned(ctx, minimal_fragmentation, n_req, exe, reserved, hosts_app, nullptr, nullptr, node_out);
+}
+
+int gf_executor_fit_zoned(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, const int64_t* exe, const int64_t* reserved,
+                          const uint32_t* hosts_app, const uint32_t* node_zone, const uint32_t* req_zone, uint32_t* node_out) {
+    GF_DELEGATE(ctx, gf_executor_fit_zoned(ctx, minimal_fragmentation, n_req, exe, reserved, hosts_app, node_zone, req_zone, node_out));
     if (!ctx) return GF_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     GF_VIEW_ENTER(ctx)
     if (n_req == 0) return GF_OK;
     if (!exe || !node_out) return fail(ctx, GF_ERR_INVALID, "exe/node_out must not be NULL");
     if (!ctx->have_orders) return fail(ctx, GF_ERR_STATE, "gf_snapshot_set + gf_orders_set must precede gf_executor_fit");
+    if ((node_zone == nullptr) != (req_zone == nullptr))
+        return fail(ctx, GF_ERR_INVALID, "node_zone and req_zone come together (both NULL: no zone step)");
     for (size_t i = 0; i < 3 * (size_t)n_req; ++i)
         if (exe[i] < 0 || exe[i] >= GF_MAX_ABS_QUANTITY) return fail(ctx, GF_ERR_INVALID, "executor request outside [0, 2^62)");
     const uint32_t n = ctx->n_nodes;
+    if (node_zone)
+        for (uint32_t i = 0; i < n; ++i)
+            if (node_zone[i] == GF_ANY_ZONE) return fail(ctx, GF_ERR_INVALID, "node_zone[%u] is GF_ANY_ZONE: a node has a zone", i);
     if (reserved)
         for (size_t i = 0; i < 3 * (size_t)n; ++i)
             if (reserved[i] < 0 || reserved[i] >= GF_MAX_ABS_QUANTITY)
@@ -1010,9 +1034,16 @@ int gf_executor_fit(gf_ctx* ctx, int minimal_fragmentation, uint32_t n_req, cons
         GF_HIP(ctx, ctx->d_xhosts.reserve((size_t)n_req * words));
         GF_HIP(ctx, hipMemcpyAsync(ctx->d_xhosts.ptr, hosts_app, (size_t)n_req * words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
+    if (node_zone) {
+        GF_HIP(ctx, ctx->d_xnzone.reserve((size_t)n + 1));
+        GF_HIP(ctx, ctx->d_xqzone.reserve(n_req));
+        if (n) GF_HIP(ctx, hipMemcpyAsync(ctx->d_xnzone.ptr, node_zone, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        GF_HIP(ctx, hipMemcpyAsync(ctx->d_xqzone.ptr, req_zone, (size_t)n_req * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
     GF_HIP(ctx, gangfit::launch_executor_fit(minimal_fragmentation != 0, make_table(ctx, ctx->d_snap.ptr),
                                              reserved ? ctx->d_xreserved.ptr : nullptr, n_req, ctx->d_xexe.ptr,
-                                             with_hosts ? ctx->d_xhosts.ptr : nullptr, words, ctx->d_xout.ptr, st));
+                                             with_hosts ? ctx->d_xhosts.ptr : nullptr, words, node_zone ? ctx->d_xnzone.ptr : nullptr,
+                                             node_zone ? ctx->d_xqzone.ptr : nullptr, ctx->d_xout.ptr, st));
     GF_HIP(ctx, hipMemcpyAsync(node_out, ctx->d_xout.ptr, (size_t)n_req * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     GF_HIP(ctx, gf_wait_stream(st));
     return GF_OK;

@@ -143,7 +143,7 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
             constexpr uint32_t kWavesPerGroup = 16;
             bps = (n_first + per_wave * kWavesPerGroup - 1) / (per_wave * kWavesPerGroup);
             if (bps < 1) bps = 1;
-            if (1u + bps > room) bps = room - 1u;
+            if (1u + bps > room) bps = room > 1u ? room - 1u : 1u;  // (a one-CU device: refused below, never divided by zero)
         }
         if (sets == 0) {
             sets = (room - 1u) / bps;
@@ -301,6 +301,7 @@ int gf_worker_submit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_batches, const gf
     }
     bool need_launch = false;
     ctx->worker.hint_per_wave = 3;  // a stream of tickets: throughput (worker_launch)
+    if (n_batches) ctx->worker.hint_apps = batches[0].n_apps;  // a launch sizes itself by the batch about to be posted, not by the last gf_worker_fit
     if (const int rc = worker_prepare(ctx, algo, max_k, &need_launch); rc != GF_OK) return rc;
     gf_ctx::Worker& w = ctx->worker;
     const uint64_t first = w.posted;

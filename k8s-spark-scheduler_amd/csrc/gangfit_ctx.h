@@ -366,7 +366,7 @@ struct gf_ctx {
 
     // single-executor requests (gf_executor_fit)
     DeviceBuf<int64_t> d_xexe, d_xreserved;
-    DeviceBuf<uint32_t> d_xhosts, d_xout;
+    DeviceBuf<uint32_t> d_xhosts, d_xout, d_xnzone, d_xqzone;
 
     // ---- multi-device context (gf_init with n_dev > 1): this object only routes; one sub-context per device id does the
     //      work and owns shard `shard` of `n_shards` of the priority order.  The g_* members live in the sub-contexts.
@@ -397,6 +397,10 @@ struct gf_ctx {
     DeviceBuf<gf_app> d_apps;
     DeviceBuf<gf_result> d_results;
     DeviceBuf<uint32_t> d_exec, d_scratch;
+    // gf_fit_feasible's own placement / scratch / per-view buffers: the call may return while its kernel is still storing
+    // placements (the answers announce themselves), so nothing another entry point launches — on a caller's stream, or with a
+    // null-stream copy — may share them
+    DeviceBuf<uint32_t> d_feas_exec, d_feas_scratch, d_feas_zexec;
     DeviceBuf<int32_t> d_failed;
     DeviceBuf<ScanStats> d_stats;
     PinnedBuf<gf_app> h_apps;

@@ -392,8 +392,8 @@ hipError_t launch_shard_reduce_pull(const PeerPtrs& srcs, uint32_t* d_dst, size_
 // Placing one executor per request (gangfit_executor.inc): first fit or the minimal-fragmentation choice.
 // d_reserved: 3 x n_nodes int64 by node index (row-major, nullable); d_hosts: per request a bit set over node indices.
 hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& table, const int64_t* d_reserved, uint32_t n_req,
-                               const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
-                               hipStream_t stream);
+                               const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, const uint32_t* d_node_zone,
+                               const uint32_t* d_req_zone, uint32_t* d_node_out, hipStream_t stream);
 
 // findNodes of the failover reconciler (gangfit_findnodes.inc): n_req requests against the executor order; chained = one
 // wavefront walks them in order on `table` (the mutable working copy) and subtracts each request's `reserved` map.

@@ -2383,16 +2383,16 @@ hipError_t launch_shard_reduce_pull(const PeerPtrs& srcs, uint32_t* d_dst, size_
 }
 
 hipError_t launch_executor_fit(bool minimal_fragmentation, const NodeTable& table, const int64_t* d_reserved, uint32_t n_req,
-                               const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, uint32_t* d_node_out,
-                               hipStream_t stream) {
+                               const int64_t* d_exe, const uint32_t* d_hosts, uint32_t hosts_stride, const uint32_t* d_node_zone,
+                               const uint32_t* d_req_zone, uint32_t* d_node_out, hipStream_t stream) {
     if (n_req == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
     if (minimal_fragmentation)
         hipLaunchKernelGGL(executor_fit_kernel<true>, app_grid(n_req), block, 0, stream, table, d_reserved, n_req, d_exe,
-                           d_hosts, hosts_stride, d_node_out);
+                           d_hosts, hosts_stride, d_node_zone, d_req_zone, d_node_out);
     else
         hipLaunchKernelGGL(executor_fit_kernel<false>, app_grid(n_req), block, 0, stream, table, d_reserved, n_req, d_exe,
-                           d_hosts, hosts_stride, d_node_out);
+                           d_hosts, hosts_stride, d_node_zone, d_req_zone, d_node_out);
     return hipGetLastError();
 }
 

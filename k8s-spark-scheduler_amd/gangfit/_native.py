@@ -38,12 +38,13 @@ assert APP_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
 
 # every symbol include/gangfit.h declares (tests check that the library exports all of them)
 GF_RESIDENT_USAGE = 0xFFFFFFFF
+GF_ANY_ZONE = 0xFFFFFFFF
 
 EXPORTED_SYMBOLS = [
     "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch", "gf_fit_feasible",
     "gf_fit_batch_dev", "gf_spark_binpack", "gf_residual_get", "gf_timer_begin", "gf_timer_end", "gf_scan_stats", "gf_chain_profile",
     "gf_selftest", "gf_device_info_get", "gf_zones_set", "gf_avg_packing_efficiency", "gf_packing_efficiencies",
-    "gf_hbm_probe", "gf_executor_fit", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
+    "gf_hbm_probe", "gf_executor_fit", "gf_executor_fit_zoned", "gf_snapshot_build", "gf_snapshot_get", "gf_shard_set", "gf_shard_partials_dev", "gf_shard_drivers_dev", "gf_shard_emit_dev", "gf_shard_finish_dev",
     "gf_find_nodes", "gf_ctx_lock", "gf_ctx_unlock", "gf_launch_floor",
     "gf_graph_begin", "gf_graph_end", "gf_graph_launch", "gf_graph_destroy", "gf_cluster_set", "gf_snapshot_build_resident",
     "gf_usage_reset", "gf_usage_apply", "gf_set_option", "gf_chain_cache_stats", "gf_generation", "gf_shard_count", "gf_ctx_view",
@@ -154,6 +155,8 @@ def load() -> C.CDLL:
     L.gf_snapshot_get.argtypes = [p, p, p]
     L.gf_executor_fit.restype = i32
     L.gf_executor_fit.argtypes = [p, i32, u32, p, p, p, p]
+    L.gf_executor_fit_zoned.restype = i32
+    L.gf_executor_fit_zoned.argtypes = [p, i32, u32, p, p, p, p, p, p]
     L.gf_ctx_lock.restype = None
     L.gf_ctx_lock.argtypes = [p]
     L.gf_ctx_unlock.restype = None

@@ -293,9 +293,11 @@ class Context:
                                                       N.ptr(ex) if len(ex) else None, N.ptr(eff)))
         return eff
 
-    def executor_fit(self, exe, reserved=None, minimal_fragmentation: bool = False, hosts=None) -> np.ndarray:
+    def executor_fit(self, exe, reserved=None, minimal_fragmentation: bool = False, hosts=None, node_zone=None,
+                     req_zone=None) -> np.ndarray:
         """One node index (GF_NO_NODE = no capacity) per executor request: rescheduleExecutor's first-fit loop, or
-        rescheduleExecutorWithMinimalFragmentation.  hosts: (n_req, n_nodes) booleans."""
+        rescheduleExecutorWithMinimalFragmentation.  hosts: (n_req, n_nodes) booleans.  node_zone (n_nodes) + req_zone (n_req,
+        GF_ANY_ZONE = anywhere): filterNodesToZone on the device (gf_executor_fit_zoned)."""
         exe = np.ascontiguousarray(exe, dtype=np.int64).reshape(-1, 3)
         r = None if reserved is None else np.ascontiguousarray(reserved, dtype=np.int64).reshape(-1, 3)
         bits = None
@@ -307,6 +309,13 @@ class Context:
             bits = np.packbits(pad.reshape(len(exe), words, 32), axis=2, bitorder="little").view("<u4").reshape(len(exe), words)
             bits = np.ascontiguousarray(bits)
         out = np.zeros(len(exe), dtype=np.uint32)
+        if node_zone is not None or req_zone is not None:  # the zone step of the executor Filter on the device
+            nz = np.ascontiguousarray(node_zone, dtype=np.uint32).reshape(-1)
+            qz = np.ascontiguousarray(req_zone, dtype=np.uint32).reshape(-1)
+            assert len(nz) == self.n_nodes and len(qz) == len(exe)
+            self._check(self._lib.gf_executor_fit_zoned(self._h, int(minimal_fragmentation), len(exe), N.ptr(exe), N.ptr(r),
+                                                        N.ptr(bits), N.ptr(nz), N.ptr(qz), N.ptr(out)))
+            return out
         self._check(self._lib.gf_executor_fit(self._h, int(minimal_fragmentation), len(exe), N.ptr(exe), N.ptr(r),
                                               N.ptr(bits), N.ptr(out)))
         return out

@@ -198,6 +198,100 @@ SelectNodeResult SparkSchedulerExtender::rescheduleExecutor(const Pod& driver, c
     return out;
 }
 
+bool filterNodesToZone(const std::vector<Node>& initialNodes, const std::string& zone, std::vector<Node>* out, std::string* err) {
+    out->clear();
+    for (const Node& node : initialNodes) {
+        auto z = node.labels.find(kLabelTopologyZone);
+        if (z == node.labels.end()) {  // resource.go:466-468
+            if (err) *err = "Could not read zone label from node, unable to make scheduling decisions based on AZ";
+            return false;
+        }
+        if (z->second == zone) out->push_back(node);
+    }
+    return true;
+}
+
+std::pair<std::string, bool> SparkSchedulerExtender::getCommonZoneForExecutorsApplication(const Pod& executor,
+                                                                                         const std::vector<Pod>& allPods,
+                                                                                         std::string* err) const {
+    if (err) err->clear();
+    auto label = executor.labels.find(common::SparkAppIDLabel);
+    if (label == executor.labels.end()) {  // :494-497
+        if (err) *err = "Executor does not have a Spark app id label, could not create label selector";
+        return {"", false};
+    }
+    std::set<std::string> azs;
+    for (const Pod& pod : allPods) {  // podLister.Pods(namespace).List(selector spark-app-id == label), :548-555
+        if (pod.Namespace != executor.Namespace) continue;
+        auto l = pod.labels.find(common::SparkAppIDLabel);
+        if (l == pod.labels.end() || l->second != label->second) continue;
+        if (pod.Phase != "Running") continue;  // filterToRunningPods, :535-545: other phases are not assigned to a node
+        const Node* node = nullptr;            // getAzsOfPods, :521-533
+        for (const Node& n : nodes)
+            if (n.Name == pod.NodeName) {
+                node = &n;
+                break;
+            }
+        if (node == nullptr) {
+            if (err) *err = "node \"" + pod.NodeName + "\" not found";  // the lister's NotFound error
+            return {"", false};
+        }
+        auto z = node->labels.find(kLabelTopologyZone);
+        if (z == node->labels.end()) {
+            if (err) *err = "Could not read zone label from node, unable to make scheduling decisions based on AZ";
+            return {"", false};
+        }
+        azs.insert(z->second);
+    }
+    if (azs.size() > 1) return {"", false};  // :511-513
+    if (azs.empty()) {                        // :514-516
+        if (err) *err = "Application has no scheduled pods, can't make scheduling decisions based on AZ";
+        return {"", false};
+    }
+    return {*azs.begin(), true};
+}
+
+SelectNodeResult SparkSchedulerExtender::rescheduleExecutor(const Pod& executor, const Pod& driver, const std::vector<Pod>& allPods,
+                                                            const std::vector<std::string>& nodeNames,
+                                                            const std::set<std::string>& nodesHostingApp, bool isExtraExecutor) {
+    SelectNodeResult out;
+    std::string err;
+    // sparkResources(driver) comes first in the reference (:599-602): its failure is failure-internal whatever the zones say
+    if (!sparkResources(driver, &err)) {
+        out.outcome = outcome::failureInternal;
+        out.error = err;
+        return out;
+    }
+    std::vector<Node> availableNodes;  // getNodes (:448-460): lister order of nodeNames, unknown names skipped
+    for (const std::string& name : nodeNames)
+        for (const Node& n : nodes)
+            if (n.Name == name) {
+                availableNodes.push_back(n);
+                break;
+            }
+    std::vector<std::string> names = nodeNames;
+    if (binpacker_.IsSingleAz && shouldScheduleDynamicallyAllocatedExecutorsInSameAZ) {  // :608
+        auto [zone, allPodsInSameAz] = getCommonZoneForExecutorsApplication(executor, allPods, &err);
+        if (!err.empty()) {  // :611-613: ("", "", err)
+            out.outcome = "";
+            out.error = err;
+            return out;
+        }
+        if (allPodsInSameAz) {  // :614-627
+            std::vector<Node> inZone;
+            if (!filterNodesToZone(availableNodes, zone, &inZone, &err)) {
+                out.outcome = outcome::failureInternal;
+                out.error = err;
+                return out;
+            }
+            availableNodes = std::move(inZone);
+            names.clear();
+            for (const Node& n : availableNodes) names.push_back(n.Name);
+        }
+    }
+    return rescheduleExecutor(driver, names, availableNodes, nodesHostingApp, isExtraExecutor);
+}
+
 bool SparkSchedulerExtender::DoesPodExceedClusterCapacity(const Pod& driver, const std::vector<Node>& availableNodes,
                                                           const NodeGroupResources& nonSchedulableOverhead, bool* served,
                                                           std::string* err) {

@@ -42,6 +42,10 @@ struct FifoConfig {  // config.FifoConfig
     std::map<std::string, int64_t> EnforceAfterPodAgeByInstanceGroup;
 };
 
+// filterNodesToZone (resource.go:462-478): the nodes whose topology.kubernetes.io/zone label equals `zone`, in order; false
+// (with the reference's message) when a node has no such label.
+bool filterNodesToZone(const std::vector<Node>& initialNodes, const std::string& zone, std::vector<Node>* out, std::string* err);
+
 ResourceReservation newResourceReservation(const std::string& driverNode, const std::vector<std::string>& executorNodes,
                                            const Pod& driver, const Resources& driverResources,
                                            const Resources& executorResources);
@@ -93,6 +97,10 @@ public:
     NodeGroupResources softReservationUsage;         // added by GetReservedResources (resourcereservations.go:258-263)
     NodeGroupResources overhead;                     // overheadComputer.GetOverhead
     int64_t nowNanos = 0;                            // time.Now()
+    // install.ShouldScheduleDynamicallyAllocatedExecutorsInSameAZ (config/config.go:33; the reference's test harness sets it,
+    // extendertest/extender_test_utils.go:135): with a single-AZ packer an executor only goes to the zone its application's
+    // running pods are in (resource.go:606-632)
+    bool shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = false;
 
     // availableNodes = nodes whose labels satisfy the driver's required node affinity; the caller passes the predicate's
     // result because affinity matching is k8s API bookkeeping (resource.go:292-298).
@@ -120,6 +128,21 @@ public:
     SelectNodeResult rescheduleExecutor(const Pod& driver, const std::vector<std::string>& nodeNames,
                                         const std::vector<Node>& availableNodes,
                                         const std::set<std::string>& nodesHostingApp, bool isExtraExecutor);
+
+    // The whole of rescheduleExecutor (resource.go:594-673) including its zone step: `executor` is the pod being filtered,
+    // `allPods` what the pod lister holds (the application's pods are selected by namespace + spark-app-id label,
+    // getSparkApplicationPodsForExecutor :548-555); availableNodes = getNodes(nodeNames) comes from `nodes` in nodeNames order
+    // (:448-460, unknown names skipped).  With a single-AZ packer and shouldScheduleDynamicallyAllocatedExecutorsInSameAZ the
+    // candidates are narrowed to the one zone (label topology.kubernetes.io/zone, quirk 7) the application's Running pods
+    // are in — BEFORE the snapshot and the sort, like the reference — and an application spread over several zones is
+    // scheduled anywhere (:628-630).  Errors are the reference's: (outcome "", error) from getCommonZone..., failure-internal
+    // from filterNodesToZone.
+    SelectNodeResult rescheduleExecutor(const Pod& executor, const Pod& driver, const std::vector<Pod>& allPods,
+                                        const std::vector<std::string>& nodeNames, const std::set<std::string>& nodesHostingApp,
+                                        bool isExtraExecutor);
+    // getCommonZoneForExecutorsApplication (resource.go:493-519): {zone, all pods in one zone}; *err set = the reference's error
+    std::pair<std::string, bool> getCommonZoneForExecutorsApplication(const Pod& executor, const std::vector<Pod>& allPods,
+                                                                      std::string* err) const;
 
     // scanForUnschedulablePods (unschedulablepods.go:93-129) as ONE independent batch: every pending driver of this
     // scheduler that is older than timeoutNanos is checked against the EMPTY cluster (the per-pod BinpackFunc calls of the

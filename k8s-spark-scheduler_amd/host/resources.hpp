@@ -24,6 +24,9 @@ constexpr const char* kResourceMemory = "memory";           // corev1.ResourceMe
 constexpr const char* kResourceNvidiaGPU = "nvidia.com/gpu";  // v1beta2.ResourceNvidiaGPU
 constexpr const char* kLabelZoneFailureDomain = "failure-domain.beta.kubernetes.io/zone";  // corev1.LabelZoneFailureDomain
 constexpr const char* kZoneLabelPlaceholder = "default";    // resources.go:26
+// corev1.LabelTopologyZone: the label the EXECUTOR path's zone filter reads (resource.go:466, :526) — not the one the bin-pack
+// snapshot reads
+constexpr const char* kLabelTopologyZone = "topology.kubernetes.io/zone";
 
 struct Resources {
     Quantity CPU, Memory, NvidiaGPU;

@@ -39,6 +39,7 @@ struct Pod {  // the fields of corev1.Pod this path reads
     std::map<std::string, std::string> Annotations;
     int64_t CreationTimestampNanos = 0;  // metav1.Time
     std::string NodeName;                // Spec.NodeName
+    std::string Phase;                   // Status.Phase ("Pending", "Running", ...): filterToRunningPods, resource.go:535-545
     std::string SchedulerName;           // Spec.SchedulerName
     bool Deleting = false;               // DeletionTimestamp != nil
     std::string InstanceGroup;           // value the pod's node affinity / selector requires for the instance-group label

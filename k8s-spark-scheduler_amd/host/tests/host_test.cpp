@@ -505,6 +505,89 @@ static void TestMinimalFragmentationEdgeCase() {  // resource_test.go:127-170
     CHECK(r.served && r.node == "node2");  // 8 - 1 - 2*2.001 < 3 although allocatable - usage - overhead = 4.999 >= 3
 }
 
+// TestDynamicAllocationScheduling, case "schedules an executor only in the same AZ as the original application"
+// (resource_test.go:262-292), through the mirror's whole rescheduleExecutor: NO hand-filtered order — the zone step
+// (getCommonZoneForExecutorsApplication + filterNodesToZone, resource.go:493-553, :606-632) narrows the candidates itself.
+static void TestDynamicAllocationSameAZ() {
+    Node node1 = NewNode("node1", "zone1"), node2 = NewNode("node2", "zone2");
+    auto ext = NewTestExtender("single-az-tightly-pack", {node1, node2});
+    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;  // extendertest/extender_test_utils.go:135
+    auto Executor = [](const char* app, int i) {
+        Pod p;
+        p.Name = std::string(app) + "-spark-exec-" + std::to_string(i);
+        p.Namespace = "namespace";
+        p.labels = {{common::SparkRoleLabel, common::Executor}, {common::SparkAppIDLabel, app}};
+        p.SchedulerName = common::SparkSchedulerName;
+        p.Phase = "Pending";
+        return p;
+    };
+    Pod staticDriver = Driver("static-allocation-app", StaticAnnotations(1));
+    Pod dynDriver = Driver("dynamic-allocation-app", DynamicAnnotations(0, 2, "1", "1", "1", "1"), 1);
+    std::vector<Pod> all = {staticDriver, Executor("static-allocation-app", 0), dynDriver, Executor("dynamic-allocation-app", 0),
+                            Executor("dynamic-allocation-app", 1)};
+    for (Pod& p : all) p.Phase = "Pending";
+    auto bind = [&](size_t i, const std::string& node) {  // what Harness.Schedule does on success (extender_test_utils.go:180-190)
+        all[i].NodeName = node;
+        all[i].Phase = "Running";
+    };
+    // "We first schedule a statically allocated application to zone1 to make it more desirable as there is less space"
+    SelectNodeResult r = ext.selectDriverNode("batch-medium-priority", all[0], {"node1"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::success) && r.node == "node1" && r.created.has_value());
+    if (r.created) ext.reservations.push_back(*r.created);
+    bind(0, "node1");
+    bind(1, "node1");  // the static executor binds to its reservation on node1 (resource.go:382-424: Go-host bookkeeping)
+    r = ext.selectDriverNode("batch-medium-priority", all[2], {"node2"}, ext.nodes);
+    CHECK(r.served && r.outcome == std::string(outcome::success) && r.node == "node2" && r.created.has_value());
+    if (r.created) ext.reservations.push_back(*r.created);
+    bind(2, "node2");
+    // executor-0 and executor-1 of the dynamic application, both nodes offered: node1 sorts first (less free memory), the
+    // application lives in zone2 — "node2" both times (expectedPodToNodeSoftReservationsMap, :289-292)
+    for (size_t i : {size_t(3), size_t(4)}) {
+        r = ext.rescheduleExecutor(all[i], all[2], all, {"node1", "node2"}, {}, true);
+        CHECK(r.served && r.outcome == std::string(outcome::successScheduledExtraExecutor) && r.node == "node2");
+        bind(i, r.node);
+        ext.softReservationUsage["node2"].Add(Resources::Create(1, 1, 0));  // the soft reservation AddReservationForPod records
+    }
+    // the same request with the flag off (or a packer that is not single-AZ) is scheduled anywhere: node1 comes first
+    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = false;
+    r = ext.rescheduleExecutor(all[4], all[2], all, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node == "node1");
+    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;
+    auto plain = NewTestExtender("tightly-pack", {node1, node2});
+    plain.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;
+    plain.reservations = ext.reservations;
+    r = plain.rescheduleExecutor(all[4], all[2], all, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node == "node1");
+    // an application whose running pods span two zones is scheduled anywhere (:628-630)
+    std::vector<Pod> spread = all;
+    spread[3].NodeName = "node1";
+    r = ext.rescheduleExecutor(all[4], all[2], spread, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node == "node1");
+    // no running pod: the reference's error, no outcome (:514-516, :611-613)
+    std::vector<Pod> none = all;
+    for (Pod& p : none) p.Phase = "Pending";
+    r = ext.rescheduleExecutor(all[4], all[2], none, {"node1", "node2"}, {}, true);
+    CHECK(r.node.empty() && r.outcome.empty() &&
+          r.error == "Application has no scheduled pods, can't make scheduling decisions based on AZ");
+    // an executor without the app id label (:494-497)
+    Pod bare = all[4];
+    bare.labels.erase(common::SparkAppIDLabel);
+    r = ext.rescheduleExecutor(bare, all[2], all, {"node1", "node2"}, {}, true);
+    CHECK(r.node.empty() && r.error == "Executor does not have a Spark app id label, could not create label selector");
+    // a candidate node without the topology label: failure-internal from filterNodesToZone (:466-468, :620-623)
+    Node bareNode = NewNode("node3", "zone2");
+    bareNode.labels.erase(kLabelTopologyZone);
+    ext.nodes.push_back(bareNode);
+    r = ext.rescheduleExecutor(all[4], all[2], all, {"node1", "node2", "node3"}, {}, true);
+    CHECK(r.node.empty() && r.outcome == std::string(outcome::failureInternal) &&
+          r.error == "Could not read zone label from node, unable to make scheduling decisions based on AZ");
+    ext.nodes.pop_back();
+    // the zone is full: failure-fit (the reference then creates a demand for that zone, :664-668 — Go-host bookkeeping)
+    ext.softReservationUsage["node2"].Add(Resources::Create(8, 1, 0));
+    r = ext.rescheduleExecutor(all[4], all[2], all, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node.empty() && r.outcome == std::string(outcome::failureFit));
+}
+
 // gf_snapshot_build (reservation replay + metadata + priority orders on the device) against the string-keyed host mirror
 // of the same reference functions (UsageForNodes, NodeSchedulingMetadataForNodes, NodeSorter.PotentialNodes), which the
 // reference's sort tests pin.
@@ -1222,6 +1305,7 @@ int main(int argc, char** argv) {
         TestSchedulerFailsToScheduleWhenNotEnoughNvidiaGPUs();
         TestFifoAndBinpackers();
         TestMinimalFragmentationEdgeCase();
+        TestDynamicAllocationSameAZ();
         TestDeviceSnapshotBuildAgainstHostMirror();
         TestIncrementalFilters();
         TestFindNodes();

@@ -59,6 +59,56 @@ def test_gpu_reference_dynamic_allocation_cases(gf_ctx):
         assert gf_ctx.executor_fit([[1000, 1, 0]]).tolist() == [want], name
 
 
+# resource_test.go:262-292 WITHOUT the hand-filtered order of T2_CASES[3]: both nodes stay in the executor order (node1 first:
+# less free memory), the zone step — on the device here, in host/extender.cpp for the whole mirror (host_test
+# TestDynamicAllocationSameAZ) — keeps the extra executors in zone2.
+T2_ZONE = dict(avail=[[6000, 8 * GIB - 2, 0], [7000, 8 * GIB - 1, 0]], order=[0, 1], node_zone=[0, 1], app_zone=1)
+
+
+def test_reference_same_az_case_is_the_filtered_order_for_the_oracle():
+    """filterNodesToZone (resource.go:462-478) happens before the sort: at the first-fit boundary the oracle sees the order
+    restricted to the zone.  Without the filter the reference's loop would answer node1."""
+    c = T2_ZONE
+    in_zone = [n for n in c["order"] if c["node_zone"][n] == c["app_zone"]]
+    assert ob.executor_fit(c["avail"], [1000, 1, 0], in_zone) == 1
+    assert ob.executor_fit(c["avail"], [1000, 1, 0], c["order"]) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_reference_same_az_case_zone_step_on_the_device(gf_ctx):
+    c = T2_ZONE
+    gf_ctx.set_snapshot(c["avail"])
+    gf_ctx.set_orders([0], c["order"])
+    exe = [[1000, 1, 0]] * 3
+    got = gf_ctx.executor_fit(exe, node_zone=c["node_zone"], req_zone=[c["app_zone"], 0, 0xFFFFFFFF])
+    assert got.tolist() == [1, 0, 0]  # zone2 -> node2 (the reference's expectation); zone1 -> node1; anywhere -> node1
+    assert gf_ctx.executor_fit(exe[:1], node_zone=c["node_zone"], req_zone=[7]).tolist() == [NO]  # an empty zone: failure-fit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 65, 700, 3000])
+def test_gpu_zone_step_matches_the_oracle_on_the_filtered_order(gf_ctx, n):
+    """gf_executor_fit_zoned against the oracle on the order restricted to the request's zone (both variants, with the
+    reserved map and the hosting hint): what filterNodesToZone leaves of a sorted order."""
+    rng = np.random.default_rng(77 + n)
+    avail, D, X, drv, exe, k = _random_problem(rng, n, 60, True, "merged")
+    gf_ctx.set_snapshot(avail)
+    gf_ctx.set_orders(D, X)
+    node_zone = rng.integers(0, 4, size=n).astype(np.uint32)
+    req_zone = rng.integers(0, 5, size=len(exe)).astype(np.uint32)  # zone 4 has no node
+    req_zone[rng.random(len(exe)) < 0.2] = 0xFFFFFFFF
+    reserved = rng.integers(0, 4, size=(n, 3)).astype(np.int64) * (rng.random((n, 1)) < 0.3)
+    hosts = rng.random((len(exe), n)) < 0.05
+    for res in (None, reserved):
+        def order_of(q):
+            return X if req_zone[q] == 0xFFFFFFFF else [x for x in X if node_zone[x] == req_zone[q]]
+        got = gf_ctx.executor_fit(exe, reserved=res, node_zone=node_zone, req_zone=req_zone)
+        assert got.tolist() == [ob.executor_fit(avail, e, order_of(q), reserved=res) for q, e in enumerate(exe)]
+        got = gf_ctx.executor_fit(exe, reserved=res, minimal_fragmentation=True, hosts=hosts, node_zone=node_zone, req_zone=req_zone)
+        assert got.tolist() == [ob.executor_fit(avail, e, order_of(q), reserved=res, minimal_fragmentation=True, hosts=hosts[q])
+                                for q, e in enumerate(exe)]
+
+
 def test_oracle_edge_cases():
     avail = [[1, 1, 0], [5, 5, 0], [9, 9, 1]]
     assert ob.executor_fit(avail, [2, 2, 0], [0, 1, 2]) == 1

@@ -38,7 +38,8 @@ run_group() {  # <prefix> <timeout> <command...>: stats + the four counter passe
 for g in $GROUPS_; do
   case $g in
     headline)
-      run_group hl 300 python $ROOT/bench.py --headline-only --steps 200 --warmup 5 --windows 3 ${BENCH_ARGS:-}
+      run_group hl20 300 python $ROOT/bench.py --headline-only --steps 20 --warmup 5 ${BENCH_ARGS:-}
+      run_group hl 300 python $ROOT/bench.py --headline-only ${BENCH_ARGS:-}
       ;;
     chain)
       run_group chain 300 python $ROOT/bench.py --steps 20 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline --no-extras --fifo-protocols cold --worker-sets 0

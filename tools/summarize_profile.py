@@ -70,6 +70,23 @@ def _derive(mean, div=1.0):
     return out
 
 
+def _med(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def _durations(trace_csv, name):
+    """End - Start of every dispatch of kernels whose name starts with `name`, in launch order (rocprofv3 --kernel-trace CSV)."""
+    if not os.path.exists(trace_csv):
+        return []
+    out = []
+    for r in csv.DictReader(open(trace_csv)):
+        if r.get("Kernel_Name", "").startswith(name):
+            out.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return [float(d) for _, d in sorted(out)]
+
+
 def _stats_table(path, want):
     md = "| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n"
     for r in csv.DictReader(open(path)):
@@ -103,43 +120,99 @@ def main():
             for c, v in cs.items():
                 pmc_csv.append([pre, k, c, len(v), f"{sum(v) / len(v):.3f}", f"{min(v):.3f}", f"{max(v):.3f}"])
 
-    # ---- the headline, both regimes
-    per = _group_means(src, "hl")
-    hstats = os.path.join(src, "hl_stats", "stats_kernel_stats.csv")
-    if per or os.path.exists(hstats):
-        dump_group("headline", per)
-        bj = _bench_json(os.path.join(src, "hl_stats.log")) or {}
-        steps = int(bj.get("steps") or 200)
-        hj = {"tag": tag, "command": "bench.py --headline-only --steps 200 --warmup 5 --windows 3",
-              "note": "per STEP (one 1 000-application batch); hbm_bytes = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB; "
-                      "l2_request_bytes = (TCC_HIT_sum + TCC_MISS_sum) x 128; instructions = SQ_INSTS_VALU + SALU + LDS + SMEM"}
+    # ---- the headline, both regimes, at the driver's command (K = 20) and at bench.py's default (K = 2 000)
+    runs = collections.OrderedDict()
+    for pre, cmd in (("hl20", "bench.py --headline-only --steps 20 --warmup 5   (the driver's `--steps 20 --warmup 5`, headline leg only)"),
+                     ("hl", "bench.py --headline-only   (bench.py's defaults: --steps 2000 --warmup 50)")):
+        per = _group_means(src, pre)
+        hstats = os.path.join(src, f"{pre}_stats", "stats_kernel_stats.csv")
+        if not per and not os.path.exists(hstats):
+            continue
+        dump_group(pre, per)
+        bj = _bench_json(os.path.join(src, f"{pre}_stats.log")) or {}
+        steps = int(bj.get("steps") or (20 if pre == "hl20" else 2000))
+        hj = {"command": cmd, "steps": steps}
         if "fit_independent_kernel" in per:
             mean = {c: sum(v) / len(v) for c, v in per["fit_independent_kernel"].items()}
             hj["launch_path"] = dict(_derive(mean, 1.0), kernel="fit_independent_kernel<tightly-pack>", steps_per_dispatch=1,
-                                     dispatches=len(next(iter(per["fit_independent_kernel"].values()))))
+                                     dispatches=len(next(iter(per["fit_independent_kernel"].values()))), statistic="mean over the dispatches")
         if "fit_worker_kernel" in per:
-            mean = {c: sum(v) / len(v) for c, v in per["fit_worker_kernel"].items()}
-            hj["worker"] = dict(_derive(mean, float(steps)), kernel="fit_worker_kernel<tightly-pack>", steps_per_dispatch=steps,
-                                dispatches=len(next(iter(per["fit_worker_kernel"].values()))),
+            # every dispatch serves one window's K tickets; the MEDIAN over the dispatches (warm-up windows and the first, cold
+            # one are among them: the mean is theirs)
+            med = {c: _med(v) for c, v in per["fit_worker_kernel"].items()}
+            hj["worker"] = dict(_derive(med, float(steps)), kernel="fit_worker_kernel<tightly-pack>", steps_per_dispatch=steps,
+                                dispatches=len(next(iter(per["fit_worker_kernel"].values()))), statistic="median over the dispatches",
                                 note="one dispatch serves the K tickets of a window (launch and departure included); its "
                                      "instruction and L2 counts include the polling of idle workgroups")
         if os.path.exists(hstats):
-            shutil.copy(hstats, os.path.join(dst, f"{tag}_kernel_stats_headline.csv"))
+            shutil.copy(hstats, os.path.join(dst, f"{tag}_kernel_stats_headline_steps{steps}.csv"))
+            trace = os.path.join(src, f"{pre}_stats", "stats_kernel_trace.csv")
             a, n = _avg_ns(hstats, "fit_independent_kernel")
+            d = _durations(trace, "fit_independent_kernel")
             if a and "launch_path" in hj:
                 hj["launch_path"]["rocprof_avg_dispatch_ns"], hj["launch_path"]["rocprof_dispatches"] = a, n
+                if d:
+                    hj["launch_path"]["rocprof_median_dispatch_ns"], hj["launch_path"]["rocprof_min_dispatch_ns"] = _med(d), min(d)
+                lp = hj["launch_path"]
+                t = (lp.get("rocprof_median_dispatch_ns") or a) * 1e-9
+                lp["fractions_over_own_duration"] = {k: v for k, v in (
+                    ("hbm", lp["hbm_bytes"] / t / 8e12 if lp.get("hbm_bytes") is not None else None),
+                    ("l2", lp["l2_request_bytes"] / t / 34.5e12 if lp.get("l2_request_bytes") is not None else None),
+                    ("issue", lp["instructions"] / t / (1024 * 2.4e9) if lp.get("instructions") is not None else None)) if v is not None}
             a, n = _avg_ns(hstats, "fit_worker_kernel")
+            d = _durations(trace, "fit_worker_kernel")
             if a and "worker" in hj:
-                hj["worker"]["rocprof_avg_dispatch_ns"], hj["worker"]["rocprof_dispatches"] = a, n
-                hj["worker"]["rocprof_ns_per_ticket"] = a / steps
-            md += ("## the headline, both regimes (`bench.py --headline-only --steps 200`)\n\nEvery `fit_independent_kernel` dispatch is "
-                   "one headline batch (launch path); every `fit_worker_kernel` dispatch serves one window's 200 tickets.\n\n" +
+                wk = hj["worker"]
+                wk["rocprof_avg_dispatch_ns"], wk["rocprof_dispatches"] = a, n
+                if d:
+                    wk["rocprof_dispatch_ns"] = d
+                    wk["rocprof_median_dispatch_ns"], wk["rocprof_min_dispatch_ns"], wk["rocprof_max_dispatch_ns"] = _med(d), min(d), max(d)
+                ref = _med(d) if d else a
+                wk["rocprof_ns_per_ticket"] = ref / steps
+                wk["rocprof_ns_per_ticket_is"] = "median dispatch duration / K" if d else "average dispatch duration / K"
+                if d:
+                    wk["rocprof_min_ns_per_ticket"] = min(d) / steps
+                # the fractions a reader gets from THIS file alone: the profile's counters over the profile's own duration
+                t = wk["rocprof_ns_per_ticket"] * 1e-9
+                own = {}
+                if wk.get("hbm_bytes") is not None:
+                    own["hbm"] = wk["hbm_bytes"] / t / 8e12
+                if wk.get("l2_request_bytes") is not None:
+                    own["l2"] = wk["l2_request_bytes"] / t / 34.5e12
+                if wk.get("instructions") is not None:
+                    own["issue"] = wk["instructions"] / t / (1024 * 2.4e9)
+                wk["fractions_over_own_duration"] = own
+                # the traced run's own line: the kernel cannot take longer per ticket than a step of the window it served
+                if bj.get("ms_per_step") and (bj.get("config") or {}).get("regime", "").startswith("streamed"):
+                    wk["traced_run_ms_per_step"] = bj["ms_per_step"]
+                    wk["traced_run_kernel_ms"] = (bj.get("roofline") or {}).get("kernel_ms")
+                    wk["ns_per_ticket_le_ms_per_step"] = bool(wk["rocprof_ns_per_ticket"] <= bj["ms_per_step"] * 1e6 * 1.02)
+                    assert wk["ns_per_ticket_le_ms_per_step"], (
+                        f"{pre}: rocprofv3's median fit_worker_kernel dispatch / K = {wk['rocprof_ns_per_ticket']:.0f} ns per ticket exceeds the "
+                        f"traced run's own ms_per_step = {bj['ms_per_step'] * 1e6:.0f} ns: the profile does not describe the line's kernel")
+            md += (f"## the headline, both regimes (`{cmd}`)\n\nEvery `fit_independent_kernel` dispatch is "
+                   f"one headline batch (launch path); every `fit_worker_kernel` dispatch serves one window's {steps} tickets.\n\n" +
                    _stats_table(hstats, ("fit_independent", "fit_worker", "empty_kernel")) + "\n")
+            if d:
+                md += (f"`fit_worker_kernel` dispatches (ns, launch order): {', '.join(str(int(x)) for x in d)} — median {_med(d):.0f}, "
+                       f"min {min(d):.0f} = {_med(d) / steps:.0f} / {min(d) / steps:.0f} ns per ticket\n\n")
             if bj:
                 rf = bj.get("roofline") or {}
                 md += (f"bench line of that (traced) run: value {bj.get('value', 0) / 1e6:.1f} M decisions/s, "
                        f"{bj.get('ms_per_step', 0) * 1e3:.2f} us per step, roofline.kernel {rf.get('kernel')} "
                        f"kernel_ms {rf.get('kernel_ms')}\n\n")
+        runs[f"steps{steps}"] = hj
+    if runs:
+        first = next(iter(runs.values()))
+        hj = {"tag": tag,
+              "note": "per STEP (one 1 000-application batch); hbm_bytes = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB; "
+                      "l2_request_bytes = (TCC_HIT_sum + TCC_MISS_sum) x 128; instructions = SQ_INSTS_VALU + SALU + LDS + SMEM.  `runs` "
+                      "holds one entry per profiled command (bench.py picks the one with its own --steps); the top-level launch_path / "
+                      "worker repeat the driver's command (steps20).",
+              "command": first["command"], "runs": runs}
+        for k in ("launch_path", "worker"):
+            if k in first:
+                hj[k] = first[k]
         json.dump(hj, open(os.path.join(dst, "pmc_headline.json"), "w"), indent=1)
         md += "```json\n" + json.dumps(hj, indent=1) + "\n```\n\n"
 
