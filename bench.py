@@ -300,6 +300,10 @@ def _r(x, digits=6):
     """Numbers of the line with `digits` significant digits (the full precision is in bench_full.json)."""
     if isinstance(x, bool) or x is None:
         return x
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
     if isinstance(x, float):
         return float(f"{x:.{digits}g}")
     return x
@@ -1144,8 +1148,20 @@ def main():
                     t = torch.tensor([wall_s], dtype=torch.float64, device=dev)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     wall_s = float(t.item())
+                # the three data-path exchanges of a batch, device time (events on the engine's stream), median of five batches
+                try:
+                    ex = [sb.step_timed() for _ in range(5)]
+                    exchange_us = [_median([e[i] for e in ex]) for i in range(3)]
+                except Exception:
+                    exchange_us = None
+                feas = None
+                try:
+                    feas = float(sb.fetch().results["has_capacity"].mean())
+                except Exception:
+                    pass
                 return {"decisions_per_s": sb.n_apps * steps / wall_s, "ms_per_batch": wall_s / steps * 1e3,
                         "apps": sb.n_apps, "nodes": len(wk.snapshot.avail), "n_shards": world, "steps": steps,
+                        "feasible_fraction": feas, "exchange_us": exchange_us,
                         "collectives_per_batch": "2 all-gather (16 B/app) + 1 all-reduce (4 B/executor)"}
 
             node_sharded = {"headline": time_sharded(ctx, base, max(10, min(args.steps, 200) // 4), 5)}
@@ -1155,6 +1171,23 @@ def main():
             ctx4.set_snapshot(w4.snapshot.avail, w4.snapshot.sched)
             ctx4.set_orders(w4.snapshot.driver_order, w4.snapshot.exec_order)
             node_sharded["config4_50k_nodes_x_10k_apps"] = time_sharded(ctx4, w4, 10, 2)
+            # The same size on a nearly full cluster (usage U[0.93, 1]: the variant tests/test_gpu_fullsize.py checks against the
+            # oracle): most gangs need the whole executor order — infeasible ones a full scan — so that every shard has work.  On the
+            # nominal cluster tightly-pack drains the FRONT of the order: the first range does the scanning and sharding can only
+            # cost.  This is the leg the contract line carries on N > 1 (config.node_sharded).
+            w4c = wl.Workload("C4 congested", wl.make_snapshot(50000, 0x5EED0004, 0.93, 1.0), w4.drv, w4.exe, w4.k, w4.k_max, w4.flags)
+            ctx4.set_snapshot(w4c.snapshot.avail, w4c.snapshot.sched)
+            ctx4.set_orders(w4c.snapshot.driver_order, w4c.snapshot.exec_order)
+            node_sharded["config4_congested_50k_nodes_x_10k_apps"] = time_sharded(ctx4, w4c, 10, 2)
+            c4c = node_sharded["config4_congested_50k_nodes_x_10k_apps"]
+            out["config"]["node_sharded"] = {
+                "workload": "config 4 congested, 50k nodes x 10k apps, node-range shards", "n_shards": world,
+                "ms_per_batch": c4c["ms_per_batch"], "exchange_us": c4c["exchange_us"], "feasible_fraction": c4c["feasible_fraction"],
+                # ranks of the DATA-path collectives (two all-gathers + one all-reduce per batch), not of the timing barrier
+                "rccl_ranks": (dist.get_world_size() if (dist is not None and backend == "nccl") else 0),
+                "nominal_ms_per_batch": node_sharded["config4_50k_nodes_x_10k_apps"]["ms_per_batch"]}
+            ctx4.set_snapshot(w4.snapshot.avail, w4.snapshot.sched)
+            ctx4.set_orders(w4.snapshot.driver_order, w4.snapshot.exec_order)
             if world == 1:  # the unsharded kernel on the same table, for the cost of the four-step path itself
                 a4, k4 = gangfit.with_offsets(gangfit.make_apps(w4.drv, w4.exe, w4.k, w4.flags))
                 d_a4 = torch.from_numpy(a4.view(np.uint8).copy()).to(dev)
@@ -1168,6 +1201,19 @@ def main():
                     ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
                 torch.cuda.synchronize()
                 node_sharded["config4_unsharded_one_gpu_decisions_per_s"] = len(a4) * 10 / (time.perf_counter() - t0)
+                ctx4.set_snapshot(w4c.snapshot.avail, w4c.snapshot.sched)
+                ctx4.set_orders(w4c.snapshot.driver_order, w4c.snapshot.exec_order)
+                for _ in range(2):
+                    ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    ctx4.fit_batch_dev(IND, TIGHT, len(a4), d_a4.data_ptr(), d_r4.data_ptr(), d_e4.data_ptr(), k4, stream=stream)
+                torch.cuda.synchronize()
+                node_sharded["config4_congested_unsharded_one_gpu_ms_per_batch"] = (time.perf_counter() - t0) / 5 * 1e3
+                out["config"]["node_sharded"]["unsharded_one_gpu_ms_per_batch"] = node_sharded["config4_congested_unsharded_one_gpu_ms_per_batch"]
+                ctx4.set_snapshot(w4.snapshot.avail, w4.snapshot.sched)
+                ctx4.set_orders(w4.snapshot.driver_order, w4.snapshot.exec_order)
                 # the dynamic-allocation tail of config 4: (max - min) single-executor first fits for 10 % of the apps
                 # (rescheduleExecutor's loop, resource.go:658-662), as independent requests against the same snapshot
                 extra = np.repeat(w4.exe[::10], np.maximum(w4.k_max[::10] - w4.k[::10], 0), axis=0)

@@ -188,7 +188,7 @@ struct WorkerArgs {
 };
 
 hipError_t worker_blocks_per_cu(gf_algo algo, int* out);
-// One launch: 1 + sets * blocks_per_set workgroups of four wavefronts.
+// One launch: 1 + sets * blocks_per_set workgroups of sixteen wavefronts.
 hipError_t launch_fit_worker(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const WorkerArgs& args,
                              hipStream_t stream);
 

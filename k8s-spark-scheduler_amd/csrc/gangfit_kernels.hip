@@ -385,11 +385,23 @@ struct Orders {
 
 // Lane `lane` owns a run of t copies of `id` starting at out[start].  Short runs: per-lane loop.  Long runs are
 // written cooperatively by all 64 lanes (coalesced) so that one huge node cannot serialise the wave.
-__device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t start, int32_t t, uint32_t id, int lane) {
+// wt (wave-uniform; constant false everywhere but in the resident worker): the placements leave as write-through
+// (system-scope) stores — the destination is read by someone else while this kernel is still running.
+__device__ __forceinline__ void put_out(uint32_t* __restrict__ p, uint32_t v, bool wt) {
+#if defined(GF_WK_NOSTORE) && GF_WK_NOSTORE
+    if (wt) return;  // (measurement build of the worker: see gangfit_worker.inc)
+#endif
+    if (wt)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+        *p = v;
+}
+__device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t start, int32_t t, uint32_t id, int lane,
+                                          const bool wt = false) {
     constexpr int32_t kLong = 16;
     uint64_t long_mask = __ballot(t > kLong);
     if (t > 0 && t <= kLong) {
-        for (int32_t i = 0; i < t; ++i) out[start + i] = id;
+        for (int32_t i = 0; i < t; ++i) put_out(out + start + i, id, wt);
     }
     while (long_mask) {
         const int src = __ffsll((unsigned long long)long_mask) - 1;
@@ -397,7 +409,7 @@ __device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t st
         const int64_t s = read_lane(start, src);
         const int32_t n = read_lane(t, src);
         const uint32_t v = read_lane(id, src);
-        for (int32_t i = lane; i < n; i += kWave) out[s + i] = v;
+        for (int32_t i = lane; i < n; i += kWave) put_out(out + s + i, v, wt);
     }
 }
 
@@ -559,7 +571,8 @@ struct ScanPre {
 template <class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& O, const App& app, uint32_t ds,
                                                    uint32_t* __restrict__ out, int lane,
-                                                   unsigned long long& visited, const ScanPre& pre = ScanPre()) {
+                                                   unsigned long long& visited, const ScanPre& pre = ScanPre(),
+                                                   const bool wt = false) {
     const int64_t K = app.k;
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;
     int64_t taken = 0;
@@ -608,7 +621,7 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
                 const int64_t room = K - start;
                 const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
                 const uint32_t id = SLOTS ? j : node;
-                emit_runs(out, start, t, id, lane);
+                emit_runs(out, start, t, id, lane, wt);
             }
             taken += tot;
             if (taken >= K) return taken;
@@ -629,7 +642,8 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
 template <class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const Orders& O, const App& app, uint32_t ds,
                                                            uint32_t* __restrict__ out, int lane,
-                                                           unsigned long long& visited, const ScanPre& pre = ScanPre()) {
+                                                           unsigned long long& visited, const ScanPre& pre = ScanPre(),
+                                                           const bool wt = false) {
     constexpr uint32_t kDenseLanes = 20;
     const int64_t K = app.k;
     const uint32_t xc = (O.n_x + kWave - 1) / kWave;
@@ -646,7 +660,7 @@ __device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const 
         const int64_t start = taken + (int64_t)(incl - cp);
         const int64_t room = K - start;
         const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
-        emit_runs(out, start, t, id, lane);
+        emit_runs(out, start, t, id, lane, wt);
         taken += tot;
         return taken >= K;
     };
@@ -878,12 +892,12 @@ template <int ALGO, class View, bool SLOTS>
 __device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, const App& app, uint32_t ds,
                                              uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
                                              uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
-                                             unsigned long long& xvis, const ScanPre& pre = ScanPre()) {
-    if (ALGO == GF_ALGO_TIGHTLY_PACK) {
+                                             unsigned long long& xvis, const ScanPre& pre = ScanPre(), const bool wt = false) {
+    if (ALGO == GF_ALGO_TIGHTLY_PACK) {  // (wt: tightly-pack only — the other packers' callers never set it)
         if constexpr (HasCompactScan<View>::value)
-            return wave_tight_scan_compact<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre);
+            return wave_tight_scan_compact<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre, wt);
         else
-            return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre);
+            return wave_tight_scan<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre, wt);
     }
     if (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) return wave_minfrag<View, SLOTS>(V, O, app, ds, out, lane, xvis);
     pass1 = wave_even_pass1<View, SLOTS>(V, O, app, ds, out, scratch_a, lane, xvis, pre);
@@ -898,7 +912,8 @@ template <int ALGO, class View, bool SLOTS>
 __device__ __forceinline__ Decision wave_fallback(const View& V, const Orders& O, const App& app, int64_t p0,
                                                   uint32_t ds0, int64_t S_d, uint32_t* __restrict__ out,
                                                   uint32_t* __restrict__ scratch_a, uint32_t* __restrict__ scratch_b,
-                                                  int lane, unsigned long long& xvis, unsigned long long& dvis) {
+                                                  int lane, unsigned long long& xvis, unsigned long long& dvis,
+                                                  const bool wt = false) {
     Decision dec;
     dec.feasible = false;
     dec.ds = ds0;
@@ -915,7 +930,7 @@ __device__ __forceinline__ Decision wave_fallback(const View& V, const Orders& O
     if (p1 < 0) return dec;
     const uint32_t ds = O.driver_slot((uint32_t)p1);
     int64_t pass1 = 0;
-    const int64_t S1 = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis);
+    const int64_t S1 = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis, ScanPre(), wt);
     dec.feasible = S1 >= K;  // always true here; kept as a guard so a logic error shows up as a parity failure
     dec.ds = ds;
     dec.pass1 = pass1;
@@ -928,7 +943,7 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ scratch_a,
                                                 uint32_t* __restrict__ scratch_b, int lane, unsigned long long& xvis,
                                                 unsigned long long& dvis, const Group0* g0p = nullptr,
-                                                const SparseTable* gpu_view = nullptr) {
+                                                const SparseTable* gpu_view = nullptr, const bool wt = false) {
     Decision dec;
     dec.feasible = false;
     dec.ds = 0;
@@ -1019,7 +1034,7 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
                                 gpu_view->n_chunks};
             const Orders OS{gpu_view->slot_node, nullptr, gpu_view->n_x, 0u, true};
             const int64_t S_s = wave_pack<ALGO, GlobalView, false>(VS, OS, app, p0_sub, out, scratch_a, scratch_b, lane, pass1,
-                                                                   xvis, ScanPre());
+                                                                   xvis, ScanPre(), wt);
             if (S_s >= K) {
                 dec.feasible = true;
                 dec.pass1 = pass1;
@@ -1039,14 +1054,14 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
     }
     // (2) executors with the driver reserved on that candidate — the common case ends here
     pass1 = 0;
-    const int64_t S_d = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis, pre);
+    const int64_t S_d = wave_pack<ALGO, View, SLOTS>(V, O, app, ds, out, scratch_a, scratch_b, lane, pass1, xvis, pre, wt);
     if (S_d >= K) {
         dec.feasible = true;
         dec.pass1 = pass1;
         return dec;
     }
     // (3) rare: the first candidate's node is where the executors were needed
-    return wave_fallback<ALGO, View, SLOTS>(V, O, app, p0, ds, S_d, out, scratch_a, scratch_b, lane, xvis, dvis);
+    return wave_fallback<ALGO, View, SLOTS>(V, O, app, p0, ds, S_d, out, scratch_a, scratch_b, lane, xvis, dvis, wt);
 }
 
 // sparkResourceUsage + SubtractUsageIfExists (internal/extender/sparkpods.go:139-146, LIB/resources/resources.go:129-135)
@@ -1781,6 +1796,25 @@ __global__ __launch_bounds__(kWave) void selftest_kernel(uint64_t seed, uint32_t
 // ------------------------------------------------------------------------------------------------ launchers
 
 // Workgroups of the worker kernel one CU holds at a time (what the runtime reports; the caller keeps a margin).
+namespace {
+// hipFuncAttributeMaxDynamicSharedMemorySize is per kernel and per device and only ever needs raising: the runtime call is
+// made when a launch asks for more than any launch before it (one call less per chain otherwise).
+hipError_t raise_dynamic_lds(const void* kernel, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> raised;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = raised[{kernel, dev}];
+    if (lds <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have = lds;
+    return e;
+}
+
+}  // namespace
+
 hipError_t worker_blocks_per_cu(gf_algo algo, int* out) {
     const int threads = kWave * kWorkerWaves;
     if (algo == GF_ALGO_TIGHTLY_PACK)
@@ -1852,22 +1886,6 @@ size_t fifo_solo_lds_bytes(uint32_t lds_slots, uint32_t n_chunks) {
 }
 
 namespace {
-// hipFuncAttributeMaxDynamicSharedMemorySize is per kernel and per device and only ever needs raising: the runtime call is
-// made when a launch asks for more than any launch before it (one call less per chain otherwise).
-hipError_t raise_dynamic_lds(const void* kernel, size_t lds) {
-    static std::mutex mu;
-    static std::map<std::pair<const void*, int>, size_t> raised;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lock(mu);
-    size_t& have = raised[{kernel, dev}];
-    if (lds <= have) return hipSuccess;
-    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) have = lds;
-    return e;
-}
-
 template <class Kernel, class... Args>
 hipError_t launch_one_workgroup(Kernel kernel, int n_waves, size_t lds, hipStream_t stream, Args... args) {
     const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kernel), lds);

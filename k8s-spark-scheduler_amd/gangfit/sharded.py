@@ -16,7 +16,7 @@ for the headline size the throughput path is app sharding with no collective (be
 
 This file is orchestration only: no arithmetic on placements happens in Python, and there is no CPU fallback —
 `HipShardEngine` raises when libgangfit or the GPU is missing.  `Comm`/engine are small interfaces so that the N > 1 control
-flow is also exercised on CPU (tests/test_sharded_gloo.py: world_size-2 gloo with a numpy engine from tests/).
+flow is also exercised on CPU (tests/test_sharded_cpu.py: world_size-2 gloo with a numpy engine from tests/).
 """
 from __future__ import annotations
 
@@ -219,6 +219,31 @@ class ShardedBatch:
             self.res, self.exec2 = e.emit(algo, self.d_apps, n, all_part, all_drv, self.half)
             c.all_reduce_sum_(self.exec2)
             e.finish(algo, self.d_apps, n, all_part, all_drv, self.res, self.exec2, self.half)
+
+    def step_timed(self):
+        """step(), with a pair of events on the engine's stream around each of the three exchanges (GPU engines only).  Returns
+        [all-gather of the partials, all-gather of the drivers, all-reduce of the placements] in microseconds of device time —
+        what the data-path collectives of one batch cost (bench.py: config.node_sharded.exchange_us)."""
+        import torch
+
+        e, c, algo, n = self.engine, self.comm, self.algo, self.n_apps
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        with e.stream_context():
+            part = e.partials(algo, self.d_apps, n)
+            ev[0].record(e.stream)
+            all_part = c.all_gather(part)
+            ev[1].record(e.stream)
+            drv = e.drivers(algo, self.d_apps, n, all_part)
+            ev[2].record(e.stream)
+            all_drv = c.all_gather(drv)
+            ev[3].record(e.stream)
+            self.res, self.exec2 = e.emit(algo, self.d_apps, n, all_part, all_drv, self.half)
+            ev[4].record(e.stream)
+            c.all_reduce_sum_(self.exec2)
+            ev[5].record(e.stream)
+            e.finish(algo, self.d_apps, n, all_part, all_drv, self.res, self.exec2, self.half)
+        e.stream.synchronize()
+        return [ev[2 * i].elapsed_time(ev[2 * i + 1]) * 1e3 for i in range(3)]
 
     def fetch(self) -> BatchOut:
         with self.engine.stream_context():

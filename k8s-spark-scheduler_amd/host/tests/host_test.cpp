@@ -540,29 +540,31 @@ static void TestDynamicAllocationSameAZ() {
     CHECK(r.served && r.outcome == std::string(outcome::success) && r.node == "node2" && r.created.has_value());
     if (r.created) ext.reservations.push_back(*r.created);
     bind(2, "node2");
-    // executor-0 and executor-1 of the dynamic application, both nodes offered: node1 sorts first (less free memory), the
-    // application lives in zone2 — "node2" both times (expectedPodToNodeSoftReservationsMap, :289-292)
+    // Before any soft reservation exists node1 sorts first (less free memory: 8 GiB - 2 against 8 GiB - 1).  The same request
+    // with the flag off, or with a packer that is not single-AZ, is scheduled anywhere — node1:
+    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = false;
+    r = ext.rescheduleExecutor(all[3], all[2], all, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node == "node1");
+    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;
+    auto plain = NewTestExtender("tightly-pack", {node1, node2});
+    plain.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;
+    plain.reservations = ext.reservations;
+    r = plain.rescheduleExecutor(all[3], all[2], all, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node == "node1");
+    // ... and so is an application whose running pods span two zones (:628-630)
+    std::vector<Pod> spread = all;
+    spread[3].NodeName = "node1";
+    spread[3].Phase = "Running";
+    r = ext.rescheduleExecutor(all[4], all[2], spread, {"node1", "node2"}, {}, true);
+    CHECK(r.served && r.node == "node1");
+    // executor-0 and executor-1 of the dynamic application, both nodes offered: the application lives in zone2 — "node2" both
+    // times (expectedPodToNodeSoftReservationsMap, :289-292)
     for (size_t i : {size_t(3), size_t(4)}) {
         r = ext.rescheduleExecutor(all[i], all[2], all, {"node1", "node2"}, {}, true);
         CHECK(r.served && r.outcome == std::string(outcome::successScheduledExtraExecutor) && r.node == "node2");
         bind(i, r.node);
         ext.softReservationUsage["node2"].Add(Resources::Create(1, 1, 0));  // the soft reservation AddReservationForPod records
     }
-    // the same request with the flag off (or a packer that is not single-AZ) is scheduled anywhere: node1 comes first
-    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = false;
-    r = ext.rescheduleExecutor(all[4], all[2], all, {"node1", "node2"}, {}, true);
-    CHECK(r.served && r.node == "node1");
-    ext.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;
-    auto plain = NewTestExtender("tightly-pack", {node1, node2});
-    plain.shouldScheduleDynamicallyAllocatedExecutorsInSameAZ = true;
-    plain.reservations = ext.reservations;
-    r = plain.rescheduleExecutor(all[4], all[2], all, {"node1", "node2"}, {}, true);
-    CHECK(r.served && r.node == "node1");
-    // an application whose running pods span two zones is scheduled anywhere (:628-630)
-    std::vector<Pod> spread = all;
-    spread[3].NodeName = "node1";
-    r = ext.rescheduleExecutor(all[4], all[2], spread, {"node1", "node2"}, {}, true);
-    CHECK(r.served && r.node == "node1");
     // no running pod: the reference's error, no outcome (:514-516, :611-613)
     std::vector<Pod> none = all;
     for (Pod& p : none) p.Phase = "Pending";

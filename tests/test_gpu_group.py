@@ -44,6 +44,46 @@ def test_group_matches_oracle(algo, n_dev, n, split):
                 _assert_same(g.fit_batch(IND, algo, apps), ref, apps)
 
 
+def _device_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("exchange", ["peer_stores", "rccl"])
+@pytest.mark.parametrize("algo", [0, 1])
+def test_group_over_distinct_devices(algo, exchange):
+    """The same context over DISTINCT device ids — the first box with two GPUs exercises hipDeviceEnablePeerAccess, the posted peer
+    stores into every device's gathered table and the pull of the placements (csrc/gangfit_api_group.cpp), and, exchange = rccl,
+    ncclCommInitAll over more than one rank.  One-GPU boxes skip it (what they can run is the repeated-id form above).  A topology
+    without peer access degrades to the first device (shard_count 1): still the oracle's answers, and the test says which it saw."""
+    n_dev = _device_count()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} visible GPU(s): distinct device ids need two")
+    ids = list(range(min(n_dev, 8)))
+    rng = np.random.default_rng(777 + algo)
+    with gangfit.Context(devices=ids) as g:
+        sharded = g.shard_count() == len(ids)
+        assert sharded or g.shard_count() == 1  # degraded: no peer access between some pair (gf_last_error says which)
+        if exchange == "rccl":
+            try:
+                g.set_option("group_exchange", 1)
+            except gangfit.GangfitError as e:
+                pytest.skip(f"RCCL exchange unavailable here: {e}")
+        for n in (130, 5000):
+            for layout in ("merged", "identical"):
+                avail, D, X, drv, exe, k = _random_problem(rng, n, 200, n == 130, layout)
+                g.set_snapshot(avail)
+                g.set_orders(D, X)
+                apps = gangfit.make_apps(drv, exe, k)
+                ref = ob.fit_independent(algo, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True)
+                _assert_same(g.fit_batch(IND, algo, apps), ref, apps)
+                _assert_same(g.fit_batch(IND, algo, apps), ref, apps)  # the second batch on a snapshot runs without the self-check
+        assert g.shard_count() in (1, len(ids)), "the self-check of a sharded batch failed on distinct devices"
+        if sharded:
+            assert g.shard_count() == len(ids), "the context stopped sharding: its first sharded batch disagreed with one device"
+
+
 def test_group_general_layout_and_other_modes_run_on_the_first_device():
     rng = np.random.default_rng(99)
     avail, D, X, drv, exe, k = _random_problem(rng, 300, 60, True, "general")

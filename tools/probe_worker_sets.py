@@ -28,7 +28,8 @@ def med(x):
 
 ref = None
 for sets, bps in configs:
-    ctx = gangfit.Context(0, options={"worker_sets": sets, "worker_blocks_per_set": bps})
+    opts = {"worker_sets": sets, "worker_blocks_per_set": bps}
+    ctx = gangfit.Context(0, options=opts)
     ctx.set_snapshot(s.avail, s.sched)
     ctx.set_orders(s.driver_order, s.exec_order)
     line = f"sets {sets:2d} x {bps:2d} workgroups ({1 + sets * bps:3d} CUs)"
@@ -49,7 +50,10 @@ for sets, bps in configs:
                     kern.append(ms / n * 1e3)
         line += f" | K {K:4d}: {med(walls) * 1e6:8.1f} us = {med(walls) / K * 1e6:5.2f} us/ticket {len(apps) * K / med(walls) / 1e6:6.1f} M/s, kernel {med(kern) if kern else float('nan'):5.2f} us/ticket"
     res = (outs[0][0].cpu().numpy().tobytes(), outs[0][1].cpu().numpy().tobytes())
-    if ref is None:
-        ref = res
-    print(line + f" | answers == first config: {res == ref}", flush=True)
+    if ref is None:  # the launch path's answer (fit_independent_kernel) on the same batch
+        l_res, l_exec = torch.zeros_like(outs[0][0]), torch.zeros_like(outs[0][1])
+        ctx.fit_batch_dev(gangfit.GF_MODE_INDEPENDENT, TIGHT, len(apps), d_apps.data_ptr(), l_res.data_ptr(), l_exec.data_ptr(), total_k, stream=0)
+        torch.cuda.synchronize()
+        ref = (l_res.cpu().numpy().tobytes(), l_exec.cpu().numpy().tobytes())
+    print(line + f" | answers == launch path: {res == ref}", flush=True)
     ctx.close()

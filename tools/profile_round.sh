@@ -4,9 +4,10 @@
 # Every group = one bench.py command profiled by SEPARATE rocprofv3 runs: --kernel-trace --stats for the durations, then one
 # --pmc run per counter set with --kernel-trace only (never combined with sys / runtime / hip / hsa trace domains):
 #   FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | the SQ set (waves, cycles, instructions by type, waits)
-#   headline  bench.py --headline-only --steps 200: BOTH regimes of the headline in one process — the launch path's windows are
-#             rows of fit_independent_kernel (one dispatch per batch), every worker window is ONE dispatch of fit_worker_kernel
-#             that serves the window's 200 tickets (counters / 200 = per ticket)        -> profiles/pmc_headline.json
+#   headline  bench.py --headline-only at the DRIVER's --steps 20 --warmup 5 (hl20) and at bench.py's defaults (hl, K = 2 000): both
+#             regimes of the headline in one process — the launch path's windows are rows of fit_independent_kernel (one dispatch
+#             per batch), every worker window is ONE dispatch of fit_worker_kernel that serves the window's K tickets (median
+#             over the dispatches / K = per ticket)                                      -> profiles/pmc_headline.json (runs.stepsK)
 #   chain     bench.py --no-extras --fifo-protocols cold: every fit_fifo_solo_kernel launch replays the headline chain
 #                                                                                        -> profiles/pmc_chain.json
 #   config3   bench.py --config3-only (10 000 nodes x 10 000 apps, both packers)          -> profiles/pmc_config3.json
@@ -72,5 +73,9 @@ for g in $GROUPS_; do
   esac
 done
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
-find "$OUT" -name '*.csv' | head -60
+# summarised HERE (gpurun copies back 64 MiB at most, the raw CSVs of a K = 2 000 window are larger): the summaries go to
+# $OUT/summary/ — copy them into profiles/ — and the raw pass directories are removed
+cd "$ROOT" && python tools/summarize_profile.py "$TAG" "$OUT" "$OUT/summary" > "$OUT/summarize.log" 2>&1; echo "summarize rc=$?"; tail -3 "$OUT/summarize.log" | cut -c1-300
 grep -h '^{' "$OUT"/*.log | cut -c1-300 | head -8
+find "$OUT" -mindepth 1 -maxdepth 1 -type d ! -name summary -exec rm -rf {} +
+du -sh "$OUT"

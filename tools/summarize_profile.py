@@ -106,9 +106,12 @@ def _avg_ns(path, name):
 
 
 def main():
+    # summarize_profile.py <tag> [<src dir> [<dst dir>]]: tools/profile_round.sh runs it ON THE BOX with dst = <src>/summary and
+    # deletes the raw rocprofv3 CSVs afterwards (a K = 2 000 counter pass has 10^5 rows; gpurun copies back 64 MiB at most);
+    # the builder then copies gpurun_out/prof_<tag>/summary/* into profiles/.
     tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
-    src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
-    dst = os.path.join(REPO, "profiles")
+    src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(REPO, "gpurun_out", f"prof_{tag}")
+    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
     md = (f"# rocprofv3 summary — {tag}\n\nRecipe: `tools/profile_round.sh {tag}` on one MI355X (gfx950): per profiled command one "
           "`rocprofv3 --kernel-trace --stats` run and one `--pmc` run per counter set (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum "
@@ -290,7 +293,7 @@ def main():
           "kernels": {}}
     # a round that profiles only some instantiations (ZONED_SPECS of tools/profile_round.sh) keeps the others' entries, each under the
     # tag of the visit that produced it
-    old_zoned = os.path.join(dst, "pmc_zoned.json")
+    old_zoned = os.path.join(REPO, "profiles", "pmc_zoned.json")
     if os.path.exists(old_zoned):
         try:
             oz = json.load(open(old_zoned))
