@@ -69,7 +69,7 @@ def load_profile(name):
         return None
 
 
-def three_fractions(time_s, hbm_bytes, l2_bytes, instructions, simds=N_SIMDS):
+def three_fractions(time_s, hbm_bytes, l2_bytes, instructions, simds=N_SIMDS, valu_busy=None, profile_time_s=None):
     """The one definition of `frac` (see the module docstring): measured HBM bytes, L2 request bytes and issued instructions of
     one step, each against its own peak over the kernel's time for that step.  Returns (fractions, bound, frac); a quantity
     that was not measured is left out, and bound is None when nothing was."""
@@ -85,6 +85,13 @@ def three_fractions(time_s, hbm_bytes, l2_bytes, instructions, simds=N_SIMDS):
         peak = simds * CLOCK_GHZ
         fr["issue"] = {"instructions_per_step": instructions, "achieved": a, "peak": peak, "unit": "Ginstr/s", "frac": a / peak,
                        "simds": simds}
+    if valu_busy is not None:
+        # what the vector ALUs themselves report (rocprofv3's derived VALUBusy of the committed profile: the share of the kernel's
+        # cycles in which they process an instruction), carried over to this run's kernel time — the same instructions in less
+        # time keep the pipes busier.  The ceiling of a kernel that is neither bytes nor flops: integer / compare / select work.
+        f = valu_busy * (profile_time_s / time_s if profile_time_s else 1.0)
+        fr["valu"] = {"achieved": f, "peak": 1.0, "unit": "share of cycles the vector ALUs are busy (VALUBusy)", "frac": f,
+                      "profile_valu_busy": valu_busy}
     if not fr:
         return fr, None, None
     bound = max(fr, key=lambda k: fr[k]["frac"])
@@ -621,7 +628,7 @@ def main():
         try:
             ctx.set_option("worker_sets", max(0, args.worker_sets))  # 0 = the library chooses at every launch
             arr = ctx.worker_batches([(len(apps), d_apps.data_ptr(), w_res[i % NOUT].data_ptr(), w_exec[i % NOUT].data_ptr(), total_k)
-                                      for i in range(args.steps)])
+                                      for i in range(args.steps)], leave_after=True)  # a window is a bounded stream: K tickets, then the worker leaves
 
             def window_worker():
                 barrier()
@@ -718,7 +725,9 @@ def main():
     def kernel_roofline(kernel, regime, kernel_ms_step, how, per_step, visited):
         """per_step: the profile's counters of one step of this kernel ({hbm_bytes, l2_request_bytes, instructions, ...}) or None."""
         ps = per_step or {}
-        fr, bound, frac = three_fractions(kernel_ms_step * 1e-3, ps.get("hbm_bytes"), ps.get("l2_request_bytes"), ps.get("instructions"))
+        own_ns = ps.get("rocprof_ns_per_ticket") or ps.get("rocprof_median_dispatch_ns") or ps.get("rocprof_avg_dispatch_ns")
+        fr, bound, frac = three_fractions(kernel_ms_step * 1e-3, ps.get("hbm_bytes"), ps.get("l2_request_bytes"), ps.get("instructions"),
+                                          valu_busy=ps.get("valu_busy"), profile_time_s=(own_ns * 1e-9) if own_ns else None)
         return {"kernel": kernel, "regime": regime, "kernel_ms": kernel_ms_step, "kernel_ms_is": how,
                 "bound": bound, "frac": frac,
                 "achieved": fr[bound]["achieved"] if bound else None, "peak": fr[bound]["peak"] if bound else None,

@@ -520,7 +520,11 @@ int gf_launch_floor(gf_ctx *ctx, void *stream, uint32_t iters, float *us_per_lau
  * order; *first_ticket receives the number of batches[0].  A record array handed to the worker is read around the device's
  * L1 but through its L2: an array whose CONTENT is replaced while the worker is resident must be replaced by a stream
  * operation that completed before the submit (a finished copy or kernel), as for any kernel launch.  GF_WORKER_HOST_OUTPUTS:
- * d_results / d_exec_nodes are device addresses of PINNED HOST memory (no cache write-back before the completion word). */
+ * d_results / d_exec_nodes are device addresses of PINNED HOST memory (no cache write-back before the completion word).
+ * GF_WORKER_LEAVE_AFTER on the LAST batch of a submit: the caller has nothing more to post — a worker that this submit launches
+ * (none was resident) serves what is posted and leaves the device by itself, without waiting to be told (gf_worker_stop /
+ * gf_worker_wait behind it return as soon as the last answer is out; a bounded stream — K batches, then something else — saves the
+ * two probes for a ticket that will not come).  Ignored when the worker is already resident. */
 typedef struct gf_worker_batch {
     uint32_t n_apps;          /* > 0 */
     uint32_t flags;           /* GF_WORKER_* */
@@ -530,6 +534,7 @@ typedef struct gf_worker_batch {
     uint64_t exec_nodes_len;  /* sum of k over the batch */
 } gf_worker_batch;
 #define GF_WORKER_HOST_OUTPUTS 1u
+#define GF_WORKER_LEAVE_AFTER 2u
 int gf_worker_fit(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, gf_result *results, uint32_t *exec_nodes,
                   uint64_t exec_nodes_cap);
 int gf_worker_submit_dev(gf_ctx *ctx, gf_algo algo, uint32_t n_batches, const gf_worker_batch *batches, uint64_t *first_ticket);

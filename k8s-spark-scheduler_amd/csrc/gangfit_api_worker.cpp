@@ -1,5 +1,6 @@
 // gangfit_api_worker.cpp — the resident worker of the independent batch (gf_worker_*; device side: gangfit_worker.inc).
 #include "gangfit_ctx.h"
+#include <cstdio>
 
 using namespace gfapi;
 
@@ -114,6 +115,8 @@ int worker_launch(gf_ctx* ctx, gf_algo algo, uint64_t first_ticket) {
     a.generation = w.launches + 1;
     a.first_ticket = first_ticket;
     a.idle_ticks = (unsigned long long)w.idle_us * 100ull;  // wall_clock64 ticks at 100 MHz
+    a.leave_after = (w.leave_after != 0 && w.leave_after == w.posted && first_ticket < w.posted) ? w.leave_after : 0ull;
+    w.leave_after = 0;
     a.scratch = w.scratch.ptr;
     a.scratch_stride = w.scratch_stride;
     // every workgroup must be resident at once (a group that waits for a CU would leave its tickets unserved while the others
@@ -313,14 +316,33 @@ int gf_worker_submit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_batches, const gf
                 need_launch = false;
                 if (const int rc = worker_launch(ctx, algo, first); rc != GF_OK) return rc;
             }
+#ifdef GF_WORKER_HOST_DEBUG  // where the posting loop's time goes, and how many of the tickets in flight are done when the oldest is
+            const auto td0 = std::chrono::steady_clock::now();
+#endif
             if (const int rc = worker_wait_ticket(ctx, w.posted - kRing); rc != GF_OK) return rc;
+#ifdef GF_WORKER_HOST_DEBUG
+            {
+                static double wait_ns = 0;
+                static uint64_t n_wait = 0, done_behind = 0;
+                wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - td0).count();
+                for (uint64_t q = w.posted - kRing + 1; q < w.posted; ++q) done_behind += host_load(&w.h->done[q % kRing]) == q + 1 ? 1 : 0;
+                if ((++n_wait % 1900) == 0)
+                    std::fprintf(stderr, "[worker host] %llu waits: %.0f ns each, %.1f of the %u younger tickets already complete, relayed %llu of %llu posted\n",
+                                 (unsigned long long)n_wait, wait_ns / n_wait, (double)done_behind / n_wait, kRing - 1,
+                                 (unsigned long long)host_load(&w.h->consumed), (unsigned long long)w.posted);
+            }
+#endif
             worker_advance(w);
         }
         const gf_worker_batch& b = batches[i];
         worker_post(w, b.n_apps, b.d_apps, b.d_results, b.d_exec_nodes, b.exec_nodes_len, (b.flags & GF_WORKER_HOST_OUTPUTS) != 0);
     }
     host_store(&w.h->posted, w.posted);  // the doorbell: one word for the whole group
-    if (need_launch) return worker_launch(ctx, algo, first);
+    if (need_launch) {
+        // a bounded stream: the launch is told where it ends (only a launch that starts with everything already posted)
+        if (n_batches != 0 && (batches[n_batches - 1].flags & GF_WORKER_LEAVE_AFTER) != 0) w.leave_after = w.posted;
+        return worker_launch(ctx, algo, first);
+    }
     return GF_OK;
 }
 

@@ -238,6 +238,7 @@ struct gf_ctx {
         uint32_t cur_sets = 0, cur_blocks_per_set = 0;  // what the last launch ran with (gf_worker_geometry)
         uint32_t hint_apps = 1000, hint_per_wave = 3;   // what the caller that launches expects: ticket size, applications per wavefront
         uint32_t idle_us = 200;
+        uint64_t leave_after = 0;     // the next launch serves tickets below this one and leaves (GF_WORKER_LEAVE_AFTER), 0 = resident
         uint64_t launches = 0;
         int per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // resident workgroups of the worker kernel per CU, by packer (asked of the runtime once)
         // HIP events on the worker's stream around its launch: how long the last finished launch stayed on the device and how

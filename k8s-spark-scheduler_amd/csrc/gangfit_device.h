@@ -134,7 +134,10 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
                                   uint32_t* d_feasible_sync = nullptr);
 
 // ---- the resident worker of the independent batch (gangfit_worker.inc; host side: gangfit_api_worker.cpp)
-constexpr uint32_t kWorkerRing = 64;
+#ifndef GF_WORKER_RING
+#define GF_WORKER_RING 64  // (a power of two; every translation unit must see the same value)
+#endif
+constexpr uint32_t kWorkerRing = GF_WORKER_RING;
 constexpr uint32_t kWorkerInline = 16;  // tickets a launch of the worker carries in its arguments (at most one per set)
 constexpr int kWorkerWaves = 16;             // wavefronts per workgroup of the worker kernel (one workgroup fills a CU)
 constexpr uint32_t kWorkerCountStride = 64;  // words between two tickets' counters: one 256-byte line (one memory channel) each  // tickets in flight at most (host side waits for ticket t - kWorkerRing before it posts t)
@@ -172,6 +175,7 @@ struct WorkerArgs {
     unsigned long long generation;    // of this launch (1, 2, ...): the value the leader writes into the quit word when it leaves
     unsigned long long first_ticket;  // tickets below this one were served by an earlier launch
     unsigned long long idle_ticks;    // the leader leaves after this long without a new ticket (100 MHz)
+    unsigned long long leave_after;   // != 0: nothing behind ticket leave_after - 1 will be posted to this launch (GF_WORKER_LEAVE_AFTER)
     uint32_t* scratch;                // [kWorkerRing][3 * scratch_stride]: private placements, two survivor lists
     unsigned long long scratch_stride;
     uint32_t sets;

@@ -39,6 +39,7 @@ assert APP_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
 # every symbol include/gangfit.h declares (tests check that the library exports all of them)
 GF_RESIDENT_USAGE = 0xFFFFFFFF
 GF_ANY_ZONE = 0xFFFFFFFF
+GF_WORKER_LEAVE_AFTER = 2
 
 EXPORTED_SYMBOLS = [
     "gf_version", "gf_init", "gf_destroy", "gf_last_error", "gf_snapshot_set", "gf_orders_set", "gf_fit_batch", "gf_fit_feasible",

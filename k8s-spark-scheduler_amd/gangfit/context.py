@@ -371,12 +371,15 @@ class Context:
         self._check(self._lib.gf_worker_submit_dev(self._h, algo, len(batches), arr, C.byref(first)))
         return int(first.value)
 
-    def worker_batches(self, batches):
-        """A prepared ctypes array for worker_submit_prepared (keeps the marshalling out of a timed region)."""
+    def worker_batches(self, batches, leave_after: bool = False):
+        """A prepared ctypes array for worker_submit_prepared (keeps the marshalling out of a timed region).  leave_after: the
+        last batch carries GF_WORKER_LEAVE_AFTER (a bounded stream: a worker this submit launches leaves by itself)."""
         arr = (N.WorkerBatch * len(batches))()
         for i, b in enumerate(batches):
             arr[i].n_apps, arr[i].d_apps, arr[i].d_results, arr[i].d_exec_nodes, arr[i].exec_nodes_len = b[0], b[1], b[2], b[3], b[4]
             arr[i].flags = b[5] if len(b) > 5 else 0
+        if leave_after and len(batches):
+            arr[len(batches) - 1].flags |= N.GF_WORKER_LEAVE_AFTER
         return arr
 
     def worker_submit_prepared(self, algo: int, arr) -> int:

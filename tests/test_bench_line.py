@@ -34,7 +34,7 @@ def test_line_is_short_and_round_trips():
     rf = line["roofline"]
     for key in ("kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic", "fractions", "wait_fraction"):
         assert key in rf, key
-    assert set(rf["fractions"]) == {"hbm", "l2", "issue"}
+    assert {"hbm", "l2", "issue"} <= set(rf["fractions"]) <= {"hbm", "l2", "issue", "valu"}
     assert rf["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-4)
     assert rf["fifo_chain"]["filter_p50_ms"] == pytest.approx(full["roofline"]["fifo_chain"]["filter_p50_ms"], rel=1e-5)

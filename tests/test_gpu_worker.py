@@ -135,6 +135,47 @@ def test_tickets_in_flight_device_resident(algo, sets):
         ctx.close()
 
 
+@pytest.mark.parametrize("n_batches", [1, 20, 150])
+def test_a_bounded_stream_tells_the_worker_where_it_ends(n_batches):
+    """GF_WORKER_LEAVE_AFTER on the last batch of a submit that launches the worker: it serves what was posted and leaves the device
+    by itself (no stop word, no idle period); the same flag on a submit that finds the worker resident is ignored.  Every ticket
+    answers what a launch answers — more tickets than the ring holds included (the host then posts the rest while the worker runs:
+    the launch was told the end of what was posted when it started, and the rest reaches a second launch)."""
+    import torch
+
+    ctx = gangfit.Context(0, options={"worker_idle_us": 500000})  # an idle period this long would fail the timing below
+    try:
+        w = wl.headline(3000, 400, seed=0x1EA7)
+        _install(ctx, w)
+        dev = torch.device("cuda:0")
+        apps, total_k = gangfit.with_offsets(gangfit.make_apps(w.drv, w.exe, w.k))
+        d_apps = torch.from_numpy(apps.view(np.uint8).copy()).to(dev)
+        want_res = torch.zeros(len(apps) * 16, dtype=torch.uint8, device=dev)
+        want_exec = torch.zeros(total_k + 1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.fit_batch_dev(IND, TIGHT, len(apps), d_apps.data_ptr(), want_res.data_ptr(), want_exec.data_ptr(), total_k)
+        torch.cuda.synchronize()
+        outs = [(torch.zeros_like(want_res), torch.zeros_like(want_exec)) for _ in range(n_batches)]
+        torch.cuda.synchronize()
+        arr = ctx.worker_batches([(len(apps), d_apps.data_ptr(), r.data_ptr(), e.data_ptr(), total_k) for r, e in outs], leave_after=True)
+        for rep in range(3):
+            for r, e in outs:
+                r.zero_()
+                e.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            first = ctx.worker_submit_prepared(TIGHT, arr)
+            ctx.worker_wait(first, n_batches)
+            ctx.worker_stop()
+            torch.cuda.synchronize()
+            assert time.perf_counter() - t0 < 0.25, "the worker waited to be told (or for its idle period) instead of leaving"
+            assert all(torch.equal(r, want_res) and torch.equal(e, want_exec) for r, e in outs)
+            st = ctx.worker_stats()
+            assert st["posted"] == st["complete"] == (rep + 1) * n_batches and not st["resident"]
+    finally:
+        ctx.close()
+
+
 def test_worker_refusals():
     ctx = gangfit.Context(0)
     try:

@@ -34,7 +34,7 @@ for sets, bps in configs:
     ctx.set_orders(s.driver_order, s.exec_order)
     line = f"sets {sets:2d} x {bps:2d} workgroups ({1 + sets * bps:3d} CUs)"
     for K in (20, 200, 2000):
-        arr = ctx.worker_batches([(len(apps), d_apps.data_ptr(), outs[i % NOUT][0].data_ptr(), outs[i % NOUT][1].data_ptr(), total_k) for i in range(K)])
+        arr = ctx.worker_batches([(len(apps), d_apps.data_ptr(), outs[i % NOUT][0].data_ptr(), outs[i % NOUT][1].data_ptr(), total_k) for i in range(K)], leave_after=os.environ.get("PROBE_LEAVE_AFTER", "1") != "0")
         walls, kern = [], []
         for rep in range(9):
             torch.cuda.synchronize()

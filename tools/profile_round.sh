@@ -35,18 +35,28 @@ run_group() {  # <prefix> <timeout> <command...>: stats + the four counter passe
   timeout $to rocprofv3 --kernel-trace --pmc WRITE_SIZE -T -f csv -d "$OUT/${pre}_write" -o pmc -- "$@" > "$OUT/${pre}_write.log" 2>&1
   timeout $to rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -T -f csv -d "$OUT/${pre}_l2" -o pmc -- "$@" > "$OUT/${pre}_l2.log" 2>&1
   timeout $to rocprofv3 --kernel-trace --pmc $SQSET -T -f csv -d "$OUT/${pre}_sq" -o pmc -- "$@" > "$OUT/${pre}_sq.log" 2>&1
+  # what the ALUs themselves report: the fraction of the kernel's cycles the vector / scalar ALUs process instructions
+  # (rocprofv3's derived VALUBusy / SALUBusy) and the pipes' raw active cycles, the instruction fetches, the issue stalls
+  if [ -n "${BUSY_PASS:-}" ]; then
+    timeout $to rocprofv3 --kernel-trace --pmc VALUBusy SALUBusy -T -f csv -d "$OUT/${pre}_busy" -o pmc -- "$@" > "$OUT/${pre}_busy.log" 2>&1
+    timeout $to rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_IFETCH SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_BUSY_CU_CYCLES -T -f csv -d "$OUT/${pre}_sq2" -o pmc -- "$@" > "$OUT/${pre}_sq2.log" 2>&1
+  fi
 }
 for g in $GROUPS_; do
   case $g in
     headline)
+      BUSY_PASS=1
       run_group hl20 300 python $ROOT/bench.py --headline-only --steps 20 --warmup 5 ${BENCH_ARGS:-}
       run_group hl 300 python $ROOT/bench.py --headline-only ${BENCH_ARGS:-}
+      BUSY_PASS=
       ;;
     chain)
       run_group chain 300 python $ROOT/bench.py --steps 20 --warmup 5 --windows 3 --filter-calls 30 --no-cpu-baseline --no-extras --fifo-protocols cold --worker-sets 0
       ;;
     config3)
+      BUSY_PASS=1
       run_group c3 300 python $ROOT/bench.py --config3-only
+      BUSY_PASS=
       ;;
     zoned)
       LDSSET="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_WAVE_CYCLES"

@@ -22,7 +22,7 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PASSES = ("fetch", "write", "l2", "sq")
+PASSES = ("fetch", "write", "l2", "sq", "busy", "sq2")
 INST = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")
 
 
@@ -67,6 +67,13 @@ def _derive(mean, div=1.0):
         out["instructions"] = sum(mean.get(c, 0.0) for c in INST) / div
     if mean.get("SQ_WAVE_CYCLES"):
         out["wait_fraction"] = mean.get("SQ_WAIT_ANY", 0.0) / mean["SQ_WAVE_CYCLES"]
+    # rocprofv3's derived metrics (percent of the kernel's GPU time): NOT divided by the steps of a dispatch
+    if mean.get("VALUBusy") is not None:
+        out["valu_busy"] = mean["VALUBusy"] / 100.0
+        out["VALUBusy"] = mean["VALUBusy"]
+    if mean.get("SALUBusy") is not None:
+        out["salu_busy"] = mean["SALUBusy"] / 100.0
+        out["SALUBusy"] = mean["SALUBusy"]
     return out
 
 
@@ -161,7 +168,8 @@ def main():
                 lp["fractions_over_own_duration"] = {k: v for k, v in (
                     ("hbm", lp["hbm_bytes"] / t / 8e12 if lp.get("hbm_bytes") is not None else None),
                     ("l2", lp["l2_request_bytes"] / t / 34.5e12 if lp.get("l2_request_bytes") is not None else None),
-                    ("issue", lp["instructions"] / t / (1024 * 2.4e9) if lp.get("instructions") is not None else None)) if v is not None}
+                    ("issue", lp["instructions"] / t / (1024 * 2.4e9) if lp.get("instructions") is not None else None),
+                    ("valu", lp.get("valu_busy"))) if v is not None}
             a, n = _avg_ns(hstats, "fit_worker_kernel")
             d = _durations(trace, "fit_worker_kernel")
             if a and "worker" in hj:
@@ -184,6 +192,8 @@ def main():
                     own["l2"] = wk["l2_request_bytes"] / t / 34.5e12
                 if wk.get("instructions") is not None:
                     own["issue"] = wk["instructions"] / t / (1024 * 2.4e9)
+                if wk.get("valu_busy") is not None:
+                    own["valu"] = wk["valu_busy"]
                 wk["fractions_over_own_duration"] = own
                 # the traced run's own line: the kernel cannot take longer per ticket than a step of the window it served
                 if bj.get("ms_per_step") and (bj.get("config") or {}).get("regime", "").startswith("streamed"):
