@@ -686,11 +686,18 @@ def main():
     visited_bytes = xvis * 24 + dvis * 28 + len(apps) * 88 + 4 * int(w.k.sum())
     visited_worker = None
     if used_worker:
-        try:  # the same counters inside the worker: one window of K tickets, per ticket
+        try:  # the same counters inside the worker, per ticket.  A SHORT stream: the counters are two device-wide atomics per
+            # application, a ticket then takes twenty times as long, and a long stream of such tickets lets the leader idle out
+            # between two postings (round 6's K = 2 000 profile held 31 relaunches of 64 tickets each from this one window)
+            n_cnt = min(args.steps, 20)
+            arr_cnt = ctx.worker_batches([(len(apps), d_apps.data_ptr(), w_res[i % NOUT].data_ptr(), w_exec[i % NOUT].data_ptr(), total_k)
+                                          for i in range(n_cnt)], leave_after=True)
             ctx.scan_stats(enable=True, reset=True)
-            window_worker()
+            ctx.worker_submit_prepared(TIGHT, arr_cnt)
+            ctx.worker_stop()
+            torch.cuda.synchronize()
             xw, dw = ctx.scan_stats(enable=False, reset=True)
-            visited_worker = (xw * 24 + dw * 28) / args.steps + len(apps) * 88 + 4 * int(w.k.sum())
+            visited_worker = (xw * 24 + dw * 28) / n_cnt + len(apps) * 88 + 4 * int(w.k.sum())
         except Exception:
             visited_worker = None
     try:

@@ -25,8 +25,11 @@ for K in (20, 2000):
         ctx.worker_submit_prepared(TIGHT, arr); ctx.worker_stop(); torch.cuda.synchronize()
     ctx.scan_stats(enable=True, reset=True)
     ctx.worker_submit_prepared(TIGHT, arr); ctx.worker_stop(); torch.cuda.synchronize()
-    ctx.scan_stats(enable=False, reset=False)
+    lp_looks, lp_ticks = ctx.scan_stats(enable=False, reset=False)
     rounds = ctx.last_fifo_clock[0]
+    lp = ctx.last_fifo_clock[1]
+    print(f"   the leader: {lp_looks} looks that found tickets, {lp_ticks / max(1, lp_looks) / 100:.1f} us from a look to the end of its relay, "
+          f"{(lp & 0xFFFFFFFF) / max(1, lp_looks):.1f} tickets per look (most: {lp >> 32})")
     w0 = ctx.last_fifo_phases
     out = np.zeros(12, dtype=np.uint64)
     ctx._check(ctx._lib.gf_chain_profile(ctx._h, gangfit._native.ptr(out)))
@@ -36,5 +39,8 @@ for K in (20, 2000):
     for nm, a, b in zip(names, w0, w5):
         print(f"   {nm:14s} wavefront 0 {a / max(1, rounds):9.0f}   wavefront 5 {b / max(1, rounds):9.0f}")
     print(f"   over all workgroups, wavefront 0: waiting for a ticket {(1000 - int(out[2])) / 10:.1f} .. {int(out[1]) / 10:.1f} % of the rounds; decisions per round {(1 << 30) - int(out[4])} .. {int(out[3])} cycles")
+    hw = int(out[10]) | (int(out[11]) << 32)
+    print(f"   probed workgroup, wavefront 0: the next ticket was there when the round began in {hw & 0xFFFFFFFF} of {rounds} rounds; {hw >> 32} probes in the probe loop")
+    print(f"   tickets: {int(out[0])} completed, {int(out[5]) / max(1, int(out[0])) / 100:.1f} us on average from the FIRST workgroup's share to the ticket's completion")
     print(f"   {'sum':14s} wavefront 0 {sum(w0) / max(1, rounds):9.0f}   wavefront 5 {sum(w5) / max(1, rounds):9.0f}   (2.4 GHz: {sum(w0) / max(1, rounds) / 2400:.2f} us)")
 ctx.close()

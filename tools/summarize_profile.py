@@ -172,6 +172,14 @@ def main():
                     ("valu", lp.get("valu_busy"))) if v is not None}
             a, n = _avg_ns(hstats, "fit_worker_kernel")
             d = _durations(trace, "fit_worker_kernel")
+            # the dispatches that served a whole K-ticket window: within a quarter of the traced run's own kernel time per window
+            # (HIP events, the line's roofline.kernel_ms x K); the others are the short counter window and relaunches
+            ref_ns = ((bj.get("roofline") or {}).get("kernel_ms") or 0) * 1e6 * steps
+            if d and ref_ns and (bj.get("config") or {}).get("regime", "").startswith("streamed"):
+                full = [x for x in d if 0.75 * ref_ns <= x <= 1.25 * ref_ns]
+                if len(full) >= 3:
+                    hj.setdefault("worker", {})["rocprof_dispatches_all_ns"] = d
+                    d = full
             if a and "worker" in hj:
                 wk = hj["worker"]
                 wk["rocprof_avg_dispatch_ns"], wk["rocprof_dispatches"] = a, n
@@ -278,7 +286,7 @@ def main():
         t = c3.get(nme)
         if t:
             t.update({k: v for k, v in _derive(t, 1.0).items() if k in ("fetch_bytes_raw", "write_bytes", "hbm_bytes", "l2_request_bytes",
-                                                                       "instructions", "wait_fraction")})
+                                                                       "instructions", "wait_fraction", "valu_busy", "salu_busy")})
     kst = os.path.join(src, "c3_stats", "stats_kernel_stats.csv")
     if os.path.exists(kst):
         shutil.copy(kst, os.path.join(dst, f"{tag}_kernel_stats_config3.csv"))
