@@ -31,11 +31,15 @@ namespace gangfit {
 namespace {
 
 constexpr int kWave = 64;
+#ifndef GF_MF_TEAM
+#define GF_MF_TEAM 1  // minimal-fragmentation, independent batch: the wavefronts of a workgroup share ONE application's passes (team_minfrag_hist); 0 = one application per wavefront
+#endif
 constexpr int kMfHistBins = 256;  // minimal-fragmentation: capacities below this are counted in a histogram (Orders::mf_hist)
 #ifndef GF_WAVES_PER_BLOCK
 #define GF_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = GF_WAVES_PER_BLOCK;  // independent-batch kernel: apps (= waves) per workgroup
+constexpr int kMfTeamMax = kWavesPerBlock;          // ... and the wavefronts of a minimal-fragmentation team
 
 // ------------------------------------------------------------------------------------------------ wave primitives
 
@@ -360,6 +364,11 @@ struct Orders {
     // calling wavefront, 16-byte aligned, and the snapshot's scaled int32 columns (NodeTable::ncpu ..); nullptr = the
     // pass-per-question walk on the wide table
     lds_u32h* mf_hist = nullptr;
+    // a TEAM of wavefronts on one application (gangfit_minfrag.inc: team_minfrag_hist): mf_team wavefronts, this one is mf_rank; the
+    // rows of wavefront r start at mf_team_base + r * 3 * kMfHistBins (mf_hist = this wavefront's), mf_words: one word per wavefront
+    uint32_t mf_team = 1, mf_rank = 0;
+    lds_u32h* mf_team_base = nullptr;
+    lds_u32h* mf_words = nullptr;
     bool mf_lent = false;  // (an LDS array may sit at LDS address 0, which compares equal to nullptr: the flag says whether mf_hist is lent)
     const int32_t* ncpu = nullptr;
     const int32_t* nmem = nullptr;
@@ -1161,7 +1170,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
     ScanStats* __restrict__ stats) {
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t a = blockIdx.x * kWavesPerBlock + wave;
+    constexpr bool kMfTeam = ALGO == GF_ALGO_MINIMAL_FRAGMENTATION && GF_MF_TEAM != 0;
+    const uint32_t a = kMfTeam ? blockIdx.x : blockIdx.x * kWavesPerBlock + wave;
+    const bool reports = !kMfTeam || wave == 0u;  // (a team's wavefronts reach the same decision: one of them reports it)
     const uint32_t n_waves = n_apps;
     if (FEAS && blockIdx.x == gridDim.x - 1u) {  // the collecting workgroup (launch_fit_independent appends it)
         if (wave == 0) feasible_collect(reinterpret_cast<uint32_t*>(stats), reinterpret_cast<uint32_t*>(results), n_apps, lane);
@@ -1171,9 +1182,16 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
     GlobalView V{T.cpu, T.mem, T.gpu, T.cmax, T.cmax + T.n_chunks, T.cmax + 2 * (size_t)T.n_chunks, T.xmask, T.dmask,
                  T.n_chunks};
     Orders O{T.slot_node, T.dslot, T.n_x, T.n_d, T.d_identity != 0};
-    if constexpr (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) {  // the capacity histogram of this wavefront's application
+    if constexpr (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION) {  // the capacity histogram rows of this wavefront
         __shared__ __attribute__((aligned(16))) uint32_t mf_hist[kWavesPerBlock * 3 * kMfHistBins];
         O.lend_minfrag((lds_u32h*)mf_hist + (size_t)wave * 3 * kMfHistBins, T);
+        if constexpr (kMfTeam) {  // the workgroup is a team on ONE application (launch_fit_independent: a workgroup per application)
+            __shared__ uint32_t mf_words[kMfTeamMax];
+            O.mf_team = (uint32_t)kWavesPerBlock;
+            O.mf_rank = wave;
+            O.mf_team_base = (lds_u32h*)mf_hist;
+            O.mf_words = (lds_u32h*)mf_words;
+        }
 #ifdef GF_MF_PROBE
         if (stats != nullptr) O.mf_probe = &stats->fifo_phase_cycles[0];
 #endif
@@ -1192,8 +1210,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
                                                             scratch + scratch_half + app.exec_off, lane, xvis, dvis,
                                                             merged ? &g0 : nullptr, &G);
         if (FEAS) {
-            if (lane == 0) feasible_announce(reinterpret_cast<uint32_t*>(stats), ai, dec.feasible);
-        } else if (lane == 0) {
+            if (lane == 0 && reports) feasible_announce(reinterpret_cast<uint32_t*>(stats), ai, dec.feasible);
+        } else if (lane == 0 && reports) {
             gf_result r;
             r.has_capacity = dec.feasible ? 1 : 0;
             if (dec.feasible && dec.ds_node == GF_NO_NODE) dec.ds_node = T.slot_node[dec.ds];
@@ -1206,9 +1224,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) GF_IND_OCC void fit_independ
     decide(load_app(apps, a), a);
 #ifdef GF_MF_PROBE
     if constexpr (ALGO == GF_ALGO_MINIMAL_FRAGMENTATION)
-        if (!FEAS && stats != nullptr && lane == 0) atomicAdd(&stats->fifo_phase_cycles[0], __builtin_readcyclecounter() - t_kernel0);
+        if (!FEAS && stats != nullptr && lane == 0 && reports) atomicAdd(&stats->fifo_phase_cycles[0], __builtin_readcyclecounter() - t_kernel0);
 #endif
-    if (!FEAS && stats != nullptr && lane == 0) {
+    if (!FEAS && stats != nullptr && lane == 0 && reports) {
         atomicAdd(&stats->exec_slots_visited, xvis);
         atomicAdd(&stats->driver_slots_visited, dvis);
     }
@@ -1849,7 +1867,9 @@ hipError_t launch_fit_independent(gf_algo algo, const NodeTable& table, const Sp
     if (n_apps == 0) return hipSuccess;
     if (d_feasible != nullptr && d_feasible_sync == nullptr) return hipErrorInvalidValue;
     const dim3 block(kWave * kWavesPerBlock);
-    const dim3 grid((n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
+    // (minimal-fragmentation: a workgroup per application — its wavefronts share the passes over the executor order)
+    const bool team = algo == GF_ALGO_MINIMAL_FRAGMENTATION && GF_MF_TEAM != 0;
+    const dim3 grid(team ? n_apps : (n_apps + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 grid_feas(grid.x + 1);  // + the collecting workgroup
 #define GF_IND(ALGO)                                                                                                               \
     if (d_feasible != nullptr)                                                                                                     \
