@@ -60,7 +60,7 @@ for g in $GROUPS_; do
       ;;
     zoned)
       LDSSET="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_WAVE_CYCLES"
-      for spec in "zb_saz batch single-az-tightly-pack" "zb_smf batch single-az-minimal-fragmentation" \
+      for spec in "zb_saz batch single-az-tightly-pack" "zb_smf batch single-az-minimal-fragmentation" "zb_mf batch minimal-fragmentation" \
                   "zc_saz chain single-az-tightly-pack" "zc_aza chain az-aware-tightly-pack" \
                   "mc_mf chain minimal-fragmentation" "mc_smf chain single-az-minimal-fragmentation"; do
         set -- $spec

@@ -299,6 +299,7 @@ def main():
     # ---- the zone-aware / minimal-fragmentation kernels, one instantiation per profiled command (tools/profile_cmd.py)
     ZONED = (("zb_saz", "fit_zoned_fused_kernel", "single-az-tightly-pack", "independent batch, one launch", 1024),
              ("zb_smf", "fit_zoned_fused_kernel", "single-az-minimal-fragmentation", "independent batch, one launch", 1024),
+             ("zb_mf", "fit_independent_kernel", "minimal-fragmentation", "independent batch, a workgroup per application (round 6)", 1024),
              ("zc_saz", "fit_fifo_zoned_lds_kernel", "single-az-tightly-pack", "cold FIFO chain", 4),
              ("zc_aza", "fit_fifo_zoned_lds_kernel", "az-aware-tightly-pack", "cold FIFO chain", 4),
              ("mc_mf", "fit_fifo_minfrag_lds_kernel", "minimal-fragmentation", "cold FIFO chain (8-wavefront instantiation)", 4),
