@@ -12,6 +12,8 @@ these models document WHY the routines are exact, step by step, and run without 
                          chain_prologue_kernel), against the walk back through the checkpoints
   minfrag_histogram      minimalFragmentation (minimal_fragmentation.go:59-137) decided on the histogram of the capacities + one
                          emission pass (csrc/gangfit_minfrag.inc: wave_minfrag_hist), against the walk over the sorted list
+  minfrag_team           the same decision by a TEAM of wavefronts (team_minfrag_hist): quarters of the order's chunks, private count /
+                         first-slot rows, the prefix of the quarters before as the starting ranks of the emission pass
 """
 import numpy as np
 import pytest
@@ -472,6 +474,131 @@ def minfrag_histogram(count, capacities, bins=256):
             out[K - R + i] = last_pos
     assert all(v is not None for v in out)
     return out, True
+
+
+def minfrag_team(count, capacities, team=4, chunk=WAVE, bins=256):
+    """team_minfrag_hist, wavefront by wavefront: wavefront r walks chunks [r * per, (r + 1) * per) of the order in BOTH passes and
+    writes only its own rows; what crosses between the wavefronts is the sum of the count rows, the minimum of the first-slot rows
+    and — per wavefront — the sum of the rows of the quarters before it.  Everything else is minfrag_histogram's plan."""
+    K = count
+    if K == 0:
+        return [], True
+    n = len(capacities)
+    xc = (n + chunk - 1) // chunk
+    per = (xc + team - 1) // team
+    ranges = []
+    for r in range(team):
+        lo = min(r * per, xc)
+        hi = min(lo + per, xc)
+        ranges.append((lo * chunk, min(hi * chunk, n)))
+    # pass 1: private rows
+    cnt_r = [[0] * bins for _ in range(team)]
+    first_r = [[None] * bins for _ in range(team)]
+    for r, (lo, hi) in enumerate(ranges):
+        for p in range(lo, hi):
+            c = capacities[p]
+            if c >= bins:
+                return None  # (the maximum over the team's words: every wavefront takes the walk)
+            if c > 0:
+                cnt_r[r][c] += 1
+                if first_r[r][c] is None:
+                    first_r[r][c] = p
+    # behind the barrier: everybody reads everybody's rows
+    cnt = [sum(cnt_r[r][c] for r in range(team)) for c in range(bins)]
+    first = [min((first_r[r][c] for r in range(team) if first_r[r][c] is not None), default=None) for c in range(bins)]
+    pre_r = [[sum(cnt_r[q][c] for q in range(r)) for c in range(bins)] for r in range(team)]
+    S = sum(cnt[c] * min(c, K) for c in range(bins))
+    if S < K:
+        return None, False
+    max_cap = max(c for c in range(bins) if cnt[c])
+    top = bins
+    if K < max_cap:
+        target = (K + max_cap) // 2
+        if sum(cnt[c] * min(c, K) for c in range(target)) >= K:
+            top = target
+
+    def smallest_at_least(need, below):
+        return next((c for c in range(max(need, 1), below) if cnt[c]), None)
+
+    def largest_below(below):
+        return next((c for c in range(below - 1, 0, -1) if cnt[c]), 0)
+
+    R = K
+    cf = smallest_at_least(R, top)
+    if cf is not None:
+        return [first[cf]] * K, True  # (wavefront 0 emits)
+    take, base = {}, {}
+    last_pos, next_level, next_rank = None, None, 0
+    while True:
+        m = largest_below(top)
+        assert 0 < m < R
+        q = R // m
+        drained = min(cnt[m], q)
+        take[m], base[m] = drained, K - R
+        R -= drained * m
+        if R == 0:
+            break
+        if drained < cnt[m]:
+            cf = smallest_at_least(R, m)
+            if cf is not None:
+                last_pos = first[cf]
+            else:
+                next_level, next_rank = m, drained
+            break
+        top = m
+        cf = smallest_at_least(R, top)
+        if cf is not None:
+            last_pos = first[cf]
+            break
+    last_from_plan = last_pos is not None
+    # pass 2: every quarter on its own, its level counts starting at the prefix of the quarters before; it stops when what the
+    # plan wants from it is out (`left`)
+    out = [None] * K
+    writers = [0] * K  # every output word is written exactly once
+    found = None
+    for r, (lo, hi) in enumerate(ranges):
+        left = sum(min(max(take.get(c, 0) - pre_r[r][c], 0), cnt_r[r][c]) for c in range(1, bins))
+        if next_level is not None and pre_r[r][next_level] <= next_rank < pre_r[r][next_level] + cnt_r[r][next_level]:
+            left += 1
+        seen = {c: pre_r[r][c] for c in range(bins)}
+        for p in range(lo, hi):
+            if left == 0:
+                break
+            c = capacities[p]
+            if c in take or c == next_level:
+                rank = seen[c]
+                seen[c] = rank + 1
+                if rank < take.get(c, 0):
+                    for i in range(c):
+                        out[base[c] + rank * c + i] = p
+                        writers[base[c] + rank * c + i] += 1
+                    left -= 1
+                if c == next_level and rank == next_rank:
+                    found = p
+                    left -= 1
+        assert left == 0
+    if R > 0:
+        node = last_pos if last_from_plan else found  # (wavefront 0 / the quarter that found it emits)
+        for i in range(R):
+            out[K - R + i] = node
+            writers[K - R + i] += 1
+    assert all(w == 1 for w in writers)
+    return out, True
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_minfrag_team_is_the_single_wavefront_form(seed):
+    rng = np.random.default_rng(9100 + seed)
+    n = int(rng.integers(1, 1200))
+    hi = int(rng.choice([2, 5, 12, 40, 255, 300]))
+    caps = [int(v) for v in rng.integers(0, hi + 1, size=n)]
+    if rng.random() < 0.5:  # neighbours with equal capacities, as a priority order has them
+        caps = sorted(caps)
+    total = sum(min(c, 255) for c in caps)
+    for _ in range(25):
+        K = int(rng.integers(0, max(2, min(total + 3, 600))))
+        for team in (1, 2, 4, 8):
+            assert minfrag_team(K, caps, team=team) == minfrag_histogram(K, caps), (seed, K, team)
 
 
 def test_minfrag_histogram_doc_comment_examples():
