@@ -18,7 +18,18 @@ int shard_ready(gf_ctx* ctx, gf_algo algo, gangfit::ShardRange* r) {
     r->c_hi = (uint32_t)(xc * (ctx->shard + 1) / ctx->n_shards);
     r->shard = ctx->shard;
     r->n_shards = ctx->n_shards;
+    // the range's sub-slots of the sparse gpu view (gangs of gpu executors are summed and emitted from it: gangfit_shard.inc)
+    r->g_lo = r->g_hi = 0;
+    if (ctx->n_g != 0 && !ctx->g_prefix.empty()) {
+        const size_t last = ctx->g_prefix.size() - 1;
+        r->g_lo = ctx->g_prefix[r->c_lo < last ? r->c_lo : last];
+        r->g_hi = ctx->g_prefix[r->c_hi < last ? r->c_hi : last];
+    }
     return GF_OK;
+}
+// (a context without the prefix table — a view — takes the full order)
+static gangfit::SparseTable shard_sparse(gf_ctx* ctx) {
+    return (ctx->n_g != 0 && !ctx->g_prefix.empty()) ? make_sparse(ctx) : gangfit::SparseTable{};
 }
 
 // ---- the submitting threads (GroupPool, gangfit_ctx.h)
@@ -142,6 +153,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
             set[d].c_lo[q] = r.c_lo;
             set[d].c_hi[q] = r.c_hi;
             set[d].shard[q] = sh;
+            set[d].g_lo[q] = r.g_lo;
+            set[d].g_hi[q] = r.g_hi;
         }
         GF_HIP(g, c->d_apps.reserve(n_apps));
         GF_HIP(g, c->d_results.reserve(n_apps));
@@ -169,7 +182,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         gf_ctx* c = g->group[d];
         if (!GF_STEP(d, hipSetDevice(c->device))) return;
         if (!GF_STEP(d, hipMemcpyAsync(c->d_apps.ptr, g->h_apps.ptr, (size_t)n_apps * sizeof(gf_app), hipMemcpyHostToDevice, c->stream))) return;
-        if (!GF_STEP(d, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), set[d], n_apps, c->d_apps.ptr, c->g_part_loc.ptr,
+        if (!GF_STEP(d, gangfit::launch_shard_partials(algo, make_table(c, c->d_snap.ptr), shard_sparse(c), set[d], n_apps, c->d_apps.ptr, c->g_part_loc.ptr,
                                                        use_rccl ? no_peers : part_all, c->stream)))
             return;
         if (g->g_fault == 2 && d > 0 && !use_rccl) {  // fault injection: this device's capacity sums arrive as zeros everywhere
@@ -200,7 +213,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         gf_ctx* c = g->group[d];
         if (rc_of[d] != GF_OK || !GF_STEP(d, hipSetDevice(c->device))) return;
         if (D > 1 && !use_rccl) wait_others(d, 1);
-        if (!GF_STEP(d, gangfit::launch_shard_emit(algo, make_table(c, c->d_snap.ptr), set[d], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
+        if (!GF_STEP(d, gangfit::launch_shard_emit(algo, make_table(c, c->d_snap.ptr), shard_sparse(c), set[d], n_apps, c->d_apps.ptr, c->g_part_all.ptr,
                                                    c->g_drv_all.ptr, c->d_results.ptr, c->g_exec2.ptr, half, c->stream)))
             return;
         if (D > 1) (void)GF_STEP(d, hipEventRecord(c->g_ev[2], c->stream));
@@ -352,7 +365,7 @@ int gf_shard_partials_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_a
     const int rc = shard_ready(ctx, algo, &r);
     if (rc != GF_OK) return rc;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    GF_HIP(ctx, gangfit::launch_shard_partials(algo, make_table(ctx, ctx->d_snap.ptr), gangfit::shard_set_of(r), n_apps, d_apps, d_out,
+    GF_HIP(ctx, gangfit::launch_shard_partials(algo, make_table(ctx, ctx->d_snap.ptr), shard_sparse(ctx), gangfit::shard_set_of(r), n_apps, d_apps, d_out,
                                                gangfit::PeerPtrs{}, st));
     return GF_OK;
 }
@@ -385,7 +398,7 @@ int gf_shard_emit_dev(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* 
     const int rc = shard_ready(ctx, algo, &r);
     if (rc != GF_OK) return rc;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    GF_HIP(ctx, gangfit::launch_shard_emit(algo, make_table(ctx, ctx->d_snap.ptr), gangfit::shard_set_of(r), n_apps, d_apps, d_all_partials,
+    GF_HIP(ctx, gangfit::launch_shard_emit(algo, make_table(ctx, ctx->d_snap.ptr), shard_sparse(ctx), gangfit::shard_set_of(r), n_apps, d_apps, d_all_partials,
                                            d_all_drivers, d_results, d_exec2, half, st));
     return GF_OK;
 }

@@ -320,6 +320,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
     // ---- sparse gpu view (gangfit::SparseTable): the executor candidates with a free gpu as a compact table of their own,
     //      when they are a minority of the order (merged layout only: the independent kernel's fast path)
     ctx->n_g = ctx->n_gpad = 0;
+    ctx->g_prefix.clear();
     if (mergeable && ctx->sparse_gpu) {
         uint32_t n_g = 0;
         for (uint32_t s2 = 0; s2 < merged.size(); ++s2)
@@ -336,7 +337,9 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
             for (uint32_t i = 0; i < n_gpad; ++i) gnode[i] = GF_NO_NODE;
             for (uint32_t s2 = 0; s2 < n_slots; ++s2) gsub[s2] = GF_NO_NODE;
             uint32_t k = 0;
-            for (uint32_t s2 = 0; s2 < merged.size(); ++s2)
+            ctx->g_prefix.assign((size_t)n_slots / 64u + 2u, n_g);
+            for (uint32_t s2 = 0; s2 < merged.size(); ++s2) {
+                if ((s2 & 63u) == 0u) ctx->g_prefix[s2 >> 6] = k;
                 if ((mflags[s2] & 1) && tgpu[s2] > 0) {
                     g0[k] = tcpu[s2];
                     g0[n_gpad + k] = tmem[s2];
@@ -344,6 +347,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
                     gnode[k] = slot_node[s2];
                     gsub[s2] = k++;
                 }
+            }
             for (int j = 0; j < 3; ++j)
                 for (uint32_t c = 0; c < gch; ++c) {
                     int64_t m = INT64_MIN;
@@ -842,6 +846,7 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         if (zone_of_node) ctx->zone.assign(zone_of_node, zone_of_node + N);
         ctx->n_x = ctx->n_d = n;
         ctx->n_g = ctx->n_gpad = 0;  // the sparse gpu view is built by gf_orders_set only; the full order serves here
+        ctx->g_prefix.clear();
         ctx->n_slots = n_slots;
         ctx->n_chunks = n_chunks;
         ctx->d_identity = true;

@@ -286,6 +286,7 @@ struct gf_ctx {
     PinnedBuf<int64_t> h_gtab;
     PinnedBuf<uint32_t> h_gidx;
     uint32_t n_g = 0, n_gpad = 0;  // sub-slots, padded to whole chunks; 0 = no view
+    std::vector<uint32_t> g_prefix;  // [chunk of the full order] sub-slots before it: where a node-range shard's part of the view begins
     bool sparse_gpu = true;        // option "sparse_gpu" = 0 disables the view
     bool zero_copy = true;         // option "zero_copy" = 0: gf_fit_batch always stages through device buffers
     bool feasible_announce = true; // option "feasible_announce" = 0: gf_fit_feasible waits for the stream instead of watching its answers arrive

@@ -356,10 +356,12 @@ constexpr uint32_t kMaxGroupDevices = 16;
 struct ShardRange {
     uint32_t c_lo, c_hi;
     uint32_t shard, n_shards;
+    uint32_t g_lo, g_hi;  // the range's sub-slots of the sparse gpu view (SparseTable; g_lo == g_hi: none / no view)
 };
 struct ShardSet {  // the shards one device hosts (grid row q of a step's launch handles entry q)
     uint32_t n, n_shards;
     uint32_t c_lo[kMaxGroupDevices], c_hi[kMaxGroupDevices], shard[kMaxGroupDevices];
+    uint32_t g_lo[kMaxGroupDevices], g_hi[kMaxGroupDevices];
 };
 inline ShardSet shard_set_of(const ShardRange& r) {
     ShardSet s{};
@@ -368,6 +370,8 @@ inline ShardSet shard_set_of(const ShardRange& r) {
     s.c_lo[0] = r.c_lo;
     s.c_hi[0] = r.c_hi;
     s.shard[0] = r.shard;
+    s.g_lo[0] = r.g_lo;
+    s.g_hi[0] = r.g_hi;
     return s;
 }
 // Exchanges of the in-process multi-device context: up to 16 peer pointers by value.  The producing kernels write their
@@ -377,14 +381,16 @@ struct PeerPtrs {
     void* p[kMaxGroupDevices];
     uint32_t n;
 };
-hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
-                                 const gf_app* d_apps, gf_shard_partial* d_out, const PeerPtrs& dsts, hipStream_t stream);
+// gpu_view (n_x == 0: none): gangs whose executors need a gpu are summed / emitted from the range's part of the compact table
+hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const ShardSet& set,
+                                 uint32_t n_apps, const gf_app* d_apps, gf_shard_partial* d_out, const PeerPtrs& dsts,
+                                 hipStream_t stream);
 hipError_t launch_shard_drivers(const NodeTable& table, const ShardSet& set, uint32_t n_apps, const gf_app* d_apps,
                                 const gf_shard_partial* d_all_partials, gf_shard_driver* d_out, const PeerPtrs& dsts,
                                 hipStream_t stream);
 // (zeroes d_exec2 first; every hosted shard writes its slice of the ONE buffer, row 0 also the results)
-hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
-                             const gf_app* d_apps, const gf_shard_partial* d_all_partials,
+hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const ShardSet& set,
+                             uint32_t n_apps, const gf_app* d_apps, const gf_shard_partial* d_all_partials,
                              const gf_shard_driver* d_all_drivers, gf_result* d_results, uint32_t* d_exec2, uint64_t half,
                              hipStream_t stream);
 hipError_t launch_shard_finish(gf_algo algo, uint32_t n_shards, uint32_t n_apps, const gf_app* d_apps,

@@ -2330,16 +2330,17 @@ inline dim3 app_grid(uint32_t n_apps) { return dim3((n_apps + kWavesPerBlock - 1
 
 inline dim3 shard_grid(uint32_t n_apps, const ShardSet& set) { return dim3((n_apps + kWavesPerBlock - 1) / kWavesPerBlock, set.n); }
 
-hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
-                                 const gf_app* d_apps, gf_shard_partial* d_out, const PeerPtrs& dsts, hipStream_t stream) {
+hipError_t launch_shard_partials(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const ShardSet& set,
+                                 uint32_t n_apps, const gf_app* d_apps, gf_shard_partial* d_out, const PeerPtrs& dsts,
+                                 hipStream_t stream) {
     if (n_apps == 0 || set.n == 0) return hipSuccess;
     const dim3 block(kWave * kWavesPerBlock);
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_TIGHTLY_PACK>, shard_grid(n_apps, set), block, 0, stream, table, set,
-                           n_apps, d_apps, d_out, dsts);
+        hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_TIGHTLY_PACK>, shard_grid(n_apps, set), block, 0, stream, table, gpu_view,
+                           set, n_apps, d_apps, d_out, dsts);
     else
         hipLaunchKernelGGL(shard_partials_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, shard_grid(n_apps, set), block, 0, stream, table,
-                           set, n_apps, d_apps, d_out, dsts);
+                           gpu_view, set, n_apps, d_apps, d_out, dsts);
     return hipGetLastError();
 }
 
@@ -2352,8 +2353,8 @@ hipError_t launch_shard_drivers(const NodeTable& table, const ShardSet& set, uin
     return hipGetLastError();
 }
 
-hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardSet& set, uint32_t n_apps,
-                             const gf_app* d_apps, const gf_shard_partial* d_all_partials,
+hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const SparseTable& gpu_view, const ShardSet& set,
+                             uint32_t n_apps, const gf_app* d_apps, const gf_shard_partial* d_all_partials,
                              const gf_shard_driver* d_all_drivers, gf_result* d_results, uint32_t* d_exec2, uint64_t half,
                              hipStream_t stream) {
     if (n_apps == 0 || set.n == 0) return hipSuccess;
@@ -2361,11 +2362,11 @@ hipError_t launch_shard_emit(gf_algo algo, const NodeTable& table, const ShardSe
     if (e != hipSuccess) return e;
     const dim3 block(kWave * kWavesPerBlock);
     if (algo == GF_ALGO_TIGHTLY_PACK)
-        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_TIGHTLY_PACK>, shard_grid(n_apps, set), block, 0, stream, table, set,
-                           n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
+        hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_TIGHTLY_PACK>, shard_grid(n_apps, set), block, 0, stream, table, gpu_view,
+                           set, n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
     else
         hipLaunchKernelGGL(shard_emit_kernel<GF_ALGO_DISTRIBUTE_EVENLY>, shard_grid(n_apps, set), block, 0, stream, table,
-                           set, n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
+                           gpu_view, set, n_apps, d_apps, d_all_partials, d_all_drivers, d_results, d_exec2, half);
     return hipGetLastError();
 }
 
