@@ -56,6 +56,38 @@ def test_shards_of_one_gpu_match_oracle(algo, world, n):
                 _assert_same(out, ref, apps)
 
 
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+def test_gpu_gangs_take_the_ranges_part_of_the_compact_view(algo, world):
+    """Clusters whose gpu nodes are a minority (the sparse gpu view exists: gangfit_api_snapshot.cpp) and sit in clumps, so that
+    the shards' parts of the compact table are ragged — empty for some ranges, cut in the middle of a 64-lane chunk for
+    others —, gangs of gpu executors that fit, that do not, and whose driver lands on a gpu node (gangfit_shard.inc)."""
+    rng = np.random.default_rng(777 + 13 * world + algo)
+    seen = [0, 0]  # gangs of gpu executors that fit / that do not
+    for n in (70, 700, 3000):
+        for tight_cluster in (True, False):
+            avail, D, X, drv, exe, k = _random_problem(rng, n, 200, tight_cluster, "merged")
+            # gpus on ~12 % of the nodes, in clumps of the PRIORITY order (X), none anywhere else
+            avail[:, 2] = 0
+            pos = np.arange(len(X))
+            clump = ((pos // max(1, len(X) // 9)) % 3 == 1) & (rng.random(len(X)) < 0.4)
+            nodes = X[clump]
+            nodes = nodes[nodes < n]
+            avail[nodes, 2] = rng.integers(1, 9, size=len(nodes))
+            exe[:, 2] = np.where(rng.random(len(exe)) < 0.7, rng.integers(1, 4, size=len(exe)), 0)
+            drv[:, 2] = np.where(rng.random(len(drv)) < 0.3, 1, 0)
+            small = rng.random(len(k)) < 0.75  # the others keep gang sizes of up to three times the cluster
+            k = np.where(small, np.minimum(k, rng.integers(0, 40, size=len(k))), k).astype(np.int32)
+            apps = gangfit.make_apps(drv, exe, k)
+            ref = ob.fit_independent(algo, avail, ob.make_apps(drv, exe, k), D, X, closed_form=True)
+            gpu_gang = (exe[:, 2] > 0) & (k > 0)
+            seen[0] += int((ref.results["has_capacity"][gpu_gang] != 0).sum())
+            seen[1] += int((ref.results["has_capacity"][gpu_gang] == 0).sum())
+            for out in _run(world, algo, avail, D, X, apps):
+                _assert_same(out, ref, apps)
+    assert seen[0] > 20 and seen[1] > 20
+
+
 def test_general_layout_is_refused():
     with gangfit.Context(0) as ctx:
         ctx.set_snapshot([[5, 5, 0], [5, 5, 0]])
