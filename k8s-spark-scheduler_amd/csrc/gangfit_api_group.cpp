@@ -130,6 +130,8 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         return fail(g, GF_ERR_CAPACITY, "exec_nodes holds %llu entries, %llu needed", (unsigned long long)exec_nodes_cap,
                     (unsigned long long)total_k);
     const uint64_t half = total_k + 1;
+    // what the reduce of the placement buffers carries: its second half (the capacities of pass 1's nodes) is distribute-evenly's
+    const size_t reduce_words = (size_t)(algo == GF_ALGO_DISTRIBUTE_EVENLY ? 2 * half : half);
     GF_HIP(g, g->h_results.reserve(n_apps));
     GF_HIP(g, g->h_exec.reserve(total_k + 1));
     // ---- buffers on every device (growth only: no-ops from the second batch of a size on) and what each device's kernels
@@ -224,7 +226,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
             for (uint32_t s2 = 1; s2 < D; ++s2)
                 if (!GF_STEP(0, hipStreamWaitEvent(first->stream, g->group[s2]->g_ev[2], 0))) return;
             if (g->g_fault != 1 && D > 1)  // fault injection: the other devices' placement slices never arrive
-                if (!GF_STEP(0, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, (size_t)(2 * half), first->stream))) return;
+                if (!GF_STEP(0, gangfit::launch_shard_reduce_pull(exec_others, first->g_exec2.ptr, reduce_words, first->stream))) return;
         }
         if (!GF_STEP(0, gangfit::launch_shard_finish(algo, S, n_apps, first->d_apps.ptr, first->g_part_all.ptr, first->g_drv_all.ptr,
                                                      first->d_results.ptr, first->g_exec2.ptr, half, first->stream)))
@@ -278,7 +280,7 @@ int group_fit_batch(gf_ctx* g, gf_mode mode, gf_algo algo, uint32_t n_apps, cons
         for (uint32_t d = 0; d < D; ++d) {
             gf_ctx* c = g->group[d];
             if (hipSetDevice(c->device) != hipSuccess) bad = 1;
-            bad |= rccl().Reduce(c->g_exec2.ptr, first->g_exec2.ptr, (size_t)(2 * half), Rccl::kUint32, Rccl::kSum, 0, g->g_comms[d], c->stream);
+            bad |= rccl().Reduce(c->g_exec2.ptr, first->g_exec2.ptr, reduce_words, Rccl::kUint32, Rccl::kSum, 0, g->g_comms[d], c->stream);
         }
         if ((rccl().GroupEnd() | bad) != 0) return fail_drained("ncclReduce of the placements failed");
         step_finish();

@@ -209,6 +209,11 @@ class ShardedBatch:
             self.d_apps = engine.upload_apps(self.apps_off)
         self.res = self.exec2 = None
 
+    def _placements(self):
+        """What the all-reduce carries: the placement half of the buffer; the second half (the capacities of pass 1's nodes) is
+        only written and read by distribute-evenly (shard_emit_kernel / shard_finish_kernel)."""
+        return self.exec2 if self.algo == N.GF_ALGO_DISTRIBUTE_EVENLY else self.exec2[: self.half]
+
     def step(self):
         e, c, algo, n = self.engine, self.comm, self.algo, self.n_apps
         with e.stream_context():
@@ -217,7 +222,7 @@ class ShardedBatch:
             drv = e.drivers(algo, self.d_apps, n, all_part)
             all_drv = c.all_gather(drv)
             self.res, self.exec2 = e.emit(algo, self.d_apps, n, all_part, all_drv, self.half)
-            c.all_reduce_sum_(self.exec2)
+            c.all_reduce_sum_(self._placements())
             e.finish(algo, self.d_apps, n, all_part, all_drv, self.res, self.exec2, self.half)
 
     def step_timed(self):
@@ -239,7 +244,7 @@ class ShardedBatch:
             ev[3].record(e.stream)
             self.res, self.exec2 = e.emit(algo, self.d_apps, n, all_part, all_drv, self.half)
             ev[4].record(e.stream)
-            c.all_reduce_sum_(self.exec2)
+            c.all_reduce_sum_(self._placements())
             ev[5].record(e.stream)
             e.finish(algo, self.d_apps, n, all_part, all_drv, self.res, self.exec2, self.half)
         e.stream.synchronize()
