@@ -287,8 +287,10 @@ int gf_fit_batch(gf_ctx *ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
  * signal (a kernel that never answers is noticed after 2 ms through the stream).  No gf_scan_stats counters.  Blocking.  Every packer: the plain ones
  * through fit_independent_kernel's feasibility instantiation, the zone-aware ones through fit_zoned_fused_kernel's (one launch;
  * option "zoned_fused" = 0, more than 63 zones or missing schedulable columns: gf_fit_batch internally, of which only
- * HasCapacity is handed on — as for a multi-device context).  The kernel's placements go to buffers no other entry point uses,
- * so a call that follows on another stream never meets the tail of this one. */
+ * HasCapacity is handed on — as for a multi-device context).  The zone-aware packers' answer is chooseBestResult's (single_az.go:75-97:
+ * some zone fits AND its average Max efficiency is above 0); the averages are only computed where they could be 0 — a driver that asks
+ * for neither cpu nor memory, or a snapshot in which some node's available quantity exceeds its schedulable one.  The kernel's
+ * placements go to buffers no other entry point uses, so a call that follows on another stream never meets the tail of this one. */
 int gf_fit_feasible(gf_ctx *ctx, gf_algo algo, uint32_t n_apps, const gf_app *apps, uint8_t *has_capacity);
 
 /* Incremental FIFO chains.  The reference replays every earlier driver on every Filter (internal/extender/resource.go:309-328);

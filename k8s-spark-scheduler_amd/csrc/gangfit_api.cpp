@@ -30,6 +30,7 @@ int view_refresh(gf_ctx* v) {
     v->n_nodes = p->n_nodes;
     v->have_snapshot = p->have_snapshot;
     v->have_sched = p->have_sched;
+    v->eff_nonneg = p->eff_nonneg;
     v->have_orders = p->have_orders;
     v->n_x = p->n_x;
     v->n_d = p->n_d;

@@ -933,7 +933,7 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
         if (e == hipSuccess)
             e = gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), zt,
                                                 ctx->d_sched.ptr, ctx->d_feas_zexec.ptr, half, n_apps, d_apps, nullptr, nullptr,
-                                                ctx->d_feas_scratch.ptr, half, st, d_feas, ctx->d_feasible_sync.ptr);
+                                                ctx->d_feas_scratch.ptr, half, st, d_feas, ctx->d_feasible_sync.ptr, ctx->eff_nonneg);
     } else {
         e = gangfit::launch_fit_independent(algo, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), n_apps, d_apps, nullptr,
                                             ctx->d_feas_exec.ptr, ctx->d_feas_scratch.ptr, half, nullptr, st, d_feas,

@@ -56,6 +56,13 @@ int gf_snapshot_set(gf_ctx* ctx, uint32_t n_nodes, const int64_t* avail_cpu_mill
                     return fail(ctx, GF_ERR_INVALID, "schedulable[%d][%u] outside [0, 2^62)", j, n);
     ctx->zone.clear();
     ctx->host_stale = false;
+    ctx->eff_nonneg = ctx->have_sched;  // (fit_zoned_fused_kernel's feasibility instantiation: when no efficiency can be negative)
+    for (int j = 0; j < 3 && ctx->eff_nonneg; ++j)
+        for (uint32_t n = 0; n < n_nodes; ++n)
+            if (av[j][n] > sc[j][n]) {
+                ctx->eff_nonneg = false;
+                break;
+            }
     for (int j = 0; j < 3; ++j) {
         ctx->avail[j].assign(av[j], av[j] + n_nodes);
         if (ctx->have_sched)
@@ -858,6 +865,7 @@ int gf_snapshot_build_resident(gf_ctx* ctx, uint32_t n_res, const uint32_t* res_
         ctx->work_valid = false;
         ++ctx->snap_epoch;
         ctx->host_stale = true;
+        ctx->eff_nonneg = false;
         if (driver_order_out || exec_order_out || n_d_out || n_x_out) {  // the two lists, for callers that want them
             GF_HIP(ctx, hipMemcpyAsync(ctx->h_border.ptr, d_perm_b, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             GF_HIP(ctx, gf_wait_stream(st));

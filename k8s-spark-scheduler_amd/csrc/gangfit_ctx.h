@@ -331,6 +331,9 @@ struct gf_ctx {
     uint32_t n_zones = 0, zstride = 0;
     uint32_t zd_row0 = 0;              // row of d_zmasks where the driver masks start (n_zones, or the zone count of a device build)
     bool host_stale = false;           // the host mirrors (avail / sched / h_node_slot) still sit on the device (gf_snapshot_build)
+    // every node's available quantities lie at or below its schedulable ones in the snapshot on the device (gf_snapshot_set checked the
+    // host arrays; a snapshot built on the device leaves it false): then every term of an average packing efficiency is >= 0
+    bool eff_nonneg = false;
     bool snapshot_finalize_on_device = true;  // option "snapshot_finalize_host" = 1 builds the slot tables through gf_orders_set
     int sort_fault = 0;                       // option "sort_fault" (tests): the priority sort's grid barrier cannot complete
     DeviceBuf<gf_result> d_zres;

@@ -295,7 +295,8 @@ hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable
                                   const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, hipStream_t stream, uint8_t* d_feasible = nullptr,
-                                  uint32_t* d_feasible_sync = nullptr);  // (feasibility only: as launch_fit_independent)
+                                  uint32_t* d_feasible_sync = nullptr,  // (feasibility only: as launch_fit_independent)
+                                  bool eff_nonneg = false);  // feasibility only: no node's efficiency can be negative (gf_ctx::eff_nonneg)
 
 // FIFO chain for any packer (zone-aware ones included): one workgroup, one wavefront per candidate view of the current
 // app (each zone, plus the plain pack for az-aware), working table in global memory.  buf.zexec needs

@@ -2101,9 +2101,11 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
 hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const ZoneTable& zones,
                                   const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
-                                  uint64_t scratch_half, hipStream_t stream, uint8_t* d_feasible, uint32_t* d_feasible_sync) {
+                                  uint64_t scratch_half, hipStream_t stream, uint8_t* d_feasible, uint32_t* d_feasible_sync,
+                                  bool eff_nonneg) {
     if (n_apps == 0) return hipSuccess;
     if (d_feasible != nullptr && d_feasible_sync == nullptr) return hipErrorInvalidValue;
+    const uint32_t nonneg = eff_nonneg ? 1u : 0u;
     if (inner_algo != GF_ALGO_TIGHTLY_PACK && inner_algo != GF_ALGO_MINIMAL_FRAGMENTATION) return hipErrorInvalidValue;
     if (az_aware && inner_algo != GF_ALGO_TIGHTLY_PACK) return hipErrorInvalidValue;
     if (zones.n_zones + (az_aware ? 1u : 0u) > 64u) return hipErrorInvalidValue;
@@ -2114,10 +2116,10 @@ hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable
     if (d_feasible != nullptr)                                                                                                  \
         hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, true>), grid_feas, block, 0, stream, table, zones, d_sched, n_apps, \
                            d_apps, reinterpret_cast<gf_result*>(d_feasible), d_feasible_sync, d_zexec, zexec_stride, d_scratch, \
-                           scratch_half);                                                                                       \
+                           scratch_half, nonneg);                                                                               \
     else                                                                                                                        \
         hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, false>), grid, block, 0, stream, table, zones, d_sched, n_apps,     \
-                           d_apps, d_results, d_exec_nodes, d_zexec, zexec_stride, d_scratch, scratch_half)
+                           d_apps, d_results, d_exec_nodes, d_zexec, zexec_stride, d_scratch, scratch_half, 0u)
     if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION) {
         GF_FUSED(GF_ALGO_MINIMAL_FRAGMENTATION, false);
     } else if (az_aware) {

@@ -48,6 +48,45 @@ def test_feasible_zone_aware_packers(gf_ctx, algo):
     assert fits.any()
 
 
+@pytest.mark.parametrize("algo", [3, 4, 5])
+def test_feasible_zone_aware_without_the_averages(gf_ctx, algo):
+    """fit_zoned_fused_kernel's feasibility instantiation skips a zone's average efficiency when it is certainly above 0 (no node's
+    available quantity above its schedulable one — checked by gf_snapshot_set — and a driver that asks for cpu or memory).  The
+    cases around that short cut, each against the full batch (which always computes the averages, single_az.go:75-97):
+    drivers with and without cpu / memory requests, gangs of nothing at all on nodes nobody uses (every efficiency is exactly 0:
+    chooseBestResult's strict '<' turns the application down although it fits), and a snapshot with one node whose available
+    memory exceeds its schedulable memory (the short cut must switch itself off)."""
+    w, s = _congested(1200, 200, 0xFEA9 + algo)
+    zone = (wl.splitmix64(0xA7, len(s.avail), 9) % np.uint64(3)).astype(np.uint32)
+    order = wl.reference_node_order(s.avail, zone)
+    drv, exe, k = w.drv.copy(), w.exe.copy(), w.k.copy()
+    drv[0::5] = 0                  # drivers that ask for nothing
+    drv[1::5, 0] = 0               # ... for memory only
+    drv[2::5, 1] = 0               # ... for cpu only
+    exe[0::10] = 0
+    k[0::10] = 3                   # gangs of nothing at all
+    apps = gangfit.make_apps(drv, exe, k, w.flags)
+    verdicts = []
+    for variant in ("as generated", "empty nodes", "one node above its schedulable memory"):
+        avail, sched = s.avail.copy(), s.sched.copy()
+        if variant == "empty nodes":
+            avail = sched.copy()   # nothing is used anywhere: a gang of nothing has efficiency 0 everywhere
+        elif variant == "one node above its schedulable memory":
+            avail[order[0], 1] = sched[order[0], 1] + 1
+        gf_ctx.set_snapshot(avail, sched)
+        gf_ctx.set_zones(zone)
+        gf_ctx.set_orders(order, order)
+        fits = gf_ctx.fit_feasible(algo, apps)
+        full = gf_ctx.fit_batch(IND, algo, apps)
+        assert np.array_equal(fits, full.results["has_capacity"].astype(bool)), variant
+        verdicts.append(fits)
+    # the quirk is there: on empty nodes the gangs of nothing with a driver of nothing are turned down
+    nothing = (~drv.any(axis=1)) & (~exe.any(axis=1))
+    assert nothing.any() and verdicts[1][~nothing].any()
+    if algo != 3:  # (az-aware-tightly-pack falls back to the plain placement when no zone is chosen: az_aware_pack_tightly.go:33-37)
+        assert not verdicts[1][nothing].any()
+
+
 def test_feasible_rejects_what_the_batch_rejects(gf_ctx):
     w, s = _congested(64, 4, 3)
     gf_ctx.set_snapshot(s.avail, s.sched)
