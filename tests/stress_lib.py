@@ -68,13 +68,17 @@ def one_seed(ctxs, seed):
     oapps = ob.make_apps(drv, exe, k, flags)
     where = f"seed={seed} n={n} a={a} layout={layout} tight={tight} nz={nz} kcap={kcap}"
     cases = 0
+    ind_refs = {}  # the literal oracle's answer for the independent batch, once per packer: the contexts share the inputs (its
+    #                driver retry loop is O(|D| N) per gang that does not fit — seed 61038: 44 s per pass over the six packers)
     for cname, ctx in ctxs.items():
         ctx.set_snapshot(avail, sched)
         ctx.set_zones(zone)
         ctx.set_orders(D, X)
         for algo in ALGOS:
             gpu = ctx.fit_batch(0, algo, apps)
-            ref = ob.fit_independent(algo, avail, oapps, D, X, sched=sched, zone=zone)
+            if algo not in ind_refs:
+                ind_refs[algo] = ob.fit_independent(algo, avail, oapps, D, X, sched=sched, zone=zone)
+            ref = ind_refs[algo]
             bad = same(gpu, ref, False)
             if bad is None and algo in (0, 1, 2) and cname == "default":  # the same batch as a ticket of the resident worker
                 wk = ctx.worker_fit(algo, apps)
