@@ -136,13 +136,18 @@ class ThreadComm(Comm):
 
 
 # ------------------------------------------------------------------------------------------------ the HIP engine
+_first_look = threading.Lock()
+
+
 class HipShardEngine:
     """The four device steps through the C ABI, on torch device tensors (torch only owns memory and the stream)."""
 
     def __init__(self, ctx: Context, shard: int, n_shards: int, device):
         import torch
 
-        if not torch.cuda.is_available():
+        with _first_look:  # (one thread at a time: shards of one device as a thread group may all get here first)
+            have_gpu = torch.cuda.is_available()
+        if not have_gpu:
             raise RuntimeError("HipShardEngine needs an MI355X: the HIP path is the only product path")
         self.ctx = ctx
         self.device = torch.device(device)

@@ -20,6 +20,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(world, algo, avail, D, X, apps):
+    import torch
+
+    # the HIP runtime and torch's device count are initialised HERE, by one thread: `world` threads that meet in the first
+    # torch.cuda.is_available() of a process — next to the first gf_init of their siblings — have seen "no device" on the MI355X box
+    # (tools/stress_sharded.py when its first seed drew eight shards: gpurun_out/r6av, r6aw), and torch caches that answer
+    torch.cuda.init()
     group = sharded.ThreadGroup(world)
     outs, errs = [None] * world, []
 
