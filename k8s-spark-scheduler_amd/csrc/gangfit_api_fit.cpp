@@ -46,6 +46,8 @@ gangfit::SparseTable make_sparse(gf_ctx* ctx) {
     g.xmask = ctx->d_gmask.ptr;
     g.n_x = ctx->n_g;
     g.n_chunks = ctx->n_gpad / 64;
+    g.zmask = g.xmask + g.n_chunks;
+    g.slot_of_sub = g.sub_of_slot + ctx->n_slots;
     return g;
 }
 
@@ -343,7 +345,7 @@ int launch_zoned(gf_ctx* ctx, gf_mode mode, gf_algo algo, uint32_t n_apps, const
         GF_HIP(ctx, ctx->d_zexec.reserve(((uint64_t)nz + 1) * half));
         gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)ctx->zd_row0 * ctx->zstride, nz, ctx->zstride};
         if (const int arc = apps_to_device(ctx, stream); arc != GF_OK) return arc;
-        GF_HIP(ctx, gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), zt,
+        GF_HIP(ctx, gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), zt,
                                                     ctx->d_sched.ptr, ctx->d_zexec.ptr, half, n_apps, d_apps, d_results,
                                                     d_exec_nodes, ctx->d_scratch.ptr, half, stream));
         return GF_OK;
@@ -931,7 +933,7 @@ int gf_fit_feasible(gf_ctx* ctx, gf_algo algo, uint32_t n_apps, const gf_app* ap
         e = ctx->d_feas_zexec.reserve(((uint64_t)nz + 1) * half);
         gangfit::ZoneTable zt{ctx->d_zmasks.ptr, ctx->d_zmasks.ptr + (size_t)ctx->zd_row0 * ctx->zstride, nz, ctx->zstride};
         if (e == hipSuccess)
-            e = gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), zt,
+            e = gangfit::launch_fit_zoned_fused(inner, algo == GF_ALGO_AZ_AWARE_TIGHTLY_PACK, make_table(ctx, ctx->d_snap.ptr), make_sparse(ctx), zt,
                                                 ctx->d_sched.ptr, ctx->d_feas_zexec.ptr, half, n_apps, d_apps, nullptr, nullptr,
                                                 ctx->d_feas_scratch.ptr, half, st, d_feas, ctx->d_feasible_sync.ptr, ctx->eff_nonneg);
     } else {

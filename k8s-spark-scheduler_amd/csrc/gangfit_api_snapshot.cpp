@@ -335,13 +335,15 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         if (n_g > 0 && (uint64_t)n_g * 4 <= merged.size()) {
             const uint32_t n_gpad = (n_g + 63u) / 64u * 64u, gch = n_gpad / 64u;
             GF_HIP(ctx, ctx->h_gtab.reserve(3 * (size_t)n_gpad + 3 * (size_t)gch));
-            GF_HIP(ctx, ctx->h_gidx.reserve((size_t)n_gpad + n_slots));
+            GF_HIP(ctx, ctx->h_gidx.reserve(2 * (size_t)n_gpad + n_slots));
             int64_t* g0 = ctx->h_gtab.ptr;
             int64_t* gmax = g0 + 3 * (size_t)n_gpad;
             uint32_t* gnode = ctx->h_gidx.ptr;
             uint32_t* gsub = gnode + n_gpad;
+            uint32_t* gslot = gsub + n_slots;  // sub-slot -> slot (SparseTable::slot_of_sub; the padding names the sentinel slot)
             for (uint32_t i = 0; i < 3 * n_gpad; ++i) g0[i] = kSentinelAvail;
             for (uint32_t i = 0; i < n_gpad; ++i) gnode[i] = GF_NO_NODE;
+            for (uint32_t i = 0; i < n_gpad; ++i) gslot[i] = n_slots - 1u;
             for (uint32_t s2 = 0; s2 < n_slots; ++s2) gsub[s2] = GF_NO_NODE;
             uint32_t k = 0;
             ctx->g_prefix.assign((size_t)n_slots / 64u + 2u, n_g);
@@ -352,6 +354,7 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
                     g0[n_gpad + k] = tmem[s2];
                     g0[2 * (size_t)n_gpad + k] = tgpu[s2];
                     gnode[k] = slot_node[s2];
+                    gslot[k] = s2;
                     gsub[s2] = k++;
                 }
             }
@@ -363,16 +366,12 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
                 }
             GF_HIP(ctx, ctx->d_gtab.reserve(3 * (size_t)n_gpad));
             GF_HIP(ctx, ctx->d_gcmax.reserve(3 * (size_t)gch));
-            GF_HIP(ctx, ctx->d_gidx.reserve((size_t)n_gpad + n_slots));
-            GF_HIP(ctx, ctx->d_gmask.reserve(gch));
+            GF_HIP(ctx, ctx->d_gidx.reserve(2 * (size_t)n_gpad + n_slots));
             GF_HIP(ctx, hipMemcpyAsync(ctx->d_gtab.ptr, g0, 3 * (size_t)n_gpad * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
             GF_HIP(ctx, hipMemcpyAsync(ctx->d_gcmax.ptr, gmax, 3 * (size_t)gch * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gidx.ptr, gnode, ((size_t)n_gpad + n_slots) * sizeof(uint32_t), hipMemcpyHostToDevice,
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gidx.ptr, gnode, (2 * (size_t)n_gpad + n_slots) * sizeof(uint32_t), hipMemcpyHostToDevice,
                                        ctx->stream));
-            std::vector<uint64_t> gm(gch, 0);
-            for (uint32_t i = 0; i < n_g; ++i) gm[i >> 6] |= 1ull << (i & 63);
-            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gmask.ptr, gm.data(), gch * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-            GF_HIP(ctx, gf_wait_stream(ctx->stream));  // gm is a local
+            // (the candidate words of the view — all sub-slots, then one row per zone of the evaluation list — follow the zone views below)
             ctx->n_g = n_g;
             ctx->n_gpad = n_gpad;
         }
@@ -442,6 +441,20 @@ int gf_orders_set(gf_ctx* ctx, const uint32_t* driver_order, uint32_t n_d, const
         ctx->n_zones = nz;
         ctx->zstride = zstride;
         ctx->zd_row0 = nz;
+        if (ctx->n_g != 0) {  // SparseTable::xmask (row 0: every sub-slot) and ::zmask (row 1 + zi: the sub-slots of zone eval[zi])
+            const uint32_t gch = ctx->n_gpad / 64u;
+            const uint32_t* gnode = ctx->h_gidx.ptr;
+            std::vector<uint64_t> gm((size_t)gch * (1u + nz), 0);
+            for (uint32_t i = 0; i < ctx->n_g; ++i) {
+                gm[i >> 6] |= 1ull << (i & 63);
+                const uint32_t z = zone_of(gnode[i]);
+                for (uint32_t zi = 0; zi < nz; ++zi)
+                    if (eval[zi] == z) gm[(size_t)gch * (1u + zi) + (i >> 6)] |= 1ull << (i & 63);
+            }
+            GF_HIP(ctx, ctx->d_gmask.reserve(gm.size()));
+            GF_HIP(ctx, hipMemcpyAsync(ctx->d_gmask.ptr, gm.data(), gm.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+            GF_HIP(ctx, gf_wait_stream(ctx->stream));  // gm is a local
+        }
     }
     GF_HIP(ctx, gf_wait_stream(ctx->stream));
     ctx->n_x = n_x_slots;

@@ -62,6 +62,9 @@ struct SparseTable {
     const uint32_t* sub_of_slot;  // [n_slots of the full table] slot -> sub-slot, GF_NO_NODE when the slot is not in the view
     uint32_t n_x;                 // sub-slots (0 = no sparse view: the kernel uses the full table)
     uint32_t n_chunks;
+    // the zone packers' one-launch kernel (fit_zoned_fused_kernel) packs a zone's gangs of gpu executors from the view too:
+    const uint64_t* zmask;        // [n_zones of the evaluation list][n_chunks] the sub-slots whose node lies in the zone
+    const uint32_t* slot_of_sub;  // [n_sub + pad] sub-slot -> slot of the full table (its placements are slot ids)
 };
 
 // Zone view of the two candidate orders for the single-AZ packers (LIB/binpack/single_az.go:23-72): zone zi of the
@@ -291,7 +294,7 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
 // The same as ONE launch (fit_zoned_fused_kernel): a workgroup per application, a wavefront per candidate view, the choice
 // through LDS, the winner's placements written as node indices to d_exec_nodes / d_results — which may be device-mapped host
 // memory.  d_zexec: (n_zones + 1) rows of zexec_stride uint32 (the candidates' placements as slot ids).  At most 64 views.
-hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const ZoneTable& zones,
+hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const SparseTable& gpu_view, const ZoneTable& zones,
                                   const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, hipStream_t stream, uint8_t* d_feasible = nullptr,

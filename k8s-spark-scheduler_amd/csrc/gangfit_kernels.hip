@@ -377,6 +377,13 @@ struct Orders {
 #ifdef GF_MF_PROBE  // experiment build: where a minimal-fragmentation decision's cycles go (summed over the launch's applications)
     unsigned long long* mf_probe = nullptr;
 #endif
+    // Run capture (fit_zoned_fused_kernel): a tightly-pack placement leaves the scan as its RUNS — (what a placement names, index
+    // of the run's first executor) pairs in LDS words private to the calling wavefront — instead of K expanded entries in global
+    // memory: word 0 = runs so far (it may exceed run_cap_max: the pairs beyond are not stored and the caller decides again,
+    // expanded), then run_cap_max ids, then run_cap_max first indices.
+    lds_u32h* run_cap = nullptr;
+    uint32_t run_cap_max = 0;
+    bool run_cap_on = false;  // (an LDS array may sit at LDS address 0, which compares equal to nullptr)
     __device__ __forceinline__ void lend_minfrag(lds_u32h* lds, const NodeTable& T) {
         mf_hist = lds;
         mf_lent = true;
@@ -420,6 +427,19 @@ __device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t st
         const uint32_t v = read_lane(id, src);
         for (int32_t i = lane; i < n; i += kWave) put_out(out + s + i, v, wt);
     }
+}
+
+// emit_runs for a caller that wants the runs themselves (Orders::run_cap)
+__device__ __forceinline__ void capture_runs(const Orders& O, int64_t start, int32_t t, uint32_t id, int lane) {
+    const uint64_t tm = (uint64_t)__builtin_amdgcn_sicmp(t, 0, 38);  // lanes with t > 0
+    if (tm == 0ull) return;
+    const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)O.run_cap[0]);
+    const uint32_t idx = have + (uint32_t)__popcll((unsigned long long)(tm & ((1ull << lane) - 1ull)));
+    if (t > 0 && idx < O.run_cap_max) {
+        O.run_cap[1u + idx] = id;
+        O.run_cap[1u + O.run_cap_max + idx] = (uint32_t)start;
+    }
+    if (lane == 0) O.run_cap[0] = have + (uint32_t)__popcll((unsigned long long)tm);
 }
 
 __device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t width) {
@@ -630,7 +650,10 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
                 const int64_t room = K - start;
                 const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
                 const uint32_t id = SLOTS ? j : node;
-                emit_runs(out, start, t, id, lane, wt);
+                if (O.run_cap_on)
+                    capture_runs(O, start, t, id, lane);
+                else
+                    emit_runs(out, start, t, id, lane, wt);
             }
             taken += tot;
             if (taken >= K) return taken;
@@ -669,7 +692,10 @@ __device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const 
         const int64_t start = taken + (int64_t)(incl - cp);
         const int64_t room = K - start;
         const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
-        emit_runs(out, start, t, id, lane, wt);
+        if (O.run_cap_on)
+            capture_runs(O, start, t, id, lane);
+        else
+            emit_runs(out, start, t, id, lane, wt);
         taken += tot;
         return taken >= K;
     };
@@ -903,6 +929,7 @@ __device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, con
                                              uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
                                              unsigned long long& xvis, const ScanPre& pre = ScanPre(), const bool wt = false) {
     if (ALGO == GF_ALGO_TIGHTLY_PACK) {  // (wt: tightly-pack only — the other packers' callers never set it)
+        if (O.run_cap_on && lane == 0) O.run_cap[0] = 0;  // every pack starts its run list anew
         if constexpr (HasCompactScan<View>::value)
             return wave_tight_scan_compact<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre, wt);
         else
@@ -965,6 +992,7 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
     const bool sparse = gpu_view != nullptr && gpu_view->n_x != 0 && app.exe2 > 0 && K > 0 && O.d_identity &&
                         (ALGO == GF_ALGO_TIGHTLY_PACK || ALGO == GF_ALGO_DISTRIBUTE_EVENLY);
     uint32_t p0_sub = GF_NO_NODE;
+    bool p0_sub_known = false;  // the driver came from the first step below, which looked its sub-slot up on the way
     if (O.d_identity && ALGO != GF_ALGO_MINIMAL_FRAGMENTATION) {
         // Merged layout (driver position == slot): the chunk masks of group 0 for BOTH roles in one round trip (the
         // maxima are the same words), then the first candidate chunk of both roles — and the node ids — in one more.
@@ -1014,6 +1042,7 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
                 p0 = (int64_t)bd * kWave + fl;
                 p0_node = read_lane(dnode, fl);
                 p0_sub = read_lane(dsub, fl);
+                p0_sub_known = true;
             }
             from = ((uint32_t)bd + 1) * kWave;
         }
@@ -1032,16 +1061,21 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
         return dec;
     }
     int64_t pass1 = 0;
-    if constexpr (std::is_same<View, GlobalView>::value && !SLOTS) {
+    // (SLOTS callers — the zone packers' one-launch kernel — hand in a view whose `slot_node` names SLOTS of the full table and whose
+    //  candidate words are the zone's)
+    if constexpr (std::is_same<View, GlobalView>::value) {
         if (sparse) {
             // (2s) the same pack over the compact table of gpu nodes.  S_s = the capacity total with the driver reserved,
             //      exactly what the full order would give (every node left out has capacity 0 for this request).
-            if (p0_node == GF_NO_NODE) p0_sub = gpu_view->sub_of_slot[ds];  // the driver came from the generic search
+            if (!p0_sub_known) p0_sub = gpu_view->sub_of_slot[ds];  // the driver came from the generic search
             const GlobalView VS{const_cast<int64_t*>(gpu_view->cpu), const_cast<int64_t*>(gpu_view->mem),
                                 const_cast<int64_t*>(gpu_view->gpu), gpu_view->cmax, gpu_view->cmax + gpu_view->n_chunks,
                                 gpu_view->cmax + 2 * (size_t)gpu_view->n_chunks, gpu_view->xmask, gpu_view->xmask,
                                 gpu_view->n_chunks};
-            const Orders OS{gpu_view->slot_node, nullptr, gpu_view->n_x, 0u, true};
+            Orders OS{gpu_view->slot_node, nullptr, gpu_view->n_x, 0u, true};
+            OS.run_cap = O.run_cap;
+            OS.run_cap_max = O.run_cap_max;
+            OS.run_cap_on = O.run_cap_on;
             const int64_t S_s = wave_pack<ALGO, GlobalView, false>(VS, OS, app, p0_sub, out, scratch_a, scratch_b, lane, pass1,
                                                                    xvis, ScanPre(), wt);
             if (S_s >= K) {
@@ -2098,7 +2132,7 @@ hipError_t launch_fit_zoned(int inner_algo, bool az_aware, bool reserve_execs, c
     return hipGetLastError();
 }
 
-hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const ZoneTable& zones,
+hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable& table, const SparseTable& gpu_view, const ZoneTable& zones,
                                   const int64_t* d_sched, uint32_t* d_zexec, uint64_t zexec_stride, uint32_t n_apps,
                                   const gf_app* d_apps, gf_result* d_results, uint32_t* d_exec_nodes, uint32_t* d_scratch,
                                   uint64_t scratch_half, hipStream_t stream, uint8_t* d_feasible, uint32_t* d_feasible_sync,
@@ -2114,11 +2148,11 @@ hipError_t launch_fit_zoned_fused(int inner_algo, bool az_aware, const NodeTable
     // as for launch_fit_independent
 #define GF_FUSED(ALGO, AZ)                                                                                                      \
     if (d_feasible != nullptr)                                                                                                  \
-        hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, true>), grid_feas, block, 0, stream, table, zones, d_sched, n_apps, \
+        hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, true>), grid_feas, block, 0, stream, table, gpu_view, zones, d_sched, n_apps, \
                            d_apps, reinterpret_cast<gf_result*>(d_feasible), d_feasible_sync, d_zexec, zexec_stride, d_scratch, \
                            scratch_half, nonneg);                                                                               \
     else                                                                                                                        \
-        hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, false>), grid, block, 0, stream, table, zones, d_sched, n_apps,     \
+        hipLaunchKernelGGL((fit_zoned_fused_kernel<ALGO, AZ, false>), grid, block, 0, stream, table, gpu_view, zones, d_sched, n_apps,     \
                            d_apps, d_results, d_exec_nodes, d_zexec, zexec_stride, d_scratch, scratch_half, 0u)
     if (inner_algo == GF_ALGO_MINIMAL_FRAGMENTATION) {
         GF_FUSED(GF_ALGO_MINIMAL_FRAGMENTATION, false);

@@ -317,3 +317,65 @@ def test_zoned_fifo_chain_equal_zones_take_the_exact_sums(gf_ctx, nz):
                 assert np.array_equal(gf_ctx.residual(), ref.avail_after)
             if variant == "equal":
                 assert ref.results["has_capacity"].any()
+
+
+@pytest.mark.parametrize("algo", [SAZ, AZA])
+@pytest.mark.parametrize("n_zones", [1, 3, 5])
+@pytest.mark.parametrize("n", [70, 700, 3000])
+def test_zone_views_of_the_compact_gpu_table(algo, n_zones, n):
+    """One-launch zone kernel on clusters whose gpu nodes are a minority (the compact gpu view exists: a zone's gangs of gpu executors
+    are packed from the zone's sub-slots of it, placements as slots of the full table) — gangs that fit in one zone, in none, drivers
+    on gpu nodes and elsewhere, against the oracle and against the same context without the view; the averages bit for bit."""
+    rng = np.random.default_rng(7001 + 13 * algo + n_zones + n)
+    for layout in ("merged", "identical"):
+        for tight_cluster in (True, False):
+            avail, sched, zone, D, X, drv, exe, k = _zoned_problem(rng, n, 140, tight_cluster, layout, n_zones)
+            frac = float(rng.choice([0.05, 0.12, 0.2]))
+            has = rng.random(n) < frac
+            avail[:, 2] = np.where(has, rng.integers(1, 9, size=n), rng.integers(-1, 1, size=n))
+            sched[:, 2] = np.maximum(avail[:, 2], 0) + rng.integers(0, 3, size=n)
+            exe[:, 2] = np.where(rng.random(len(exe)) < 0.7, rng.integers(1, 4, size=len(exe)), 0)
+            drv[:, 2] = np.where(rng.random(len(drv)) < 0.3, 1, 0)
+            k = np.where(rng.random(len(k)) < 0.7, np.minimum(k, rng.integers(0, 30, size=len(k))), k).astype(np.int32)
+            apps = gangfit.make_apps(drv, exe, k)
+            ref = ob.fit_independent(O_ALGO[algo], avail, ob.make_apps(drv, exe, k), D, X, closed_form=True, sched=sched, zone=zone)
+            for opts in ({}, {"sparse_gpu": 0}):
+                with gangfit.Context(0, options=opts) as ctx:
+                    _setup(ctx, avail, sched, zone, D, X)
+                    gpu = ctx.fit_batch(IND, algo, apps)
+                    _assert_same(gpu, ref, apps)
+                    assert np.array_equal(_bits(ctx.avg_packing_efficiency(algo, apps, gpu)), _bits(ref.avg_eff))
+                    fits = ctx.fit_feasible(algo, apps)
+                    assert np.array_equal(fits, np.asarray(ref.results["has_capacity"]).astype(bool))
+
+
+@pytest.mark.parametrize("algo", [SAZ, AZA])
+def test_long_gangs_take_the_run_averages(gf_ctx, algo):
+    """Gangs of 1 .. 700 executors on nodes that take 1 .. 40 of them: placements of a few runs and of more than 63 (the entry-wise
+    averages), more than 512 executors (the same), the driver's node inside the list and outside — the choice between the zones
+    is made on float64 sums that must come out bit for bit."""
+    rng = np.random.default_rng(9100 + algo)
+    n, a = 2000, 160
+    sched = np.zeros((n, 3), dtype=np.int64)
+    sched[:, 0] = rng.integers(8, 65, size=n) * 1000
+    sched[:, 1] = rng.integers(16, 257, size=n) * GIB
+    used = rng.random((n, 2)) * 0.6
+    avail = sched.copy()
+    avail[:, 0] -= (used[:, 0] * sched[:, 0]).astype(np.int64) // 250 * 250
+    avail[:, 1] -= (used[:, 1] * sched[:, 1]).astype(np.int64)
+    zone = rng.integers(0, 3, size=n).astype(np.uint32)
+    order = wl.reference_node_order(avail, zone)
+    drv = np.zeros((a, 3), dtype=np.int64)
+    exe = np.zeros((a, 3), dtype=np.int64)
+    drv[:, 0] = rng.integers(1, 5, size=a) * 500
+    drv[:, 1] = rng.integers(1, 9, size=a) * GIB
+    exe[:, 0] = rng.integers(1, 9, size=a) * 250
+    exe[:, 1] = rng.integers(1, 17, size=a) * (GIB // 2)
+    k = rng.choice([1, 2, 7, 40, 64, 65, 130, 300, 511, 512, 513, 700], size=a).astype(np.int32)
+    _setup(gf_ctx, avail, sched, zone, order, order)
+    apps = gangfit.make_apps(drv, exe, k)
+    gpu = gf_ctx.fit_batch(IND, algo, apps)
+    ref = ob.fit_independent(O_ALGO[algo], avail, ob.make_apps(drv, exe, k), order, order, closed_form=True, sched=sched, zone=zone)
+    _assert_same(gpu, ref, apps)
+    assert np.array_equal(_bits(gf_ctx.avg_packing_efficiency(algo, apps, gpu)), _bits(ref.avg_eff))
+    assert ref.results["has_capacity"].mean() > 0.5
