@@ -377,13 +377,6 @@ struct Orders {
 #ifdef GF_MF_PROBE  // experiment build: where a minimal-fragmentation decision's cycles go (summed over the launch's applications)
     unsigned long long* mf_probe = nullptr;
 #endif
-    // Run capture (fit_zoned_fused_kernel): a tightly-pack placement leaves the scan as its RUNS — (what a placement names, index
-    // of the run's first executor) pairs in LDS words private to the calling wavefront — instead of K expanded entries in global
-    // memory: word 0 = runs so far (it may exceed run_cap_max: the pairs beyond are not stored and the caller decides again,
-    // expanded), then run_cap_max ids, then run_cap_max first indices.
-    lds_u32h* run_cap = nullptr;
-    uint32_t run_cap_max = 0;
-    bool run_cap_on = false;  // (an LDS array may sit at LDS address 0, which compares equal to nullptr)
     __device__ __forceinline__ void lend_minfrag(lds_u32h* lds, const NodeTable& T) {
         mf_hist = lds;
         mf_lent = true;
@@ -427,19 +420,6 @@ __device__ __forceinline__ void emit_runs(uint32_t* __restrict__ out, int64_t st
         const uint32_t v = read_lane(id, src);
         for (int32_t i = lane; i < n; i += kWave) put_out(out + s + i, v, wt);
     }
-}
-
-// emit_runs for a caller that wants the runs themselves (Orders::run_cap)
-__device__ __forceinline__ void capture_runs(const Orders& O, int64_t start, int32_t t, uint32_t id, int lane) {
-    const uint64_t tm = (uint64_t)__builtin_amdgcn_sicmp(t, 0, 38);  // lanes with t > 0
-    if (tm == 0ull) return;
-    const uint32_t have = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)O.run_cap[0]);
-    const uint32_t idx = have + (uint32_t)__popcll((unsigned long long)(tm & ((1ull << lane) - 1ull)));
-    if (t > 0 && idx < O.run_cap_max) {
-        O.run_cap[1u + idx] = id;
-        O.run_cap[1u + O.run_cap_max + idx] = (uint32_t)start;
-    }
-    if (lane == 0) O.run_cap[0] = have + (uint32_t)__popcll((unsigned long long)tm);
 }
 
 __device__ __forceinline__ uint32_t chunk_len(uint32_t n, uint32_t b, uint32_t width) {
@@ -650,10 +630,7 @@ __device__ __forceinline__ int64_t wave_tight_scan(const View& V, const Orders& 
                 const int64_t room = K - start;
                 const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
                 const uint32_t id = SLOTS ? j : node;
-                if (O.run_cap_on)
-                    capture_runs(O, start, t, id, lane);
-                else
-                    emit_runs(out, start, t, id, lane, wt);
+                emit_runs(out, start, t, id, lane, wt);
             }
             taken += tot;
             if (taken >= K) return taken;
@@ -692,10 +669,7 @@ __device__ __forceinline__ int64_t wave_tight_scan_compact(const View& V, const 
         const int64_t start = taken + (int64_t)(incl - cp);
         const int64_t room = K - start;
         const int32_t t = room <= 0 ? 0 : (room < (int64_t)cp ? (int32_t)room : cp);
-        if (O.run_cap_on)
-            capture_runs(O, start, t, id, lane);
-        else
-            emit_runs(out, start, t, id, lane, wt);
+        emit_runs(out, start, t, id, lane, wt);
         taken += tot;
         return taken >= K;
     };
@@ -929,7 +903,6 @@ __device__ __forceinline__ int64_t wave_pack(const View& V, const Orders& O, con
                                              uint32_t* __restrict__ scratch_b, int lane, int64_t& pass1,
                                              unsigned long long& xvis, const ScanPre& pre = ScanPre(), const bool wt = false) {
     if (ALGO == GF_ALGO_TIGHTLY_PACK) {  // (wt: tightly-pack only — the other packers' callers never set it)
-        if (O.run_cap_on && lane == 0) O.run_cap[0] = 0;  // every pack starts its run list anew
         if constexpr (HasCompactScan<View>::value)
             return wave_tight_scan_compact<View, SLOTS>(V, O, app, ds, out, lane, xvis, pre, wt);
         else
@@ -1072,10 +1045,7 @@ __device__ __forceinline__ Decision wave_decide(const View& V, const Orders& O, 
                                 const_cast<int64_t*>(gpu_view->gpu), gpu_view->cmax, gpu_view->cmax + gpu_view->n_chunks,
                                 gpu_view->cmax + 2 * (size_t)gpu_view->n_chunks, gpu_view->xmask, gpu_view->xmask,
                                 gpu_view->n_chunks};
-            Orders OS{gpu_view->slot_node, nullptr, gpu_view->n_x, 0u, true};
-            OS.run_cap = O.run_cap;
-            OS.run_cap_max = O.run_cap_max;
-            OS.run_cap_on = O.run_cap_on;
+            const Orders OS{gpu_view->slot_node, nullptr, gpu_view->n_x, 0u, true};
             const int64_t S_s = wave_pack<ALGO, GlobalView, false>(VS, OS, app, p0_sub, out, scratch_a, scratch_b, lane, pass1,
                                                                    xvis, ScanPre(), wt);
             if (S_s >= K) {
