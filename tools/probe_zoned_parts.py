@@ -1,5 +1,5 @@
-"""Where the one-launch zone kernel's time goes (fit_zoned_fused_kernel, single-az-tightly-pack, 10 000 nodes x 1 000 applications,
-three zones, AZ-major order): the same batch with parts taken away — no gpu requests, one executor per gang, no executors, subsets
+"""Where an independent batch's time goes (default: the one-launch zone kernel, fit_zoned_fused_kernel; any packer's name as an argument;
+10 000 nodes x 1 000 applications, three zones, AZ-major order): the same batch with parts taken away — no gpu requests, one executor per gang, no executors, subsets
 of the batch — device time between HIP events, with the plain packer beside it.  Run on the MI355X box."""
 import os
 import sys
@@ -37,9 +37,18 @@ def variants():
     big = k > 40
     yield f"only the {int(big.sum())} gangs of more than 40", drv[big], exe[big], k[big], fl[big]
     yield "one application", drv[:1], exe[:1], k[:1], fl[:1]
+    for lo, hi in ((0, 250), (250, 500), (500, 750), (750, 1000)):
+        yield f"applications {lo}..{hi}", drv[lo:hi], exe[lo:hi], k[lo:hi], fl[lo:hi]
+    order = np.argsort(k, kind="stable")
+    for lo, hi in ((0, 500), (500, 900), (900, 1000)):
+        sel = order[lo:hi]
+        yield f"K rank {lo}..{hi} (K {int(k[sel].min())}..{int(k[sel].max())})", drv[sel], exe[sel], k[sel], fl[sel]
 
 
-for name, algo, zoned in (("tightly-pack", 0, False), ("single-az-tightly-pack", 4, True), ("az-aware-tightly-pack", 3, True)):
+ALL = (("tightly-pack", 0, False), ("single-az-tightly-pack", 4, True), ("az-aware-tightly-pack", 3, True),
+       ("minimal-fragmentation", 2, False), ("single-az-minimal-fragmentation", 5, True), ("distribute-evenly", 1, False))
+want = sys.argv[1:] or ["tightly-pack", "single-az-tightly-pack", "az-aware-tightly-pack"]
+for name, algo, zoned in [x for x in ALL if x[0] in want]:
     ctx = gangfit.Context(0)
     ctx.set_snapshot(s.avail, s.sched)
     if zoned:
