@@ -20,6 +20,8 @@ w = wl.headline(n_nodes, n_apps)
 s = w.snapshot
 zone = (wl.splitmix64(0xA3, n_nodes, 9) % np.uint64(nz)).astype(np.uint32)
 zorder = wl.reference_node_order(s.avail, zone)
+if os.environ.get("PROBE_ORDER") == "scattered":  # every zone has candidates in every 64-chunk group of the order (no extender orders nodes so)
+    zorder = s.exec_order
 dev = torch.device("cuda", 0)
 
 
