@@ -1,0 +1,8 @@
+set -u
+cd $GRAFT_REPO_ROOT
+export GPU_MAX_HW_QUEUES=16
+OUT=gpurun_out/r6be; mkdir -p $OUT
+timeout 200 python tools/probe_zoned_batch.py > $OUT/zoned_batch.txt 2>&1; echo "batch rc=$?"; grep "minimal-frag" $OUT/zoned_batch.txt
+timeout 300 python tools/probe_zoned_parts.py minimal-fragmentation > $OUT/parts.txt 2>&1; echo "parts rc=$?"; grep -v amdgpu $OUT/parts.txt | head -8
+timeout 900 python -m pytest tests/test_gpu_minfrag.py tests/test_gpu_feasible.py tests/test_gpu_parity.py -m gpu -q -x > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest.log
+timeout 400 python tools/stress_parity.py 200 69001 > $OUT/stress200.txt 2>&1; echo "stress rc=$?"; tail -1 $OUT/stress200.txt
